@@ -1,0 +1,457 @@
+"""CPU oracle for the AR-DAE-VAE inner training loop  --  TEST INFRASTRUCTURE ONLY.
+
+This module is a plain-PyTorch (CPU, autograd) restatement of the reference's
+hot path.  It is the *checker* for the HIP kernels and the `cpu_baseline` leg of
+bench.py; nothing under `pytorch-ardae-vae_amd/` may import it (the product path
+fails loudly when the HIP library is missing).
+
+Parity status: PINNED.  `oracle/gen_golden.py` imports the reference's own classes
+from /root/reference (in the build container only), loads identical parameters and
+noise, and checks every function here against them before writing the fixtures in
+`tests/golden/` (the reference ships no tests or golden vectors of its own).
+
+Everything is functional: networks are `dict[str, Tensor]` keyed by the reference's
+`state_dict()` names, weights are `[out, in]` like `nn.Linear`.
+
+Reference map (file:line in /root/reference):
+  mlp()                 models/layers.py:477-515      (MLP)
+  act()                 utils/models.py:14-32         (get_nonlinear_func)
+  mnist_encode()        models/ivae/mnist.py:76-121,123-165
+  mnist_decode()        models/ivae/mnist.py:167-199
+  toy_encode()          models/ivae/toy.py:60-103,154-194 + models/layers.py:681-724
+  toy_decode()          models/ivae/toy.py:694-737
+  vae_forward()         models/ivae/mnist.py:240-249,267-301 / toy.py:777-873
+  cdae_grad_forward()   models/graddae/mlp.py:400-444
+  cdae_grad_glogprob()  models/graddae/mlp.py:446-483
+  cdae_res_forward()    models/resdae/mlp.py:344-381
+  cdae_res_glogprob()   models/resdae/mlp.py:383-413
+  latent_stats()        ivae_ardae.py:753-761
+  adam_ref_step()       utils/optim.py:49-108
+  rmsprop_step()        torch.optim.RMSprop as constructed at ivae_ardae.py:625-626
+  train_step()          ivae_ardae.py:707-846
+  iwae_logprob()        models/ivae/mnist.py:378-437, utils/stat.py:65-85,127-158
+"""
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+LOG2PI = math.log(2.0 * math.pi)
+
+
+# --------------------------------------------------------------------------- #
+# configuration
+# --------------------------------------------------------------------------- #
+@dataclass
+class ModelCfg:
+    """Implicit-posterior VAE hyper-parameters (ivae_ardae.py:295-314)."""
+    kind: str = "mnist"          # "mnist" (MNISTIPVAE) | "toy" (ToyIPVAE, enc_type='concat')
+    input_dim: int = 784
+    noise_dim: int = 100
+    h_dim: int = 256
+    z_dim: int = 32
+    n_layers: int = 2            # --model-n-layers
+    nonlin: str = "softplus"
+
+
+@dataclass
+class CdaeCfg:
+    """Conditional AR-DAE hyper-parameters (ivae_ardae.py:583-606)."""
+    kind: str = "grad"           # "grad" (MLPGradCARDAE) | "res" (MLPResCARDAE)
+    input_dim: int = 32
+    context_dim: int = 32
+    h_dim: int = 256
+    n_layers: int = 3            # --cdae-n-layers
+    nonlin: str = "softplus"
+
+
+@dataclass
+class TrainCfg:
+    """Loop constants (run_vae_dbmnist.sh / run_vae_25gaussians.sh)."""
+    delta: float = 0.1
+    std_scale: float = 1e4
+    nz_cdae: int = 256
+    nz_model: int = 1
+    nstd: int = 1
+    num_cdae_updates: int = 1
+    beta: float = 1.0
+    m_lr: float = 1e-4
+    m_beta1: float = 0.5
+    d_lr: float = 1e-4
+    d_momentum: float = 0.5
+
+
+# --------------------------------------------------------------------------- #
+# parameter specs (names/shapes exactly as the reference's named_parameters())
+# --------------------------------------------------------------------------- #
+def _mlp_spec(prefix, din, dh, dout, n_hidden):
+    spec = []
+    for i in range(n_hidden):
+        spec += [(f"{prefix}layers.{i}.weight", (dh, din if i == 0 else dh)),
+                 (f"{prefix}layers.{i}.bias", (dh,))]
+    spec += [(f"{prefix}fc.weight", (dout, din if n_hidden == 0 else dh)),
+             (f"{prefix}fc.bias", (dout,))]
+    return spec
+
+
+def _ctxcat_mlp_spec(prefix, din, dctx, dh, dout, n_hidden):
+    # ContextConcatMLP (models/layers.py:681-724): every layer eats cat([hidden, ctx])
+    spec = []
+    for i in range(n_hidden):
+        spec += [(f"{prefix}layers.{i}.weight", (dh, (din if i == 0 else dh) + dctx)),
+                 (f"{prefix}layers.{i}.bias", (dh,))]
+    spec += [(f"{prefix}fc.weight", (dout, (din if n_hidden == 0 else dh) + dctx)),
+             (f"{prefix}fc.bias", (dout,))]
+    return spec
+
+
+def model_param_spec(c: ModelCfg):
+    if c.kind == "mnist":
+        s = _mlp_spec("encode.inp_encode.", c.input_dim, c.h_dim, c.h_dim, c.n_layers + 1)
+        s += _mlp_spec("encode.fc.", c.h_dim + c.noise_dim, c.h_dim, c.z_dim, 1)
+        s += _mlp_spec("decode.main.", c.z_dim, c.h_dim, c.h_dim, c.n_layers)
+        s += [("decode.reparam.logit_fn.weight", (c.input_dim, c.h_dim)),
+              ("decode.reparam.logit_fn.bias", (c.input_dim,))]
+        return s
+    if c.kind == "toy":
+        s = _mlp_spec("encode.inp_encode.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += _ctxcat_mlp_spec("encode.fc.", c.h_dim, c.noise_dim, c.h_dim, c.z_dim, c.n_layers)
+        s += _mlp_spec("decode.main.", c.z_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += [("decode.reparam.mean_fn.weight", (c.input_dim, c.h_dim)),
+              ("decode.reparam.mean_fn.bias", (c.input_dim,)),
+              ("decode.reparam.logvar_fn.weight", (c.input_dim, c.h_dim)),
+              ("decode.reparam.logvar_fn.bias", (c.input_dim,))]
+        return s
+    raise NotImplementedError(c.kind)
+
+
+def cdae_param_spec(c: CdaeCfg):
+    s = _mlp_spec("ctx_encode.", c.context_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+    s += _mlp_spec("inp_encode.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+    if c.kind == "grad":
+        s += _mlp_spec("neglogprob.", 2 * c.h_dim + 1, c.h_dim, 1, c.n_layers)
+    elif c.kind == "res":
+        s += _mlp_spec("dae.", 2 * c.h_dim + 1, c.h_dim, c.input_dim, c.n_layers)
+    else:
+        raise NotImplementedError(c.kind)
+    return s
+
+
+def init_params(spec, seed, special=None, dtype=torch.float32):
+    """Deterministic, platform-independent initialiser (numpy PCG64).
+
+    Distribution families follow the reference (nn.Linear default: U(+-1/sqrt(fan_in)) for
+    both weight (kaiming_uniform a=sqrt5) and bias); `special` maps a name to
+    ("normal",) | ("xavier",) | ("zeros",) for the overrides listed in SURVEY App. B.
+    It is NOT bit-identical to torch's own init RNG - parity tests load the same numbers
+    into the reference, so only the family matters.
+    """
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    special = special or {}
+    out = {}
+    for name, shape in spec:
+        fan_in = shape[1] if len(shape) == 2 else None
+        kind = special.get(name, ("default",))[0]
+        if kind == "normal":
+            a = rng.standard_normal(shape)
+        elif kind == "zeros":
+            a = np.zeros(shape)
+        elif kind == "xavier":
+            bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+            a = rng.uniform(-bound, bound, shape)
+        else:
+            if fan_in is None:  # bias: bound uses the fan_in of the matching weight
+                wname = name[:-len("bias")] + "weight"
+                fan_in = dict(spec)[wname][1]
+            bound = 1.0 / math.sqrt(fan_in)
+            a = rng.uniform(-bound, bound, shape)
+        out[name] = torch.tensor(a, dtype=dtype)
+    return out
+
+
+def model_init_special(c: ModelCfg):
+    """Init overrides of the reference constructors."""
+    sp = {}
+    spec = model_param_spec(c)
+    for name, _ in spec:
+        if name.startswith("decode.") and c.kind == "mnist":
+            sp[name] = ("xavier",) if name.endswith("weight") else ("zeros",)
+    sp["encode.fc.fc.weight"] = ("normal",)          # init='gaussian' (ivae/mnist.py:158-159)
+    if c.kind == "toy":
+        sp["decode.reparam.mean_fn.weight"] = ("normal",)   # ivae/toy.py:719-720
+    return sp
+
+
+# --------------------------------------------------------------------------- #
+# building blocks
+# --------------------------------------------------------------------------- #
+def act(name):
+    if name == "softplus":
+        return F.softplus            # beta=1, threshold=20
+    if name == "relu":
+        return F.relu
+    if name == "tanh":
+        return torch.tanh
+    if name == "elu":
+        return F.elu
+    raise NotImplementedError(name)
+
+
+def mlp(p, prefix, x, n_hidden, nonlin, act_out):
+    f = act(nonlin)
+    h = x
+    for i in range(n_hidden):
+        h = f(F.linear(h, p[f"{prefix}layers.{i}.weight"], p[f"{prefix}layers.{i}.bias"]))
+    y = F.linear(h, p[f"{prefix}fc.weight"], p[f"{prefix}fc.bias"])
+    return f(y) if act_out else y
+
+
+def ctxcat_mlp(p, prefix, x, ctx, n_hidden, nonlin):
+    f = act(nonlin)
+    h = x
+    for i in range(n_hidden):
+        h = f(F.linear(torch.cat([h, ctx], 1), p[f"{prefix}layers.{i}.weight"], p[f"{prefix}layers.{i}.bias"]))
+    return F.linear(torch.cat([h, ctx], 1), p[f"{prefix}fc.weight"], p[f"{prefix}fc.bias"])
+
+
+def expand_rows(t, nz):
+    """[B, d] -> [B*nz, d], image-major (utils/msc.py:21-40)."""
+    return t.unsqueeze(1).expand(-1, nz, -1).reshape(t.size(0) * nz, -1)
+
+
+# --------------------------------------------------------------------------- #
+# implicit-posterior VAE
+# --------------------------------------------------------------------------- #
+def encode(c: ModelCfg, p, x, noise, nz):
+    """z = f(x, noise): x [B, input_dim], noise [B*nz, noise_dim] (already scaled by std)."""
+    B = x.size(0)
+    x = x.reshape(B, c.input_dim)
+    if c.kind == "mnist":
+        inp = mlp(p, "encode.inp_encode.", 2 * x - 1, c.n_layers + 1, c.nonlin, True)
+        hin = torch.cat([expand_rows(inp, nz), noise], 1)
+        z = mlp(p, "encode.fc.", hin, 1, c.nonlin, False)
+    elif c.kind == "toy":
+        inp = mlp(p, "encode.inp_encode.", x, c.n_layers - 1, c.nonlin, True)
+        z = ctxcat_mlp(p, "encode.fc.", expand_rows(inp, nz), noise, c.n_layers, c.nonlin)
+    else:
+        raise NotImplementedError
+    return z.view(B, nz, c.z_dim)
+
+
+def decode(c: ModelCfg, p, z):
+    """Returns the decoder's distribution parameters for z [R, z_dim]."""
+    if c.kind == "mnist":
+        h = mlp(p, "decode.main.", z, c.n_layers, c.nonlin, True)
+        return (F.linear(h, p["decode.reparam.logit_fn.weight"], p["decode.reparam.logit_fn.bias"]),)
+    h = mlp(p, "decode.main.", z, c.n_layers - 1, c.nonlin, True)
+    mu = F.linear(h, p["decode.reparam.mean_fn.weight"], p["decode.reparam.mean_fn.bias"])
+    logvar = F.linear(h, p["decode.reparam.logvar_fn.weight"], p["decode.reparam.logvar_fn.bias"])
+    return mu, logvar
+
+
+def recon_rows(c: ModelCfg, dist, target):
+    if c.kind == "mnist":
+        (logit,) = dist
+        return F.binary_cross_entropy_with_logits(logit, target, reduction="none").sum(1)
+    mu, logvar = dist
+    return 0.5 * (logvar + (target - mu) ** 2 / logvar.exp() + LOG2PI).sum(1)
+
+
+def prior_rows(z):
+    return (0.5 * (z ** 2 + LOG2PI)).sum(1)
+
+
+def vae_forward(c: ModelCfg, p, x, noise, beta, nz=1):
+    """-> (z [B,nz,z], loss, recon.mean, prior.mean); loss carries grad_fn."""
+    B = x.size(0)
+    x = x.reshape(B, c.input_dim)
+    z = encode(c, p, x, noise, nz)
+    zf = z.reshape(B * nz, c.z_dim)
+    dist = decode(c, p, zf)
+    rec = recon_rows(c, dist, expand_rows(x, nz))
+    pri = prior_rows(zf)
+    loss = (rec + beta * pri).mean()
+    return z, loss, rec.mean().detach(), pri.mean().detach(), dist
+
+
+# --------------------------------------------------------------------------- #
+# conditional AR-DAE
+# --------------------------------------------------------------------------- #
+def _cdae_h(c: CdaeCfg, p, x_bar, ctx_rows, std_rows):
+    ctx = mlp(p, "ctx_encode.", ctx_rows, c.n_layers - 1, c.nonlin, True)
+    inp = mlp(p, "inp_encode.", x_bar, c.n_layers - 1, c.nonlin, True)
+    return torch.cat([inp, ctx, std_rows], 1)
+
+
+def cdae_score(c: CdaeCfg, p, x_bar, ctx_rows, std_rows, create_graph):
+    """Score estimate at x_bar [N, z] (x_bar must require grad for kind='grad')."""
+    h = _cdae_h(c, p, x_bar, ctx_rows, std_rows)
+    if c.kind == "grad":
+        logprob = (-mlp(p, "neglogprob.", h, c.n_layers, c.nonlin, False)).sum()
+        return torch.autograd.grad(logprob, x_bar, retain_graph=True, create_graph=create_graph)[0]
+    return mlp(p, "dae.", h, c.n_layers, c.nonlin, False)
+
+
+def cdae_forward(c: CdaeCfg, p, inp, context, std, eps):
+    """DAE loss.  inp [B,S,z], context [B,1,c], std [B,S,1], eps [B*S,z] -> scalar loss."""
+    B, S, _ = inp.shape
+    x = inp.reshape(B * S, c.input_dim)
+    ctx_rows = expand_rows(context.reshape(B, c.context_dim), S)      # reference runs ctx_encode on N rows
+    std_rows = std.reshape(B * S, 1)
+    x_bar = (x + std_rows * eps).detach().requires_grad_(True)
+    g = cdae_score(c, p, x_bar, ctx_rows, std_rows, create_graph=True)
+    return F.mse_loss(std_rows * g, -eps)
+
+
+def cdae_glogprob(c: CdaeCfg, p, inp, context, std):
+    B, S, _ = inp.shape
+    x = inp.reshape(B * S, c.input_dim).detach().requires_grad_(True)
+    ctx_rows = expand_rows(context.reshape(B, c.context_dim), S)
+    g = cdae_score(c, p, x, ctx_rows, std.reshape(B * S, 1), create_graph=False)
+    return g.detach().view(B, S, c.input_dim)
+
+
+def latent_stats(latent, latent_mean, std_scale, delta):
+    """u = s(z - z0); std = delta * mean_d(std_nz(u)) (unbiased)  (ivae_ardae.py:753-755)."""
+    u = std_scale * (latent - latent_mean)
+    std_qz = torch.std(u, dim=1, keepdim=True)
+    std = delta * torch.mean(std_qz, dim=2, keepdim=True)
+    return u, std
+
+
+# --------------------------------------------------------------------------- #
+# optimisers
+# --------------------------------------------------------------------------- #
+def adam_ref_step(params, grads, state, lr, beta1, beta2=0.999, eps=1e-8):
+    """Vendored old-style Adam: eps added BEFORE the bias correction (utils/optim.py:102-106).
+    Tensors whose grad is None are skipped and keep no state."""
+    for name, w in params.items():
+        g = grads.get(name)
+        if g is None:
+            continue
+        st = state.setdefault(name, {"step": 0, "exp_avg": torch.zeros_like(w), "exp_avg_sq": torch.zeros_like(w)})
+        st["step"] += 1
+        bc1 = 1 - beta1 ** st["step"]
+        bc2 = 1 - beta2 ** st["step"]
+        st["exp_avg"].mul_(beta1).add_(g, alpha=1 - beta1)
+        st["exp_avg_sq"].mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        denom = (st["exp_avg_sq"].sqrt() + eps) / math.sqrt(bc2)
+        w.addcdiv_(st["exp_avg"], denom, value=-lr / bc1)
+
+
+def rmsprop_step(params, grads, state, lr, momentum, alpha=0.99, eps=1e-8):
+    """torch.optim.RMSprop (not centred) with momentum; grad None -> skipped."""
+    for name, w in params.items():
+        g = grads.get(name)
+        if g is None:
+            continue
+        st = state.setdefault(name, {"step": 0, "square_avg": torch.zeros_like(w), "momentum_buffer": torch.zeros_like(w)})
+        st["step"] += 1
+        st["square_avg"].mul_(alpha).addcmul_(g, g, value=1 - alpha)
+        avg = st["square_avg"].sqrt().add_(eps)
+        if momentum > 0:
+            st["momentum_buffer"].mul_(momentum).addcdiv_(g, avg)
+            w.add_(st["momentum_buffer"], alpha=-lr)
+        else:
+            w.addcdiv_(g, avg, value=-lr)
+
+
+# --------------------------------------------------------------------------- #
+# noise (reference draw order)
+# --------------------------------------------------------------------------- #
+def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
+    """All Gaussian/uniform draws one train step consumes, in the reference's order.
+    The std=0 encodes consume a draw that is multiplied by 0, so they are skipped here
+    (they only advance the reference's RNG stream)."""
+    N = B * tc.nz_cdae
+    return {
+        "sampler": torch.randn(N, mc.noise_dim, generator=gen),          # forward_hidden
+        "sigma": torch.randn(B, tc.nz_cdae * tc.nstd, 1, generator=gen),  # stdmat
+        "eps": torch.randn(N * tc.nstd, mc.z_dim, generator=gen),         # add_gaussian_noise
+        "vae": torch.randn(B * tc.nz_model, mc.noise_dim, generator=gen),
+    }
+
+
+# --------------------------------------------------------------------------- #
+# one train step
+# --------------------------------------------------------------------------- #
+def _grads_of(loss, p):
+    names = list(p.keys())
+    gs = torch.autograd.grad(loss, [p[n] for n in names], allow_unused=True)
+    return {n: g for n, g in zip(names, gs)}
+
+
+def cdae_update_grads(mc, cc, tc, pm, pc, x, noise):
+    """cDAE phase up to (not including) the optimiser step  (ivae_ardae.py:713-771).
+    Returns loss, grads dict (None for tensors the loss does not reach), std [B,1,1]."""
+    B = x.size(0)
+    with torch.no_grad():
+        zero = torch.zeros(B, mc.noise_dim)
+        z0 = encode(mc, pm, x, zero, 1)                          # context == latent_mean (lt0)
+        latent = encode(mc, pm, x, noise["sampler"], tc.nz_cdae)
+        u, std = latent_stats(latent, z0, tc.std_scale, tc.delta)
+        stdmat = std * noise["sigma"]
+        u_exp = u.unsqueeze(2).expand(B, tc.nz_cdae, tc.nstd, mc.z_dim).reshape(B, tc.nz_cdae * tc.nstd, mc.z_dim)
+    pc_req = {k: v.detach().requires_grad_(True) for k, v in pc.items()}
+    loss = cdae_forward(cc, pc_req, u_exp, z0, stdmat, noise["eps"])
+    grads = _grads_of(loss, pc_req)
+    return loss.detach(), grads, std
+
+
+def vae_update_grads(mc, cc, tc, pm, pc, x, noise, beta=None):
+    """VAE phase up to the optimiser step (ivae_ardae.py:781-834)."""
+    beta = tc.beta if beta is None else beta
+    B = x.size(0)
+    pm_req = {k: v.detach().requires_grad_(True) for k, v in pm.items()}
+    z, loss, rec, pri, _ = vae_forward(mc, pm_req, x, noise["vae"], beta, tc.nz_model)
+    with torch.no_grad():
+        z0 = encode(mc, pm, x, torch.zeros(B, mc.noise_dim), 1)
+    u = (tc.std_scale * (z - z0)).detach()
+    stdmat = torch.zeros(B, tc.nz_model, 1)
+    g = cdae_glogprob(cc, pc, u, z0, stdmat)
+    seed = beta * g / float(B * tc.nz_model)
+    # loss.backward(); (s*(z - z0)).backward(seed)  ==  d/dp [loss + sum(s*z*seed)]
+    total = loss + (tc.std_scale * (z - z0) * seed).sum()
+    grads = _grads_of(total, pm_req)
+    return loss.detach(), rec, pri, g, grads
+
+
+def train_step(mc, cc, tc, pm, pc, st_m, st_c, x_cdae, x_vae, noise):
+    """One iteration of ivae_ardae.py:707-846 with num_cdae_updates=1.  Mutates pm/pc/states."""
+    closs, gc, std = cdae_update_grads(mc, cc, tc, pm, pc, x_cdae, noise)
+    with torch.no_grad():
+        rmsprop_step(pc, gc, st_c, tc.d_lr, tc.d_momentum)
+    mloss, rec, pri, g, gm = vae_update_grads(mc, cc, tc, pm, pc, x_vae, noise)
+    with torch.no_grad():
+        adam_ref_step(pm, gm, st_m, tc.m_lr, tc.m_beta1)
+    return {"cdae_loss": closs, "std_mean": std.mean(), "std_max": std.max(), "std_min": std.min(),
+            "model_loss": mloss, "recon": rec, "prior": pri}
+
+
+# --------------------------------------------------------------------------- #
+# IWAE evaluation (quality gate, not timed)
+# --------------------------------------------------------------------------- #
+def iwae_logprob(mc: ModelCfg, pm, x, sample_size, enc_noise, prop_noise):
+    """IWAE-k with a full-covariance Gaussian fitted to encoder samples as proposal.
+    enc_noise [B, k, noise_dim], prop_noise [B, k, z] (standard normal draws)."""
+    assert sample_size >= 2 * mc.z_dim
+    B = x.size(0)
+    x = x.reshape(B, mc.input_dim)
+    with torch.no_grad():
+        z = encode(mc, pm, x, enc_noise.reshape(B * sample_size, mc.noise_dim), sample_size)   # [B,k,z]
+        mu = z.mean(1)
+        zc = z - mu.unsqueeze(1)
+        cov = zc.transpose(1, 2) @ zc / (sample_size - 1)
+        Lc = torch.linalg.cholesky(cov)
+        newz = mu.unsqueeze(1) + prop_noise @ Lc.transpose(1, 2)
+        half_logdet = torch.log(torch.diagonal(Lc, dim1=1, dim2=2)).sum(1, keepdim=True)
+        logq = -0.5 * (prop_noise ** 2).sum(2) - half_logdet - 0.5 * mc.z_dim * LOG2PI
+        logp = -prior_rows(newz.reshape(B * sample_size, mc.z_dim)).view(B, sample_size)
+        dist = decode(mc, pm, newz.reshape(B * sample_size, mc.z_dim))
+        loglik = -recon_rows(mc, dist, expand_rows(x, sample_size)).view(B, sample_size)
+        lw = loglik + logp - logq
+        m, _ = lw.max(1, keepdim=True)
+        out = torch.log(torch.mean((lw - m).exp(), 1, keepdim=True) + 1e-10) + m
+    return out.mean()

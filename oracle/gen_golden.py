@@ -1,0 +1,284 @@
+"""Pin the oracle against the reference and write the golden fixtures  --  TEST INFRASTRUCTURE.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU box):
+
+    python oracle/gen_golden.py            # validates + (re)writes tests/golden/*.npz
+
+What it does, per case:
+  1. builds the reference's own classes (models.MNISTIPVAE / ToyIPVAE / MLPGradCARDAE /
+     MLPResCARDAE, utils.Adam, torch.optim.RMSprop) with inert stubs for the plotting
+     imports the reference pulls in at module top (torchvision, seaborn),
+  2. loads parameters from the oracle's deterministic initialiser into them,
+  3. runs the loop body of ivae_ardae.py:713-846 on the reference objects with a fixed torch
+     seed, and replays the same seed to capture the noise tensors in the reference's draw order,
+  4. runs the oracle (oracle/ardae_oracle.py) on the same parameters + captured noise and
+     asserts agreement (fp32: rtol 2e-5 on losses, 1e-4 relative L2 on grads; fp64 case tighter),
+  5. stores the REFERENCE's outputs as the fixture.
+"""
+import os
+import sys
+import types
+import math
+import copy
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ardae_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+# --------------------------------------------------------------------------- #
+def import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    noop = lambda *a, **k: None
+    if "torchvision" not in sys.modules:
+        tv = stub("torchvision")
+        tv.utils = stub("torchvision.utils", make_grid=noop, save_image=noop)
+        tv.datasets = stub("torchvision.datasets", MNIST=object)
+        tv.transforms = stub("torchvision.transforms")
+    if "seaborn" not in sys.modules:
+        stub("seaborn", set=noop, set_style=noop, set_palette=noop, color_palette=noop, scatterplot=noop)
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+    import models as net      # noqa
+    import utils as rutils    # noqa
+    return net, rutils
+
+
+def build_reference(net, mc, cc, pm, pc, dtype):
+    if mc.kind == "mnist":
+        model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
+                               num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
+    else:
+        model = net.ToyIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
+                             num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
+    ctor = net.MLPGradCARDAE if cc.kind == "grad" else net.MLPResCARDAE
+    cdae = ctor(input_dim=cc.input_dim, context_dim=cc.context_dim, std=1., h_dim=cc.h_dim,
+                num_hidden_layers=cc.n_layers, nonlinearity=cc.nonlin, noise_type="gaussian",
+                enc_ctx=True, enc_input=True)
+    model = model.to(dtype)
+    cdae = cdae.to(dtype)
+    # names and shapes must coincide with the oracle's spec (this is App. B of SURVEY.md)
+    assert [(n, tuple(p.shape)) for n, p in model.named_parameters()] == O.model_param_spec(mc)
+    assert [(n, tuple(p.shape)) for n, p in cdae.named_parameters()] == O.cdae_param_spec(cc)
+    model.load_state_dict({k: v.clone() for k, v in pm.items()})
+    cdae.load_state_dict({k: v.clone() for k, v in pc.items()})
+    return model, cdae
+
+
+def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
+    """Loop body of ivae_ardae.py:713-846 on the reference's objects (num_cdae_updates=1, lt0)."""
+    out = {}
+    torch.manual_seed(seed)
+    model.train(); cdae.train()
+    c_opt.zero_grad()
+    B = x_cdae.size(0)
+    context = model.encode(x_cdae, std=0).detach()
+    latent_mean = model.encode(x_cdae, std=0).detach()
+    latent = model.forward_hidden(x_cdae, nz=tc.nz_cdae).detach()
+    u = tc.std_scale * (latent - latent_mean)
+    std_qz = torch.std(u, dim=1, keepdim=True)
+    std = tc.delta * torch.mean(std_qz, dim=2, keepdim=True)
+    stdmat = std * torch.randn(B, tc.nz_cdae * tc.nstd, 1, dtype=u.dtype)
+    u_exp = u.unsqueeze(2).expand(B, tc.nz_cdae, tc.nstd, u.size(-1)).reshape(B, tc.nz_cdae * tc.nstd, u.size(-1))
+    _, closs = cdae(u_exp, context, std=stdmat, scale=tc.std_scale)
+    closs.backward()
+    out["z0"] = latent_mean.clone(); out["latent"] = latent.clone(); out["std"] = std.clone()
+    out["cdae_loss"] = closs.detach().clone()
+    out["cdae_grads"] = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in cdae.named_parameters()}
+    c_opt.step()
+    out["cdae_params_after"] = {n: p.detach().clone() for n, p in cdae.named_parameters()}
+
+    model.train(); cdae.eval()
+    m_opt.zero_grad()
+    B = x_vae.size(0)
+    _, _, latent, mloss, rec, pri = model(x_vae, beta=tc.beta, eta=0., lmbd=0., nz=tc.nz_model)
+    mloss.backward(retain_graph=True)
+    context = model.encode(x_vae, std=0).detach()
+    latent_mean = model.encode(x_vae, std=0).detach()
+    lsm = tc.std_scale * (latent - latent_mean).detach()
+    stdmat = torch.zeros(B, tc.nz_model, 1, dtype=lsm.dtype)
+    g = cdae.glogprob(lsm, context, std=stdmat, scale=tc.std_scale).detach()
+    (tc.std_scale * (latent - latent_mean)).backward(tc.beta * g.detach() / float(B * tc.nz_model))
+    out["model_loss"] = mloss.detach().clone(); out["recon"] = rec.clone(); out["prior"] = pri.clone()
+    out["score"] = g.clone(); out["vae_latent"] = latent.detach().clone()
+    out["model_grads"] = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    m_opt.step()
+    out["model_params_after"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+    return out
+
+
+def replay_noise(mc, tc, B_c, B_v, seed, dtype):
+    """Re-draw, with the same seed and call sizes, what ref_step consumed (SURVEY 8 a-R)."""
+    torch.manual_seed(seed)
+    torch.randn(B_c, mc.noise_dim)                       # context encode (x0)
+    torch.randn(B_c, mc.noise_dim)                       # latent_mean encode (x0)
+    n = {}
+    n["sampler"] = torch.randn(B_c * tc.nz_cdae, mc.noise_dim)
+    n["sigma"] = torch.randn(B_c, tc.nz_cdae * tc.nstd, 1, dtype=dtype)
+    n["eps"] = torch.randn(B_c * tc.nz_cdae * tc.nstd, mc.z_dim, dtype=dtype)   # randn_like(input)
+    n["vae"] = torch.randn(B_v * tc.nz_model, mc.noise_dim)
+    # decoder's unused sample: rand_like(logit) (mnist) / randn_like(std) (toy); then 2 x encode(std=0)
+    return {k: v.to(dtype) for k, v in n.items()}
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def synth_x(mc, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    if mc.kind == "mnist":
+        p = (torch.rand(mc.input_dim, generator=g) < 0.2).float() * 0.6 + 0.03
+        return torch.bernoulli(p.expand(B, -1), generator=g)
+    mu = (torch.randint(0, 5, (B, mc.input_dim), generator=g).float() - 2) * 2
+    return mu + math.sqrt(0.1) * torch.randn(B, mc.input_dim, generator=g)
+
+
+# --------------------------------------------------------------------------- #
+def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0):
+    tol = 1e-4 if dtype == torch.float32 else 1e-10
+    pm = O.init_params(O.model_param_spec(mc), pseed, O.model_init_special(mc), dtype)
+    pc = O.init_params(O.cdae_param_spec(cc), pseed + 1, None, dtype)
+    # tame the N(0,1) head so fp32 comparisons are meaningful at tiny nz as well (values still O(1..10))
+    model, cdae = build_reference(net, mc, cc, pm, pc, dtype)
+    m_opt = rutils.Adam(model.parameters(), lr=tc.m_lr, betas=(tc.m_beta1, 0.999))
+    c_opt = torch.optim.RMSprop(cdae.parameters(), lr=tc.d_lr, momentum=tc.d_momentum)
+    st_m, st_c = {}, {}
+    fx = {"meta_B": np.int64(B), "meta_steps": np.int64(steps), "meta_pseed": np.int64(pseed)}
+    if store_full:
+        for k, v in pm.items():
+            fx[f"pm/{k}"] = v.numpy().copy()
+        for k, v in pc.items():
+            fx[f"pc/{k}"] = v.numpy().copy()
+    worst = 0.0
+    for t in range(steps):
+        xc = synth_x(mc, B, 1000 + 2 * t).to(dtype)
+        xv = synth_x(mc, B, 1001 + 2 * t).to(dtype)
+        seed = 4242 + t
+        ref = ref_step(rutils, model, cdae, m_opt, c_opt, tc, xc, xv, seed)
+        noise = replay_noise(mc, tc, B, B, seed, dtype)
+        # ---- oracle on identical inputs --------------------------------------
+        closs, gc, std = O.cdae_update_grads(mc, cc, tc, pm, pc, xc, noise)
+        errs = {"cdae_loss": abs(float(closs) - float(ref["cdae_loss"])) / abs(float(ref["cdae_loss"])),
+                "std": rel_l2(std, ref["std"])}
+        for n_, g_ in ref["cdae_grads"].items():
+            if g_ is None:
+                assert gc[n_] is None, n_
+            else:
+                errs["gc/" + n_] = rel_l2(gc[n_], g_)
+        with torch.no_grad():
+            O.rmsprop_step(pc, gc, st_c, tc.d_lr, tc.d_momentum)
+        for n_, p_ in ref["cdae_params_after"].items():
+            errs["pc/" + n_] = rel_l2(pc[n_], p_)
+        mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, tc, pm, pc, xv, noise)
+        errs["model_loss"] = abs(float(mloss) - float(ref["model_loss"])) / abs(float(ref["model_loss"]))
+        errs["recon"] = abs(float(rec) - float(ref["recon"])) / abs(float(ref["recon"]))
+        errs["prior"] = abs(float(pri) - float(ref["prior"])) / abs(float(ref["prior"]))
+        errs["score"] = rel_l2(g, ref["score"])
+        for n_, g_ in ref["model_grads"].items():
+            errs["gm/" + n_] = rel_l2(gm[n_], g_)
+        with torch.no_grad():
+            O.adam_ref_step(pm, gm, st_m, tc.m_lr, tc.m_beta1)
+        for n_, p_ in ref["model_params_after"].items():
+            errs["pm/" + n_] = rel_l2(pm[n_], p_)
+        bad = {k: v for k, v in errs.items() if not (v <= tol)}
+        worst = max(worst, max(errs.values()))
+        assert not bad, f"{name} step {t}: oracle != reference: {bad}"
+        # keep the two trajectories locked together: continue from the REFERENCE's parameters
+        pm = {k: v.clone() for k, v in ref["model_params_after"].items()}
+        pc = {k: v.clone() for k, v in ref["cdae_params_after"].items()}
+        # ---- fixture ----------------------------------------------------------
+        pre = f"s{t}/"
+        fx[pre + "x_cdae"] = xc.numpy(); fx[pre + "x_vae"] = xv.numpy()
+        for k, v in noise.items():
+            fx[pre + "noise/" + k] = v.numpy()
+        for k in ("cdae_loss", "model_loss", "recon", "prior", "std", "score", "z0"):
+            fx[pre + k] = ref[k].numpy()
+        if store_full:
+            fx[pre + "latent"] = ref["latent"].numpy()
+            fx[pre + "vae_latent"] = ref["vae_latent"].numpy()
+        for grp in ("cdae_grads", "model_grads", "cdae_params_after", "model_params_after"):
+            for k, v in ref[grp].items():
+                if v is None:
+                    fx[pre + grp + "/" + k + "/none"] = np.int64(1)
+                elif store_full:
+                    fx[pre + grp + "/" + k] = v.numpy()
+                else:   # summaries only: L2 norm, sum, first 8 elements
+                    f = v.flatten().double()
+                    fx[pre + grp + "/" + k + "/norm"] = np.float64(f.norm())
+                    fx[pre + grp + "/" + k + "/sum"] = np.float64(f.sum())
+                    fx[pre + grp + "/" + k + "/head"] = v.flatten()[:8].numpy()
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[golden] {name}: {steps} step(s), oracle-vs-reference worst rel err {worst:.2e} -> {path} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def run_iwae_case(net, name, mc, B, k, dtype):
+    """models/ivae/mnist.py:378-437 with the per-image draws captured by replaying the seed."""
+    pm = O.init_params(O.model_param_spec(mc), 7, O.model_init_special(mc), dtype)
+    cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=mc.z_dim, h_dim=32, n_layers=2)
+    pc = O.init_params(O.cdae_param_spec(cc), 8, None, dtype)
+    model, _ = build_reference(net, mc, cc, pm, pc, dtype)
+    x = synth_x(mc, B, 55).to(dtype)
+    torch.manual_seed(99)
+    model.eval()
+    with torch.no_grad():
+        ref = model.logprob(x, sample_size=k)
+    torch.manual_seed(99)
+    enc = torch.stack([torch.randn(k, mc.noise_dim) for _ in range(B)]).to(dtype)
+    # MultivariateNormal.rsample(torch.Size([1, k])) draws standard normals of shape [1, k, z]
+    prop = torch.stack([torch.randn(1, k, mc.z_dim, dtype=dtype)[0] for _ in range(B)])
+    mine = O.iwae_logprob(mc, pm, x, k, enc, prop)
+    err = abs(float(mine) - float(ref)) / abs(float(ref))
+    assert err < (1e-4 if dtype == torch.float32 else 1e-9), (float(mine), float(ref))
+    fx = {"x": x.numpy(), "enc_noise": enc.numpy(), "prop_noise": prop.numpy(), "logprob": ref.numpy(),
+          "meta_k": np.int64(k)}
+    for kk, v in pm.items():
+        fx["pm/" + kk] = v.numpy()
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[golden] {name}: IWAE-{k} ref {float(ref):.6f} oracle {float(mine):.6f} rel err {err:.2e}")
+
+
+def main():
+    torch.set_num_threads(8)
+    net, rutils = import_reference()
+    os.makedirs(GOLDEN, exist_ok=True)
+    f32, f64 = torch.float32, torch.float64
+    tiny_m = O.ModelCfg("mnist", input_dim=24, noise_dim=10, h_dim=64, z_dim=8, n_layers=2, nonlin="softplus")
+    tiny_c = O.CdaeCfg("grad", input_dim=8, context_dim=8, h_dim=64, n_layers=3)
+    tc = O.TrainCfg(nz_cdae=8)
+    # float64 pin of the maths (tight) and float32 fixtures (what the kernels are compared with)
+    run_case(net, rutils, "tiny_mnist_grad_f64", tiny_m, tiny_c, tc, B=4, steps=1, dtype=f64, store_full=True)
+    run_case(net, rutils, "tiny_mnist_grad", tiny_m, tiny_c, tc, B=4, steps=3, dtype=f32, store_full=True)
+    tiny_r = O.CdaeCfg("res", input_dim=8, context_dim=8, h_dim=64, n_layers=3)
+    run_case(net, rutils, "tiny_mnist_res", tiny_m, tiny_r, tc, B=4, steps=2, dtype=f32, store_full=True)
+    toy_m = O.ModelCfg("toy", input_dim=2, noise_dim=10, h_dim=64, z_dim=2, n_layers=2, nonlin="relu")
+    toy_c = O.CdaeCfg("grad", input_dim=2, context_dim=2, h_dim=64, n_layers=3)
+    run_case(net, rutils, "tiny_toy_grad", toy_m, toy_c, tc, B=4, steps=2, dtype=f32, store_full=True)
+    # full-width networks of BASELINE configs #2 / #1 at a small batch; parameters regenerated from the seed
+    cfg2_m = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
+    cfg2_c = O.CdaeCfg("grad", 32, 32, 256, 3)
+    run_case(net, rutils, "cfg2_b8_nz16", cfg2_m, cfg2_c, O.TrainCfg(nz_cdae=16), B=8, steps=2, dtype=f32, store_full=False)
+    cfg1_m = O.ModelCfg("toy", 2, 10, 256, 2, 2, "relu")
+    cfg1_c = O.CdaeCfg("grad", 2, 2, 256, 3)
+    run_case(net, rutils, "cfg1_b8_nz16", cfg1_m, cfg1_c, O.TrainCfg(nz_cdae=16), B=8, steps=2, dtype=f32, store_full=False)
+    run_iwae_case(net, "iwae_tiny", tiny_m, B=3, k=16, dtype=f64)
+
+
+if __name__ == "__main__":
+    main()
