@@ -1,0 +1,96 @@
+"""ctypes binding of libardae_hip.so (C ABI: include/ardae_hip.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback.  Importing this module
+without a built library raises; calling into it without a GPU raises from the HIP runtime.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libardae_hip.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class LinSrc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("ld", ctypes.c_int), ("K", ctypes.c_int), ("wp", ctypes.c_void_p)]
+
+
+class LinearArgs(ctypes.Structure):
+    _fields_ = [
+        ("M", ctypes.c_int), ("Nout", ctypes.c_int),
+        ("nsrc", ctypes.c_int),
+        ("src", LinSrc * 2),
+        ("act", ctypes.c_int),
+        ("bias", ctypes.c_void_p),
+        ("rowbias", ctypes.c_void_p), ("rowbias_ld", ctypes.c_int), ("rows_per_group", ctypes.c_int),
+        ("rowscale", ctypes.c_void_p), ("rowscale_w", ctypes.c_void_p),
+        ("S", ctypes.c_void_p), ("ldS", ctypes.c_int),
+        ("R", ctypes.c_void_p), ("ldR", ctypes.c_int),
+        ("Q", ctypes.c_void_p), ("ldQ", ctypes.c_int),
+        ("sigma", ctypes.c_void_p),
+        ("eps", ctypes.c_void_p), ("ldeps", ctypes.c_int),
+        ("scale", ctypes.c_float),
+        ("Y", ctypes.c_void_p), ("ldY", ctypes.c_int),
+        ("Y2", ctypes.c_void_p), ("ldY2", ctypes.c_int),
+        ("colsum", ctypes.c_void_p),
+        ("tile_loss", ctypes.c_void_p),
+    ]
+
+
+ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2}
+EPI_ACT, EPI_DACT, EPI_CHAIN, EPI_DAE_LOSS = 0, 1, 2, 3
+
+# every symbol include/ardae_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = {
+    "ardae_last_error": (ctypes.c_char_p, []),
+    "ardae_abi_version": (ctypes.c_int, []),
+    "ardae_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "ardae_linear_row_tiles": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "ardae_linear_col_panels": (ctypes.c_int, [ctypes.c_int]),
+    "ardae_pack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    "ardae_linear": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what="ardae call"):
+    if rc != 0:
+        msg = lib().ardae_last_error().decode("utf-8", "replace")
+        if rc < 0:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: HIP error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor (or None)."""
+    if t is None:
+        return None
+    import torch
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"expected a float32 tensor on the GPU, got {t.dtype} on {t.device}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,82 @@
+// Shared device/host helpers for the gfx950 AR-DAE-VAE kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace ardae {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ----------------------------------------------------------------------------------------------
+// error convention of the C ABI: 0 ok, <0 invalid argument, >0 hipError_t
+// ----------------------------------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+
+#define ARDAE_CHECK_ARG(cond, ...)                 \
+  do {                                             \
+    if (!(cond)) {                                 \
+      ::ardae::set_last_error(__VA_ARGS__);        \
+      return -1;                                   \
+    }                                              \
+  } while (0)
+
+#define ARDAE_HIP(call)                                                                  \
+  do {                                                                                   \
+    hipError_t e__ = (call);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      ::ardae::set_last_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return (int)e__;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+#define ARDAE_LAUNCH_CHECK() ARDAE_HIP(hipGetLastError())
+
+#define ARDAE_TRY(call)        \
+  do {                         \
+    int rc__ = (call);         \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// activations (reference: utils/models.py:14-32; F.softplus beta=1 threshold=20, F.relu)
+// The saved tensor is always the POST-activation value a = act(pre); first/second derivatives are
+// rebuilt from it:  softplus: s = sigmoid(pre) = 1 - exp(-a),  s' = s(1-s);  relu: s = [a>0], s' = 0.
+// ----------------------------------------------------------------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2 };
+
+__device__ __forceinline__ float softplus_f(float x) {
+  // max(x,0) + log1p(exp(-|x|)) is the overflow-free form of log(1+exp(x)); identity above the threshold
+  float t = __expf(-fabsf(x));
+  float r = fmaxf(x, 0.f) + log1pf(t);
+  return x > 20.f ? x : r;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float x) {
+  if (ACT == ACT_RELU) return fmaxf(x, 0.f);
+  if (ACT == ACT_SOFTPLUS) return softplus_f(x);
+  return x;
+}
+
+// derivative of the activation expressed through the saved post-activation value
+template <int ACT>
+__device__ __forceinline__ float act_d1(float a) {
+  if (ACT == ACT_RELU) return a > 0.f ? 1.f : 0.f;
+  if (ACT == ACT_SOFTPLUS) return -expm1f(-a);
+  return 1.f;
+}
+
+__device__ __forceinline__ float act_fwd_rt(int act, float x) {
+  return act == ACT_RELU ? act_fwd<ACT_RELU>(x) : act == ACT_SOFTPLUS ? act_fwd<ACT_SOFTPLUS>(x) : x;
+}
+__device__ __forceinline__ float act_d1_rt(int act, float a) {
+  return act == ACT_RELU ? act_d1<ACT_RELU>(a) : act == ACT_SOFTPLUS ? act_d1<ACT_SOFTPLUS>(a) : 1.f;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace ardae

@@ -1,0 +1,33 @@
+// Fused "linear" kernel family:  Y = epilogue( sum_s X_s[M,K_s] * Wp_s^T )  on FP32 MFMA (gfx950).
+//
+// Replaces the reference's `MLP.forward` Linear->act chain (models/layers.py:501-515) and, with the
+// derivative epilogues, the autograd passes PyTorch builds for it (first backward, the
+// create_graph=True score pass of models/graddae/mlp.py:35-36,437 and its double backward).
+#pragma once
+#include "ardae_hip.h"
+#include "common.h"
+
+namespace ardae {
+
+using LinSrc = ardae_lin_src;
+using LinArgs = ardae_linear_args;   // value-initialise: `LinArgs a{};`
+
+enum Epi : int {
+  EPI_ACT = ARDAE_EPI_ACT,
+  EPI_DACT = ARDAE_EPI_DACT,
+  EPI_CHAIN = ARDAE_EPI_CHAIN,
+  EPI_DAE_LOSS = ARDAE_EPI_DAE_LOSS
+};
+
+// number of floats of the packed image of an [nout, k] matrix
+size_t packed_floats(int nout, int k);
+// rows per row-tile of the geometry launch_linear() picks for this Nout (colsum / tile_loss sizing)
+int linear_row_tile(int nout);
+int linear_row_tiles(int M, int nout);
+int linear_col_panels(int nout);
+
+// M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]
+int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose, float* out, hipStream_t st);
+int launch_linear(const LinArgs& a, int epi, hipStream_t st);
+
+}  // namespace ardae

@@ -1,0 +1,153 @@
+"""K1 (fused linear on FP32 MFMA) against a float64 CPU restatement of the same operator.
+
+Tolerance: the kernel is an fp32 fmaf chain; |err| <= 2e-6 * sum|a*b| per output (guide: ~1e-7 at K<=1024),
+checked as max-abs error relative to the output scale, 2e-5.
+"""
+import ctypes
+
+import pytest
+import torch
+
+import ardae_amd
+from ardae_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(W, transpose=False):
+    nout, k = (W.shape[1], W.shape[0]) if transpose else W.shape
+    out = torch.empty(L.lib().ardae_packed_floats(nout, k), device="cuda", dtype=torch.float32)
+    L.check(L.lib().ardae_pack_weight(L.ptr(W), W.stride(0), nout, k, int(transpose), L.ptr(out), L.stream_ptr()))
+    return out
+
+
+def run_linear(epi, M, Nout, srcs, **kw):
+    a = L.LinearArgs()
+    a.M, a.Nout, a.nsrc = M, Nout, len(srcs)
+    keep = []
+    for i, (x, wp) in enumerate(srcs):
+        a.src[i].x = x.data_ptr(); a.src[i].ld = x.stride(0); a.src[i].K = x.shape[1]; a.src[i].wp = wp.data_ptr()
+        keep += [x, wp]
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            keep.append(v)
+            setattr(a, k, v.data_ptr())
+            ldname = {"S": "ldS", "R": "ldR", "Q": "ldQ", "eps": "ldeps", "Y": "ldY", "Y2": "ldY2", "rowbias": "rowbias_ld"}.get(k)
+            if ldname:
+                setattr(a, ldname, v.stride(0))
+        else:
+            setattr(a, k, v)
+    L.check(L.lib().ardae_linear(ctypes.byref(a), epi, L.stream_ptr()), "ardae_linear")
+    torch.cuda.synchronize()
+
+
+def relerr(a, b):
+    return float((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def d1(act, a):
+    if act == "softplus":
+        return -torch.expm1(-a)
+    if act == "relu":
+        return (a > 0).double()
+    return torch.ones_like(a)
+
+
+@pytest.mark.parametrize("M,K,Nout", [(64, 256, 256), (200, 100, 256), (131, 37, 96), (512, 784, 256),
+                                      (96, 256, 32), (300, 64, 8), (64, 2, 64), (1024, 512, 512), (70, 266, 2)])
+@pytest.mark.parametrize("act", ["none", "relu", "softplus"])
+def test_linear_act(M, K, Nout, act):
+    g = torch.Generator().manual_seed(M * 7 + K * 3 + Nout)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(Nout, K, generator=g) / K ** 0.5
+    b = torch.randn(Nout, generator=g)
+    rpg = 8
+    rb = torch.randn((M + rpg - 1) // rpg, Nout, generator=g)
+    sig = torch.randn(M, generator=g)
+    wsig = torch.randn(Nout, generator=g)
+    pre = X.double() @ W.double().T + b.double() + rb.double().repeat_interleave(rpg, 0)[:M] + sig.double()[:, None] * wsig.double()
+    ref = {"none": pre, "relu": pre.clamp(min=0), "softplus": torch.nn.functional.softplus(pre)}[act]
+    Xd, Wd = X.cuda(), W.cuda()
+    Y = torch.full((M, Nout), float("nan"), device="cuda")
+    run_linear(L.EPI_ACT, M, Nout, [(Xd, pack(Wd))], act=L.ACT[act], bias=b.cuda(), rowbias=rb.cuda(), rows_per_group=rpg,
+               rowscale=sig.cuda(), rowscale_w=wsig.cuda(), Y=Y)
+    assert relerr(Y, ref) < 2e-5
+
+
+def test_linear_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C/D or operand map (guide section 3)."""
+    n = 64
+    X = torch.eye(n)
+    W = (torch.arange(n * n, dtype=torch.float32).view(n, n) % 97) - 40.0
+    Y = torch.empty(n, n, device="cuda")
+    run_linear(L.EPI_ACT, n, n, [(X.cuda(), pack(W.cuda()))], act=0, Y=Y)
+    assert torch.equal(Y.cpu(), W.T.contiguous())
+
+
+def test_linear_transposed_pack_and_two_sources():
+    g = torch.Generator().manual_seed(5)
+    M, K1, K2, Nout = 192, 256, 10, 256
+    X1, X2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    Wfull = torch.randn(Nout, K1 + K2, generator=g) / 16            # one [out, in] matrix, two column slices
+    Wt = torch.randn(K1, Nout, generator=g) / 16                     # used transposed (backward-style product)
+    Wf = Wfull.cuda()
+    Y = torch.empty(M, Nout, device="cuda")
+    run_linear(L.EPI_ACT, M, Nout, [(X1.cuda(), pack(Wf[:, :K1])), (X2.cuda(), pack(Wf[:, K1:]))], act=0, Y=Y)
+    ref = torch.cat([X1, X2], 1).double() @ Wfull.double().T
+    assert relerr(Y, ref) < 2e-5
+    run_linear(L.EPI_ACT, M, Nout, [(X1.cuda(), pack(Wt.cuda(), transpose=True))], act=0, Y=Y)
+    assert relerr(Y, X1.double() @ Wt.double()) < 2e-5
+
+
+@pytest.mark.parametrize("act", ["relu", "softplus"])
+def test_linear_dact_and_colsum(act):
+    g = torch.Generator().manual_seed(11)
+    M, K, Nout = 200, 256, 256
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / 16
+    S = torch.nn.functional.softplus(torch.randn(M, Nout, generator=g) * 3) if act == "softplus" else torch.randn(M, Nout, generator=g).clamp(min=0)
+    Q = torch.randn(M, Nout, generator=g)
+    ref = (X.double() @ W.double().T) * d1(act, S.double()) + Q.double()
+    Y = torch.empty(M, Nout, device="cuda")
+    tiles = L.lib().ardae_linear_row_tiles(M, Nout)
+    cs = torch.zeros(tiles, Nout, device="cuda")
+    run_linear(L.EPI_DACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], S=S.cuda(), Q=Q.cuda(), Y=Y, colsum=cs)
+    assert relerr(Y, ref) < 2e-5
+    assert relerr(cs.sum(0), ref.sum(0)) < 2e-5
+
+
+def test_linear_chain():
+    g = torch.Generator().manual_seed(12)
+    M, K, Nout = 128, 256, 256
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / 16
+    S = torch.nn.functional.softplus(torch.randn(M, Nout, generator=g) * 3)
+    R = torch.randn(M, Nout, generator=g)
+    v = X.double() @ W.double().T
+    s = d1("softplus", S.double())
+    Y = torch.empty(M, Nout, device="cuda"); Y2 = torch.empty(M, Nout, device="cuda")
+    run_linear(L.EPI_CHAIN, M, Nout, [(X.cuda(), pack(W.cuda()))], act=2, S=S.cuda(), R=R.cuda(), Y=Y, Y2=Y2)
+    assert relerr(Y, v * s) < 2e-5
+    assert relerr(Y2, v * R.double() * (1 - s)) < 2e-5
+
+
+@pytest.mark.parametrize("z", [32, 8, 2])
+def test_linear_dae_loss(z):
+    g = torch.Generator().manual_seed(13)
+    M, K = 300, 256
+    X = torch.randn(M, K, generator=g); W = torch.randn(z, K, generator=g) / 16
+    sig = torch.randn(M, generator=g); eps = torch.randn(M, z, generator=g)
+    gref = X.double() @ W.double().T
+    rho = sig.double()[:, None] * gref + eps.double()
+    scale = 1.0 / (M * z)
+    Y = torch.empty(M, z, device="cuda"); Y2 = torch.empty(M, z, device="cuda")
+    tiles = L.lib().ardae_linear_row_tiles(M, z) * L.lib().ardae_linear_col_panels(z)
+    tl = torch.zeros(tiles, device="cuda")
+    run_linear(L.EPI_DAE_LOSS, M, z, [(X.cuda(), pack(W.cuda()))], sigma=sig.cuda(), eps=eps.cuda(), scale=scale, Y=Y, Y2=Y2, tile_loss=tl)
+    assert relerr(Y, gref) < 2e-5
+    assert relerr(Y2, 2 * sig.double()[:, None] * rho * scale) < 2e-5
+    assert abs(float(tl.sum().cpu()) - float((rho ** 2).sum())) / float((rho ** 2).sum()) < 1e-5
+
+
+def test_linear_rejects_bad_args():
+    a = L.LinearArgs()
+    with pytest.raises(ValueError):
+        L.check(L.lib().ardae_linear(ctypes.byref(a), 0, None))
