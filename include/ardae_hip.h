@@ -29,7 +29,8 @@ enum { ARDAE_ACT_NONE = 0, ARDAE_ACT_RELU = 1, ARDAE_ACT_SOFTPLUS = 2 };
 
 /* epilogues of ardae_linear */
 enum {
-  ARDAE_EPI_ACT = 0,      /* Y = act(V + bias[c] + rowbias[r / rows_per_group][c] + rowscale[r] * rowscale_w[c])        */
+  ARDAE_EPI_ACT = 0,      /* Y = act(V + bias[c] + rowbias[r / rows_per_group][c] + rowscale[r] * rowscale_w[c]);
+                             if Y2: Y2 = -R[c] * act'(Y)  (R is an [Nout] vector: seed of the score pass)               */
   ARDAE_EPI_DACT = 1,     /* Y = V * act'(S) (+ Q)          : one back-prop step through Linear->act                    */
   ARDAE_EPI_CHAIN = 2,    /* Y = V * act'(S); Y2 = V * R * (1 - act'(S)) : forward-mode step of the double backward    */
   ARDAE_EPI_DAE_LOSS = 3  /* g = V + bias; rho = sigma[r]*g + eps; Y = g; Y2 = 2*sigma*rho*scale; tile_loss += rho^2   */
@@ -76,6 +77,77 @@ int ardae_linear_col_panels(int nout);
 /* M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]  ->  MFMA-lane-linear image (out: ardae_packed_floats) */
 int ardae_pack_weight(const float* W, int ldw, int nout, int k, int transpose, float* out, void* stream);
 int ardae_linear(const ardae_linear_args* args, int epilogue, void* stream);
+
+
+/* ---- K6w: batched weight gradients  dW[o][i] = sum_pairs sum_m G[m][o] X[m][i]  -------------------------------
+ * replaces the grad_weight / grad_bias products of autograd's Linear backward executed by
+ * cdae_loss.backward() (ivae_ardae.py:771) and model_loss.backward() / latent.backward(grad) (:804,:834).      */
+#define ARDAE_WGRAD_MAX_PROBLEMS 20
+typedef struct ardae_wgrad_problem {
+  int M, O, I;
+  int npairs;                 /* 1 or 2 (G,X) pairs summed into the same dW                                  */
+  const float* G[2]; int ldG[2]; /* [M, O] output-side factors                                               */
+  const float* X[2]; int ldX[2]; /* [M, I] input-side factors                                                */
+  int bias_pair;              /* pair whose G is column-summed into out_bias / out_rowscale, or -1           */
+  const float* rowscale;      /* optional [M]: out_rowscale[o] = sum_m rowscale[m] * G[bias_pair][m][o]      */
+  int splits;                 /* row splits, from ardae_wgrad_splits                                         */
+  float* partial;             /* scratch [splits, O, I]                                                      */
+  float* partial_vec;         /* scratch [splits, 2, O] (needed when bias_pair >= 0)                         */
+  float* out; int ldout;      /* [O, I] view of the gradient buffer (row stride ldout)                       */
+  float* out_bias;            /* [O] or NULL                                                                 */
+  float* out_rowscale; int ld_rowscale; /* strided [O] (one column of an [O, *] matrix) or NULL              */
+  float beta;                 /* out = beta*out + sum                                                        */
+} ardae_wgrad_problem;
+int ardae_wgrad_splits(int M, int O, int I, int nproblems_hint);
+int ardae_wgrad_batch(const ardae_wgrad_problem* problems, int nproblems, void* stream);
+
+
+/* ---- helper kernels ---------------------------------------------------------------------------------------- */
+/* ivae_ardae.py:753-761 + models/graddae/mlp.py:21-23:  u = s(z - z0[b]); std_b = delta*mean_d(std_nz(u)) (unbiased);
+ * sigma[b,i] = std_b*xi[b,i]; xbar = u + sigma*eps.   latent [B,nz,z], z0 [B,z], xi [B*nz], eps [B*nz,z]            */
+int ardae_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int z,
+                         float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream);
+/* u = s (z - z0[b])  (ivae_ardae.py:827) */
+int ardae_center_scale(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float* u, void* stream);
+/* Philox4x32-10 counter RNG (replaces torch.randn at ivae/mnist.py:73, ivae_ardae.py:761, graddae/mlp.py:22) */
+int ardae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+int ardae_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* dynamic binarisation x ~ Bernoulli(p[col]) (datasets/mnist.py:36-40) */
+int ardae_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t seed, uint64_t offset, void* stream);
+/* utils/optim.py:49-108 (vendored Adam, eps before the bias correction); vmax non-NULL = amsgrad; step >= 1 */
+int ardae_adam_ref_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
+                        double lr, double beta1, double beta2, double eps, int step, void* stream);
+/* torch.optim.RMSprop(lr, momentum) as built at ivae_ardae.py:625-626 (alpha .99, eps 1e-8, not centred) */
+int ardae_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buffer, int64_t n, double lr,
+                       double alpha, double eps, double momentum, void* stream);
+
+/* ---- K4-K6: conditional AR-DAE (models/graddae/mlp.py:341-483, models/resdae/mlp.py:286-413) -----------------
+ * Parameters live in ONE flat fp32 buffer in the reference's named_parameters() order
+ * (ctx_encode.layers.*, ctx_encode.fc, inp_encode.*, neglogprob.* | dae.*), each tensor [out,in] row-major. */
+typedef struct ardae_cdae_desc {
+  int kind;        /* 0 = mlp-grad (MLPGradCARDAE: score = input-gradient of an energy MLP), 1 = mlp-res (direct score) */
+  int input_dim;   /* z */
+  int context_dim; /* c */
+  int h_dim;
+  int n_layers;    /* --cdae-n-layers */
+  int act;         /* ARDAE_ACT_SOFTPLUS (mlp-grad needs a twice-differentiable activation)                          */
+} ardae_cdae_desc;
+size_t ardae_cdae_param_floats(const ardae_cdae_desc* d);
+size_t ardae_cdae_packed_floats(const ardae_cdae_desc* d);
+size_t ardae_cdae_workspace_floats(const ardae_cdae_desc* d, int B, int S, int need_grads);
+/* refresh the MFMA-packed weight images after every optimiser step */
+int ardae_cdae_pack(const ardae_cdae_desc* d, const float* params, float* packed, void* stream);
+/* ConditionalARDAE.forward + loss.backward() fused: DAE loss  mean((sigma*score(xbar|ctx,sigma) + eps)^2)  and the
+ * gradient of every parameter (graddae/mlp.py:400-444 + ivae_ardae.py:771).  xbar [B*S,z] (already perturbed),
+ * sigma [B*S], eps [B*S,z], ctx [B,c]; loss: device scalar; grads: flat buffer (parameter layout), OVERWRITTEN
+ * except neglogprob.fc.bias which receives no gradient in the reference and is left untouched; score_out optional. */
+int ardae_cdae_loss_grads(const ardae_cdae_desc* d, const float* params, const float* packed, const float* xbar,
+                          const float* sigma, const float* eps, const float* ctx, int B, int S, float* workspace,
+                          size_t workspace_floats, float* loss, float* grads, float* score_out, void* stream);
+/* ConditionalARDAE.glogprob (graddae/mlp.py:446-483): score at x [B*S,z] for noise level sigma [B*S] */
+int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float* packed, const float* x,
+                     const float* sigma, const float* ctx, int B, int S, float* workspace, size_t workspace_floats,
+                     float* score_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,7 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
     _, closs = cdae(u_exp, context, std=stdmat, scale=tc.std_scale)
     closs.backward()
     out["z0"] = latent_mean.clone(); out["latent"] = latent.clone(); out["std"] = std.clone()
+    out["u_rows"] = u_exp.reshape(-1, u.size(-1)).clone(); out["sigma_rows"] = stdmat.reshape(-1).clone()
     out["cdae_loss"] = closs.detach().clone()
     out["cdae_grads"] = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in cdae.named_parameters()}
     c_opt.step()
@@ -205,8 +206,11 @@ def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0
         fx[pre + "x_cdae"] = xc.numpy(); fx[pre + "x_vae"] = xv.numpy()
         for k, v in noise.items():
             fx[pre + "noise/" + k] = v.numpy()
-        for k in ("cdae_loss", "model_loss", "recon", "prior", "std", "score", "z0"):
+        for k in ("cdae_loss", "model_loss", "recon", "prior", "std", "score", "z0", "sigma_rows"):
             fx[pre + k] = ref[k].numpy()
+        # the exact cDAE inputs the reference saw (u = 1e4 (z - z0) amplifies last-bit differences of the sampler
+        # between machines, so tests feed these instead of recomputing them)
+        fx[pre + "xbar"] = (ref["u_rows"] + ref["sigma_rows"][:, None] * noise["eps"]).numpy()
         if store_full:
             fx[pre + "latent"] = ref["latent"].numpy()
             fx[pre + "vae_latent"] = ref["vae_latent"].numpy()

@@ -38,6 +38,28 @@ class LinearArgs(ctypes.Structure):
     ]
 
 
+class WgradProblem(ctypes.Structure):
+    _fields_ = [
+        ("M", ctypes.c_int), ("O", ctypes.c_int), ("I", ctypes.c_int), ("npairs", ctypes.c_int),
+        ("G", ctypes.c_void_p * 2), ("ldG", ctypes.c_int * 2),
+        ("X", ctypes.c_void_p * 2), ("ldX", ctypes.c_int * 2),
+        ("bias_pair", ctypes.c_int),
+        ("rowscale", ctypes.c_void_p),
+        ("splits", ctypes.c_int),
+        ("partial", ctypes.c_void_p),
+        ("partial_vec", ctypes.c_void_p),
+        ("out", ctypes.c_void_p), ("ldout", ctypes.c_int),
+        ("out_bias", ctypes.c_void_p),
+        ("out_rowscale", ctypes.c_void_p), ("ld_rowscale", ctypes.c_int),
+        ("beta", ctypes.c_float),
+    ]
+
+
+class CdaeDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("input_dim", ctypes.c_int), ("context_dim", ctypes.c_int),
+                ("h_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
+
+
 ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2}
 EPI_ACT, EPI_DACT, EPI_CHAIN, EPI_DAE_LOSS = 0, 1, 2, 3
 
@@ -51,6 +73,24 @@ EXPORTS = {
     "ardae_pack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_linear": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_void_p]),
+    "ardae_wgrad_splits": (ctypes.c_int, [ctypes.c_int] * 4),
+    "ardae_wgrad_batch": (ctypes.c_int, [ctypes.POINTER(WgradProblem), ctypes.c_int, ctypes.c_void_p]),
+    "ardae_latent_perturb": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 4),
+    "ardae_center_scale": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2),
+    "ardae_philox_normal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),
+    "ardae_philox_uniform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),
+    "ardae_bernoulli": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
+                                       ctypes.c_uint64, ctypes.c_void_p]),
+    "ardae_adam_ref_step": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_int, ctypes.c_void_p]),
+    "ardae_rmsprop_step": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
+    "ardae_cdae_param_floats": (ctypes.c_size_t, [ctypes.POINTER(CdaeDesc)]),
+    "ardae_cdae_packed_floats": (ctypes.c_size_t, [ctypes.POINTER(CdaeDesc)]),
+    "ardae_cdae_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(CdaeDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ardae_cdae_pack": (ctypes.c_int, [ctypes.POINTER(CdaeDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "ardae_cdae_loss_grads": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 4),
+    "ardae_cdae_score": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 2),
 }
 
 _lib = None

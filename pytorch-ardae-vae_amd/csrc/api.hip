@@ -3,7 +3,9 @@
 
 #include "ardae_hip.h"
 #include "common.h"
+#include "elementwise.h"
 #include "linear.h"
+#include "wgrad.h"
 
 namespace ardae {
 static thread_local char g_last_error[512] = "";
@@ -33,6 +35,36 @@ int ardae_pack_weight(const float* W, int ldw, int nout, int k, int transpose, f
 int ardae_linear(const ardae_linear_args* args, int epilogue, void* stream) {
   ARDAE_CHECK_ARG(args != nullptr, "ardae_linear: args is NULL");
   return launch_linear(*args, epilogue, (hipStream_t)stream);
+}
+
+int ardae_wgrad_splits(int M, int O, int I, int nproblems_hint) { return wgrad_splits(M, O, I, nproblems_hint); }
+int ardae_wgrad_batch(const ardae_wgrad_problem* problems, int nproblems, void* stream) {
+  return launch_wgrad_batch(problems, nproblems, (hipStream_t)stream);
+}
+
+int ardae_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int z,
+                         float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream) {
+  return launch_latent_perturb(latent, z0, xi, eps, B, nz, z, std_scale, delta, xbar, sigma, std_b, (hipStream_t)stream);
+}
+int ardae_center_scale(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float* u, void* stream) {
+  return launch_center_scale(latent, z0, B, nz, z, std_scale, u, (hipStream_t)stream);
+}
+int ardae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  return launch_philox_normal(out, n, seed, offset, (hipStream_t)stream);
+}
+int ardae_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  return launch_philox_uniform(out, n, seed, offset, (hipStream_t)stream);
+}
+int ardae_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t seed, uint64_t offset, void* stream) {
+  return launch_bernoulli(p, rows, cols, out, seed, offset, (hipStream_t)stream);
+}
+int ardae_adam_ref_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
+                        double lr, double beta1, double beta2, double eps, int step, void* stream) {
+  return launch_adam_ref(p, g, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+}
+int ardae_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buffer, int64_t n, double lr,
+                       double alpha, double eps, double momentum, void* stream) {
+  return launch_rmsprop(p, g, square_avg, momentum_buffer, n, lr, alpha, eps, momentum, (hipStream_t)stream);
 }
 
 }  // extern "C"

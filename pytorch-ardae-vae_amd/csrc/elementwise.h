@@ -1,0 +1,35 @@
+// Bandwidth-bound helper kernels of the AR-DAE-VAE step (latent statistics, noise, reductions, optimisers, losses).
+#pragma once
+#include "ardae_hip.h"
+#include "common.h"
+
+namespace ardae {
+
+// ivae_ardae.py:753-761 + models/graddae/mlp.py:21-23:
+//   u = s (z - z0[b]);  std_b = delta * mean_d( std_unbiased_over_nz(u[:, d]) );
+//   sigma[b, i] = std_b * xi[b, i];  xbar = u + sigma * eps
+int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int zd,
+                          float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st);
+// u = s (z - z0[b]) only (VAE phase, sigma = 0: ivae_ardae.py:827)
+int launch_center_scale(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float* u,
+                        hipStream_t st);
+// out[g][c] = scale * sum_{r < rows_per_group} in[g*rows_per_group + r][c]
+int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, int cols, float scale, float* out, int ldout,
+                       hipStream_t st);
+// out[0] = scale * sum_i in[i]   (fixed order)
+int launch_sum_scale(const float* in, int n, float scale, float* out, hipStream_t st);
+// dst[i] = src[i*stride]
+int launch_gather_strided(const float* src, int stride, int n, float* dst, hipStream_t st);
+// Philox4x32-10 + Box-Muller standard normals; element i depends only on (seed, offset, i)
+int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st);
+int launch_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st);
+int launch_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t seed, uint64_t offset, hipStream_t st);
+
+// utils/optim.py:86-106 (old-style Adam: eps added before the bias correction)
+int launch_adam_ref(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
+                    double eps, int step, hipStream_t st);
+// torch.optim.RMSprop(lr, momentum) as constructed at ivae_ardae.py:625-626 (alpha, eps defaults; not centred)
+int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, double lr, double alpha, double eps,
+                   double momentum, hipStream_t st);
+
+}  // namespace ardae

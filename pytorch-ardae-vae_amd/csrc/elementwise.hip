@@ -1,0 +1,304 @@
+// Bandwidth-bound helper kernels (gfx950).  See elementwise.h for the operator definitions + reference lines.
+#include "elementwise.h"
+
+namespace ardae {
+namespace {
+
+// ------------------------------------------------------------------------------------------ Philox4x32-10
+struct Philox {
+  uint32_t c[4];
+  uint32_t k[2];
+};
+__device__ __forceinline__ void philox_round(Philox& s) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, s.c[0]), lo0 = M0 * s.c[0];
+  const uint32_t hi1 = __umulhi(M1, s.c[2]), lo1 = M1 * s.c[2];
+  const uint32_t n0 = hi1 ^ s.c[1] ^ s.k[0], n1 = lo1, n2 = hi0 ^ s.c[3] ^ s.k[1], n3 = lo0;
+  s.c[0] = n0; s.c[1] = n1; s.c[2] = n2; s.c[3] = n3;
+  s.k[0] += 0x9E3779B9u;
+  s.k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t offset, uint64_t idx, uint32_t out[4]) {
+  Philox s;
+  s.c[0] = (uint32_t)idx; s.c[1] = (uint32_t)(idx >> 32);
+  s.c[2] = (uint32_t)offset; s.c[3] = (uint32_t)(offset >> 32);
+  s.k[0] = (uint32_t)seed; s.k[1] = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(s);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = s.c[i];
+}
+__device__ __forceinline__ float u01_open(uint32_t x) { return ((x >> 8) + 1u) * (1.0f / 16777216.0f); }  // (0,1]
+
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one counter = 4 normals
+  if (q * 4 >= n) return;
+  uint32_t r[4];
+  philox4(seed, offset, (uint64_t)q, r);
+  float v[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float rad = sqrtf(-2.0f * logf(u01_open(r[2 * h])));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u01_open(r[2 * h + 1]), &sn, &cs);
+    v[2 * h] = rad * cs;
+    v[2 * h + 1] = rad * sn;
+  }
+  if (q * 4 + 4 <= n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+    *reinterpret_cast<f32x4*>(out + q * 4) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    for (int i = 0; i < 4 && q * 4 + i < n; ++i) out[q * 4 + i] = v[i];
+  }
+}
+
+__global__ void philox_uniform_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q * 4 >= n) return;
+  uint32_t r[4];
+  philox4(seed, offset, (uint64_t)q, r);
+  for (int i = 0; i < 4 && q * 4 + i < n; ++i) out[q * 4 + i] = (r[i] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+}
+
+// dynamic binarisation (datasets/mnist.py:36-40): out = Bernoulli(p[col])
+__global__ void bernoulli_kernel(const float* __restrict__ p, int64_t rows, int cols, float* __restrict__ out, uint64_t seed,
+                                 uint64_t offset) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = rows * cols;
+  if (q * 4 >= n) return;
+  uint32_t r[4];
+  philox4(seed, offset, (uint64_t)q, r);
+  for (int i = 0; i < 4 && q * 4 + i < n; ++i) {
+    const int64_t e = q * 4 + i;
+    out[e] = ((r[i] >> 8) * (1.0f / 16777216.0f)) < p[e % cols] ? 1.f : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ latent statistics
+// one workgroup per image; thread (rg, d): d = t % zp, rg = t / zp
+__global__ __launch_bounds__(256) void latent_perturb_kernel(const float* __restrict__ latent, const float* __restrict__ z0,
+                                                             const float* __restrict__ xi, const float* __restrict__ eps, int nz,
+                                                             int zd, int zp, float std_scale, float delta,
+                                                             float* __restrict__ xbar, float* __restrict__ sigma,
+                                                             float* __restrict__ std_b) {
+  __shared__ float red[256];
+  __shared__ float stat[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int d = t % zp, rg = t / zp, RG = 256 / zp;
+  const float* lat = latent + (size_t)b * nz * zd;
+  const float z0d = d < zd ? z0[(size_t)b * zd + d] : 0.f;
+  // pass 1: mean of u over the nz samples
+  float s = 0.f;
+  if (d < zd)
+    for (int r = rg; r < nz; r += RG) s += std_scale * (lat[(size_t)r * zd + d] - z0d);
+  red[t] = s;
+  __syncthreads();
+  if (rg == 0) {
+    float acc = 0.f;
+    for (int g = 0; g < RG; ++g) acc += red[g * zp + d];
+    stat[d] = acc / (float)nz;
+  }
+  __syncthreads();
+  const float mean = stat[d];
+  __syncthreads();
+  // pass 2: unbiased variance
+  float ss = 0.f;
+  if (d < zd)
+    for (int r = rg; r < nz; r += RG) {
+      const float u = std_scale * (lat[(size_t)r * zd + d] - z0d) - mean;
+      ss += u * u;
+    }
+  red[t] = ss;
+  __syncthreads();
+  if (rg == 0) {
+    float acc = 0.f;
+    for (int g = 0; g < RG; ++g) acc += red[g * zp + d];
+    stat[d] = d < zd ? sqrtf(acc / (float)(nz - 1)) : 0.f;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < zd; ++i) acc += stat[i];
+    red[0] = delta * (acc / (float)zd);
+  }
+  __syncthreads();
+  const float sb = red[0];
+  if (t == 0) std_b[b] = sb;
+  // perturb
+  for (int e = t; e < nz * zd; e += 256) {
+    const int r = e / zd, dd = e - r * zd;
+    const size_t row = (size_t)b * nz + r;
+    const float sg = sb * xi[row];
+    const float u = std_scale * (lat[e] - z0[(size_t)b * zd + dd]);
+    xbar[row * zd + dd] = u + sg * eps[row * zd + dd];
+    if (dd == 0) sigma[row] = sg;
+  }
+}
+
+__global__ void center_scale_kernel(const float* __restrict__ latent, const float* __restrict__ z0, int64_t n, int nz, int zd,
+                                    float std_scale, float* __restrict__ u) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int64_t row = e / zd;
+  const int d = (int)(e - row * zd);
+  u[e] = std_scale * (latent[e] - z0[(row / nz) * zd + d]);
+}
+
+__global__ void segment_sum_kernel(const float* __restrict__ in, int ld, int rows_per_group, int cols, float scale,
+                                   float* __restrict__ out, int ldout) {
+  const int g = blockIdx.x;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float* p = in + (size_t)g * rows_per_group * ld + c;
+    float s = 0.f;
+    for (int r = 0; r < rows_per_group; ++r) s += p[(size_t)r * ld];
+    out[(size_t)g * ldout + c] = s * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ in, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+__global__ void gather_strided_kernel(const float* __restrict__ src, int stride, int n, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[(size_t)i * stride];
+}
+
+// ------------------------------------------------------------------------------------------ optimisers
+__global__ void adam_ref_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                float* __restrict__ vmax, int64_t n, float beta1, float beta2, float eps, float step_size,
+                                float sqrt_bc2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+    float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    if (vmax) {
+      vi = fmaxf(vmax[i], vi);
+      vmax[i] = vi;
+    }
+    const float denom = (sqrtf(vi) + eps) / sqrt_bc2;   // eps BEFORE the bias correction (utils/optim.py:102)
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ buf,
+                               int64_t n, float lr, float alpha, float eps, float momentum) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float s = sq[i] * alpha + (1.f - alpha) * gi * gi;
+    sq[i] = s;
+    const float avg = sqrtf(s) + eps;
+    if (momentum > 0.f) {
+      const float bi = buf[i] * momentum + gi / avg;
+      buf[i] = bi;
+      p[i] = p[i] - lr * bi;
+    } else {
+      p[i] = p[i] - lr * (gi / avg);
+    }
+  }
+}
+
+inline int grid_for(int64_t n, int cap = 4096) {
+  int64_t g = (n + 255) / 256;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int zd,
+                          float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st) {
+  ARDAE_CHECK_ARG(latent && z0 && xi && eps && xbar && sigma && std_b, "latent_perturb: null pointer");
+  ARDAE_CHECK_ARG(B > 0 && nz >= 2 && zd >= 1 && zd <= 256, "latent_perturb: need B>0, nz>=2 (unbiased std), 1<=z<=256 (B=%d nz=%d z=%d)", B, nz, zd);
+  int zp = 1;
+  while (zp < zd) zp <<= 1;
+  hipLaunchKernelGGL(latent_perturb_kernel, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, zp, std_scale, delta, xbar,
+                     sigma, std_b);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_center_scale(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float* u, hipStream_t st) {
+  ARDAE_CHECK_ARG(latent && z0 && u && B > 0 && nz > 0 && zd > 0, "center_scale: bad arguments");
+  const int64_t n = (int64_t)B * nz * zd;
+  hipLaunchKernelGGL(center_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latent, z0, n, nz, zd, std_scale, u);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, int cols, float scale, float* out, int ldout,
+                       hipStream_t st) {
+  ARDAE_CHECK_ARG(in && out && groups > 0 && rows_per_group > 0 && cols > 0 && ld >= cols && ldout >= cols, "segment_sum: bad arguments");
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(groups), dim3(256), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sum_scale(const float* in, int n, float scale, float* out, hipStream_t st) {
+  ARDAE_CHECK_ARG(in && out && n > 0, "sum_scale: bad arguments");
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, in, n, scale, out);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gather_strided(const float* src, int stride, int n, float* dst, hipStream_t st) {
+  ARDAE_CHECK_ARG(src && dst && n > 0 && stride > 0, "gather_strided: bad arguments");
+  hipLaunchKernelGGL(gather_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, stride, n, dst);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st) {
+  ARDAE_CHECK_ARG(out && n > 0, "philox_normal: bad arguments");
+  const int64_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st) {
+  ARDAE_CHECK_ARG(out && n > 0, "philox_uniform: bad arguments");
+  const int64_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t seed, uint64_t offset, hipStream_t st) {
+  ARDAE_CHECK_ARG(p && out && rows > 0 && cols > 0, "bernoulli: bad arguments");
+  const int64_t q = (rows * cols + 3) / 4;
+  hipLaunchKernelGGL(bernoulli_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, p, rows, cols, out, seed, offset);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam_ref(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
+                    double eps, int step, hipStream_t st) {
+  ARDAE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_ref: bad arguments");
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  hipLaunchKernelGGL(adam_ref_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, vmax, n, (float)beta1, (float)beta2,
+                     (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, double lr, double alpha, double eps, double momentum,
+                   hipStream_t st) {
+  ARDAE_CHECK_ARG(p && g && sq && n > 0 && (momentum <= 0.0 || buf), "rmsprop: bad arguments");
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, sq, buf, n, (float)lr, (float)alpha, (float)eps,
+                     (float)momentum);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ardae

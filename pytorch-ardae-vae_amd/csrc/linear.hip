@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinArgs a) {
             if (a.rowscale) v += a.rowscale[row] * wsig;
             y = act_fwd<ACT>(v);
             a.Y[(size_t)row * a.ldY + col] = y;
+            // optional seed of the score pass: e_L = -w (.) act'(pre)   (R is the [Nout] vector w here)
+            if (a.Y2) a.Y2[(size_t)row * a.ldY2 + col] = -a.R[col] * act_d1<ACT>(y);
           } else if (EPI == EPI_DACT) {
             const float sd = act_d1<ACT>(a.S[(size_t)row * a.ldS + col]);
             y = v * sd;

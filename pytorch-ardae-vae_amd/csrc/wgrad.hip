@@ -1,0 +1,237 @@
+// Batched FP32-MFMA weight-gradient kernel for gfx950.  See wgrad.h.
+//
+// Workgroup tile: 128 (o) x 256 (i) outputs, 4 waves as 2(o) x 2(i), each wave 64 x 128 = 2 x 4 MFMA
+// 32x32 tiles (128 accumulator registers).  The reduction runs over ROWS m: a chunk of 32 rows of G and X
+// is staged in LDS as stored ([m][col], no transpose needed: with v_mfma_f32_32x32x2_f32 lane (c=l&31,
+// kk=l>>5) supplies A[o=c][k=kk] = G[m0+kk][o] and B[k=kk][i=c] = X[m0+kk][i], i.e. both fragment reads are
+// 32 consecutive floats per half-wave - conflict-free ds_read_b32).
+#include "wgrad.h"
+
+namespace ardae {
+namespace {
+
+constexpr int BO = 128, BI = 256, RC = 32;
+
+struct WgradBatchDev {
+  int nprob;
+  int wg_begin[WGRAD_MAX_PROBLEMS + 1];
+  int o_tiles[WGRAD_MAX_PROBLEMS];
+  int i_tiles[WGRAD_MAX_PROBLEMS];
+  WgradProblem p[WGRAD_MAX_PROBLEMS];
+};
+static_assert(sizeof(WgradBatchDev) <= 4000, "kernel argument block too large");
+
+__device__ __forceinline__ f32x4 load4_guard(const float* base, int ld, int row, int col, int row_end, int ncols,
+                                             bool vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (row < row_end && col < ncols) {
+    const float* p = base + (size_t)row * ld + col;
+    if (vec && col + 4 <= ncols) {
+      v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (col + j < ncols) v[j] = p[j];
+    }
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradBatchDev batch) {
+  __shared__ float Gs[RC * BO];
+  __shared__ float Xs[RC * BI];
+
+  int pi = 0;
+  while (pi + 1 < batch.nprob && (int)blockIdx.x >= batch.wg_begin[pi + 1]) ++pi;
+  const WgradProblem& P = batch.p[pi];
+  const int local = blockIdx.x - batch.wg_begin[pi];
+  const int split = local % P.splits;
+  const int t2 = local / P.splits;
+  const int it = t2 % batch.i_tiles[pi];
+  const int ot = t2 / batch.i_tiles[pi];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wo = wave >> 1, wi = wave & 1;
+
+  const int rows_per_split = ((P.M + P.splits - 1) / P.splits + RC - 1) / RC * RC;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(P.M, m_begin + rows_per_split);
+
+  const int o_base = ot * BO, i_base = it * BI;
+  const int nib = max(0, min(4, (P.I - (i_base + wi * 128) + 31) >> 5));   // valid 32-col blocks of this wave
+  const int nob = max(0, min(2, (P.O - (o_base + wo * 64) + 31) >> 5));
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f}, rsum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_vec = (P.bias_pair >= 0) && (it == 0) && (P.partial_vec != nullptr);
+
+  for (int pr = 0; pr < P.npairs; ++pr) {
+    const float* __restrict__ G = P.G[pr];
+    const float* __restrict__ X = P.X[pr];
+    const int ldG = P.ldG[pr], ldX = P.ldX[pr];
+    const bool vecG = ((ldG & 3) == 0) && ((reinterpret_cast<uintptr_t>(G) & 15) == 0);
+    const bool vecX = ((ldX & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool acc_vec = want_vec && pr == P.bias_pair;
+    for (int m0 = m_begin; m0 < m_end; m0 += RC) {
+      __syncthreads();
+      {  // G chunk: 32 rows x 128 cols
+        const int c = (tid & 31) << 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = (tid >> 5) + 8 * j;
+          const f32x4 v = load4_guard(G, ldG, m0 + r, o_base + c, m_end, P.O, vecG);
+          *reinterpret_cast<f32x4*>(&Gs[r * BO + c]) = v;
+          if (acc_vec) {
+            bsum += v;
+            if (P.rowscale && m0 + r < m_end) rsum += v * P.rowscale[m0 + r];
+          }
+        }
+      }
+      {  // X chunk: 32 rows x 256 cols
+        const int c = (tid & 63) << 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = (tid >> 6) + 4 * j;
+          *reinterpret_cast<f32x4*>(&Xs[r * BI + c]) = load4_guard(X, ldX, m0 + r, i_base + c, m_end, P.I, vecX);
+        }
+      }
+      __syncthreads();
+      if (nib > 0 && nob > 0) {
+        const float* ga = &Gs[hh * BO + wo * 64 + l31];
+        const float* xb = &Xs[hh * BI + wi * 128 + l31];
+#pragma unroll 4
+        for (int ks = 0; ks < RC / 2; ++ks) {
+          float av[2], bv[4];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) av[a] = ga[ks * 2 * BO + a * 32];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) bv[b] = xb[ks * 2 * BI + b * 32];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (b < nib) {
+#pragma unroll
+              for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- partial tile store: partial[split][o][i]
+  float* __restrict__ part = P.partial + (size_t)split * P.O * P.I;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i_base + wi * 128 + b * 32 + l31;
+      if (a < nob && b < nib && i < P.I) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o_base + wo * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (o < P.O) part[(size_t)o * P.I + i] = acc[a][b][r];
+        }
+      }
+    }
+  }
+  // ---- column sums of G (bias gradient) and sigma-weighted column sums (the sigma column of W1)
+  if (want_vec) {
+    __syncthreads();
+    const int c = (tid & 31) << 2, rg = tid >> 5;
+    *reinterpret_cast<f32x4*>(&Gs[rg * BO + c]) = bsum;
+    *reinterpret_cast<f32x4*>(&Xs[rg * BO + c]) = rsum;
+    __syncthreads();
+    if (tid < BO && o_base + tid < P.O) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        s0 += Gs[g * BO + tid];
+        s1 += Xs[g * BO + tid];
+      }
+      P.partial_vec[((size_t)split * 2 + 0) * P.O + o_base + tid] = s0;
+      P.partial_vec[((size_t)split * 2 + 1) * P.O + o_base + tid] = s1;
+    }
+  }
+}
+
+// out = beta*out + sum_s partial[s]  (fixed order -> reproducible)
+__global__ void wgrad_reduce_kernel(const WgradBatchDev batch) {
+  const WgradProblem& P = batch.p[blockIdx.y];
+  const size_t n_mat = (size_t)P.O * P.I;
+  const size_t n_all = n_mat + ((P.bias_pair >= 0 && P.partial_vec) ? 2 * (size_t)P.O : 0);
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_all; e += (size_t)gridDim.x * blockDim.x) {
+    if (e < n_mat) {
+      float s = 0.f;
+      for (int sp = 0; sp < P.splits; ++sp) s += P.partial[(size_t)sp * n_mat + e];
+      const int o = (int)(e / P.I), i = (int)(e - (size_t)o * P.I);
+      float* dst = P.out + (size_t)o * P.ldout + i;
+      *dst = (P.beta != 0.f ? P.beta * *dst : 0.f) + s;
+    } else {
+      const size_t v = e - n_mat;
+      const int which = (int)(v / P.O), o = (int)(v % P.O);
+      float* dst = which == 0 ? (P.out_bias ? P.out_bias + o : nullptr)
+                              : (P.out_rowscale ? P.out_rowscale + (size_t)o * P.ld_rowscale : nullptr);
+      if (dst) {
+        float s = 0.f;
+        for (int sp = 0; sp < P.splits; ++sp) s += P.partial_vec[((size_t)sp * 2 + which) * P.O + o];
+        *dst = (P.beta != 0.f ? P.beta * *dst : 0.f) + s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int wgrad_splits(int M, int O, int I, int nproblems_hint) {
+  const int tiles = ceil_div(O, BO) * ceil_div(I, BI);
+  const int target = 1024;   // ~2 resident workgroups per CU x 256 CUs x 2 waves of work
+  int s = target / (tiles * (nproblems_hint > 0 ? nproblems_hint : 1));
+  const int max_s = ceil_div(M, 4 * RC);   // at least 4 chunks of rows per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return s;
+}
+
+int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
+  ARDAE_CHECK_ARG(probs && nprob >= 1 && nprob <= WGRAD_MAX_PROBLEMS, "wgrad: 1..%d problems per batch (got %d)",
+                  WGRAD_MAX_PROBLEMS, nprob);
+  WgradBatchDev b;
+  memset(&b, 0, sizeof(b));
+  b.nprob = nprob;
+  int total = 0;
+  size_t max_elems = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const WgradProblem& p = probs[i];
+    ARDAE_CHECK_ARG(p.M > 0 && p.O > 0 && p.I > 0, "wgrad[%d]: empty problem", i);
+    ARDAE_CHECK_ARG(p.npairs >= 1 && p.npairs <= 2, "wgrad[%d]: npairs must be 1 or 2", i);
+    for (int k = 0; k < p.npairs; ++k)
+      ARDAE_CHECK_ARG(p.G[k] && p.X[k] && p.ldG[k] >= p.O && p.ldX[k] >= p.I, "wgrad[%d]: bad pair %d", i, k);
+    ARDAE_CHECK_ARG(p.splits >= 1 && p.partial && p.out && p.ldout >= p.I, "wgrad[%d]: bad output/scratch", i);
+    ARDAE_CHECK_ARG(p.bias_pair < p.npairs, "wgrad[%d]: bias_pair out of range", i);
+    ARDAE_CHECK_ARG(p.bias_pair < 0 || p.partial_vec, "wgrad[%d]: bias_pair needs partial_vec", i);
+    b.p[i] = p;
+    b.o_tiles[i] = ceil_div(p.O, BO);
+    b.i_tiles[i] = ceil_div(p.I, BI);
+    b.wg_begin[i] = total;
+    total += b.o_tiles[i] * b.i_tiles[i] * p.splits;
+    const size_t el = (size_t)p.O * p.I + 2 * (size_t)p.O;
+    if (el > max_elems) max_elems = el;
+  }
+  b.wg_begin[nprob] = total;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(256), 0, st, b);
+  ARDAE_LAUNCH_CHECK();
+  const int rb = (int)ceil_div64((int64_t)max_elems, 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb < 1024 ? rb : 1024, nprob), dim3(256), 0, st, b);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace ardae
