@@ -143,15 +143,26 @@ __global__ void center_scale_kernel(const float* __restrict__ latent, const floa
   u[e] = std_scale * (latent[e] - z0[(row / nz) * zd + d]);
 }
 
-__global__ void segment_sum_kernel(const float* __restrict__ in, int ld, int rows_per_group, int cols, float scale,
-                                   float* __restrict__ out, int ldout) {
-  const int g = blockIdx.x;
-  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+// grid (groups, ceil(cols/64)); 256 threads = 4 row lanes x 64 consecutive columns (256-B coalesced rows)
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ in, int ld, int rows_per_group, int cols,
+                                                          float scale, float* __restrict__ out, int ldout) {
+  __shared__ float red[256];
+  const int g = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
     const float* p = in + (size_t)g * rows_per_group * ld + c;
-    float s = 0.f;
-    for (int r = 0; r < rows_per_group; ++r) s += p[(size_t)r * ld];
-    out[(size_t)g * ldout + c] = s * scale;
+    int r = rl;
+    for (; r + 12 < rows_per_group; r += 16) {
+      s0 += p[(size_t)r * ld];
+      s1 += p[(size_t)(r + 4) * ld];
+      s2 += p[(size_t)(r + 8) * ld];
+      s3 += p[(size_t)(r + 12) * ld];
+    }
+    for (; r < rows_per_group; r += 4) s0 += p[(size_t)r * ld];
   }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < cols) out[(size_t)g * ldout + c] = scale * ((red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]));
 }
 
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ in, int n, float scale, float* __restrict__ out) {
@@ -239,7 +250,7 @@ int launch_center_scale(const float* latent, const float* z0, int B, int nz, int
 int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, int cols, float scale, float* out, int ldout,
                        hipStream_t st) {
   ARDAE_CHECK_ARG(in && out && groups > 0 && rows_per_group > 0 && cols > 0 && ld >= cols && ldout >= cols, "segment_sum: bad arguments");
-  hipLaunchKernelGGL(segment_sum_kernel, dim3(groups), dim3(256), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(groups, ceil_div(cols, 64)), dim3(256), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

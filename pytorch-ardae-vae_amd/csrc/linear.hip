@@ -18,6 +18,16 @@ namespace ardae {
 
 namespace {
 
+// wide geometry: K panel staged in LDS per pass and the workgroups/CU it is compiled for
+#ifndef ARDAE_WIDE_KPANEL
+#define ARDAE_WIDE_KPANEL 128
+#endif
+constexpr int WIDE_KPANEL = ARDAE_WIDE_KPANEL;
+#ifndef ARDAE_WIDE_MINB
+#define ARDAE_WIDE_MINB ((ARDAE_WIDE_KPANEL <= 128) ? 3 : 2)
+#endif
+constexpr int WIDE_MINB = ARDAE_WIDE_MINB;
+
 template <int TM, int TN, int WM, int WN, int KPANEL>
 struct Geo {
   static constexpr int BM = TM * WM * 32;
@@ -26,8 +36,103 @@ struct Geo {
   static constexpr int LDS_FLOATS = BM * LDW;
 };
 
-template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT>
-__global__ __launch_bounds__(256, 2) void linear_kernel(const LinArgs a) {
+// Epilogue of one 32x32 accumulator block (16 registers per lane).  All operand loads of the block are issued
+// first, into registers, and only then the math + stores run: outputs may alias inputs (Y == Q in place), so the
+// compiler cannot hoist loads over stores by itself and an element-at-a-time epilogue serialises on HBM latency.
+template <int EPI, int ACT, bool FULL>
+__device__ __forceinline__ void epilogue_block(const LinArgs& a, const f32x16& acc, int rbase, int col, bool cok, float bcol,
+                                               float wsig, float& csum, float& loss_part) {
+  int rowv[16];
+  bool ok[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int raw = rbase + (r & 3) + 8 * (r >> 2);
+    ok[r] = FULL ? true : (cok && raw < a.M);
+    rowv[r] = FULL ? raw : min(raw, a.M - 1);
+  }
+  float y[16];
+  if (EPI == EPI_ACT) {
+    float rb[16], rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rb[r] = 0.f, rs[r] = 0.f;
+    if (a.rowbias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rb[r] = a.rowbias[(size_t)(rowv[r] / a.rows_per_group) * a.rowbias_ld + col];
+    }
+    if (a.rowscale) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rs[r] = a.rowscale[rowv[r]];
+    }
+    const float wv = a.Y2 ? a.R[col] : 0.f;   // R is the [Nout] vector w here
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = act_fwd<ACT>(acc[r] + bcol + rb[r] + rs[r] * wsig);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
+    if (a.Y2) {   // seed of the score pass: e_L = -w (.) act'(pre)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok[r]) a.Y2[(size_t)rowv[r] * a.ldY2 + col] = -wv * act_d1<ACT>(y[r]);
+    }
+  } else if (EPI == EPI_DACT) {
+    float sv[16], qv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
+    if (a.Q) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qv[r] = a.Q[(size_t)rowv[r] * a.ldQ + col];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qv[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = acc[r] * act_d1<ACT>(sv[r]) + qv[r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
+  } else if (EPI == EPI_CHAIN) {
+    float sv[16], rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = a.R[(size_t)rowv[r] * a.ldR + col];
+    float y2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // softplus: s = 1 - exp(-a) and 1 - s = exp(-a) are both formed without cancellation
+      const float em = (ACT == ACT_SOFTPLUS) ? __expf(-sv[r]) : 0.f;
+      y[r] = acc[r] * act_d1<ACT>(sv[r]);
+      y2[r] = acc[r] * rv[r] * em;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) {
+        a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
+        a.Y2[(size_t)rowv[r] * a.ldY2 + col] = y2[r];
+      }
+  } else {  // EPI_DAE_LOSS
+    float sg[16], ev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sg[r] = a.sigma[rowv[r]];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ev[r] = a.eps[(size_t)rowv[r] * a.ldeps + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      y[r] = acc[r] + bcol;
+      const float rho = sg[r] * y[r] + ev[r];
+      if (ok[r]) {
+        if (a.Y) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
+        if (a.Y2) a.Y2[(size_t)rowv[r] * a.ldY2 + col] = 2.f * sg[r] * rho * a.scale;
+        loss_part += rho * rho;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) csum += ok[r] ? y[r] : 0.f;
+}
+
+template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB>
+__global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
   constexpr int BM = G::BM, LDW = G::LDW;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -41,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinArgs a) {
   const int nblk_total = (a.Nout + 31) >> 5;
   const int nb0 = blockIdx.y * (G::BN / 32) + wn * TN;
   const bool wave_active = nb0 < nblk_total;
+  const bool rows_full = row0 + BM <= a.M;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -62,25 +168,50 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinArgs a) {
       const int c4n = kw8 >> 2;
       __syncthreads();
       // ---- stage X[row0:row0+BM, k0:k0+kw8] into LDS (zero fill outside M x K) ----
-      for (int idx = tid; idx < BM * c4n; idx += 256) {
-        const int r = idx / c4n;
-        const int c = (idx - r * c4n) << 2;
-        const int grow = row0 + r, gcol = k0 + c;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (grow < a.M) {
-          const float* p = x + (size_t)grow * ld + gcol;
-          if (vec && gcol + 4 <= K) {
-            v = *reinterpret_cast<const f32x4*>(p);
-          } else {
+      if (vec && rows_full && kw8 == kw && (c4n & (c4n - 1)) == 0) {
+        // fast path: whole float4s, power-of-two row length -> shift/mask indexing, loads batched 4 deep
+        const int sh = 31 - __clz(c4n);
+        const int rpp = 256 >> sh;                     // rows covered per pass
+        const int passes = BM / rpp;                   // BM and rpp are powers of two, rpp <= BM since c4n >= 2... (K >= 8)
+        const int r0 = tid >> sh, c = (tid & (c4n - 1)) << 2;
+        const float* p = x + (size_t)(row0 + r0) * ld + k0 + c;
+        float* q = &lds[r0 * LDW + c];
+        const size_t gstep = (size_t)rpp * ld;
+        const int lstep = rpp * LDW;
+        if (rpp <= BM) {
+          for (int p0 = 0; p0 < passes; p0 += 4) {
+            f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (gcol + j < K) v[j] = p[j];
+            for (int u = 0; u < 4; ++u)
+              if (p0 + u < passes) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(p0 + u) * gstep);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (p0 + u < passes) *reinterpret_cast<f32x4*>(q + (p0 + u) * lstep) = v[u];
           }
+        } else if (r0 < BM) {
+          *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(p);
         }
-        *reinterpret_cast<f32x4*>(&lds[r * LDW + c]) = v;
+      } else {
+        for (int idx = tid; idx < BM * c4n; idx += 256) {
+          const int r = idx / c4n;
+          const int c = (idx - r * c4n) << 2;
+          const int grow = row0 + r, gcol = k0 + c;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (grow < a.M) {
+            const float* p = x + (size_t)grow * ld + gcol;
+            if (vec && gcol + 4 <= K) {
+              v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (gcol + j < K) v[j] = p[j];
+            }
+          }
+          *reinterpret_cast<f32x4*>(&lds[r * LDW + c]) = v;
+        }
       }
       __syncthreads();
-      // ---- MFMA over this panel ----
+      // ---- MFMA over this panel: weight fragments prefetched two chunks ahead straight from L2 ----
       if (wave_active) {
         const int nch = kw8 >> 3, kc0 = k0 >> 3;
         const float* arow[TM];
@@ -92,11 +223,17 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinArgs a) {
           const int nb = min(nb0 + j, nblk_total - 1);   // clamp: out-of-range blocks are masked at the store
           bptr[j] = wp + ((size_t)nb * kchunks + kc0) * 256 + lane * 4;
         }
-#pragma unroll 4
-        for (int kc = 0; kc < nch; ++kc) {
-          f32x4 av[TM], bv[TN];
+        f32x4 b0[TN], b1[TN];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)kc * 256);
+        for (int j = 0; j < TN; ++j) {
+          b0[j] = *reinterpret_cast<const f32x4*>(bptr[j]);
+          b1[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)min(1, nch - 1) * 256);
+        }
+        for (int kc = 0; kc < nch; ++kc) {
+          f32x4 av[TM], bn[TN];
+          const int kn = min(kc + 2, nch - 1);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bn[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)kn * 256);
 #pragma unroll
           for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc * 8);
 #pragma unroll
@@ -105,7 +242,12 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinArgs a) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], b0[j][q], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            b0[j] = b1[j];
+            b1[j] = bn[j];
+          }
         }
       }
     }
@@ -114,59 +256,24 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(const LinArgs a) {
   // ------------------------------------------------------------------ epilogue
   float loss_part = 0.f;
   if (wave_active) {
+    const bool full = rows_full && (nb0 + TN) * 32 <= a.Nout;   // wave-uniform: no masks, no clamps
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = (nb0 + j) * 32 + l31;
-      const bool cok = (nb0 + j) < nblk_total && col < a.Nout;
+      const int col_raw = (nb0 + j) * 32 + l31;
+      const bool cok = col_raw < a.Nout;
+      const int col = min(col_raw, a.Nout - 1);
+      const float bcol = ((EPI == EPI_ACT || EPI == EPI_DAE_LOSS) && a.bias) ? a.bias[col] : 0.f;
+      const float wsig = (EPI == EPI_ACT && a.rowscale_w) ? a.rowscale_w[col] : 0.f;
       float csum = 0.f;
-      float bcol = 0.f, wsig = 0.f;
-      if (EPI == EPI_ACT || EPI == EPI_DAE_LOSS) {
-        if (cok && a.bias) bcol = a.bias[col];
-        if (cok && a.rowscale_w) wsig = a.rowscale_w[col];
-      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (!(cok && row < a.M)) continue;
-          float v = acc[i][j][r];
-          float y;
-          if (EPI == EPI_ACT) {
-            v += bcol;
-            if (a.rowbias) v += a.rowbias[(size_t)(row / a.rows_per_group) * a.rowbias_ld + col];
-            if (a.rowscale) v += a.rowscale[row] * wsig;
-            y = act_fwd<ACT>(v);
-            a.Y[(size_t)row * a.ldY + col] = y;
-            // optional seed of the score pass: e_L = -w (.) act'(pre)   (R is the [Nout] vector w here)
-            if (a.Y2) a.Y2[(size_t)row * a.ldY2 + col] = -a.R[col] * act_d1<ACT>(y);
-          } else if (EPI == EPI_DACT) {
-            const float sd = act_d1<ACT>(a.S[(size_t)row * a.ldS + col]);
-            y = v * sd;
-            if (a.Q) y += a.Q[(size_t)row * a.ldQ + col];
-            a.Y[(size_t)row * a.ldY + col] = y;
-          } else if (EPI == EPI_CHAIN) {
-            const float sd = act_d1<ACT>(a.S[(size_t)row * a.ldS + col]);
-            y = v * sd;
-            a.Y[(size_t)row * a.ldY + col] = y;
-            float pb = 0.f;
-            if (ACT == ACT_SOFTPLUS) pb = v * a.R[(size_t)row * a.ldR + col] * (1.f - sd);
-            a.Y2[(size_t)row * a.ldY2 + col] = pb;
-          } else {  // EPI_DAE_LOSS
-            const float g = v + bcol;
-            const float sg = a.sigma[row];
-            const float rho = sg * g + a.eps[(size_t)row * a.ldeps + col];
-            if (a.Y) a.Y[(size_t)row * a.ldY + col] = g;
-            if (a.Y2) a.Y2[(size_t)row * a.ldY2 + col] = 2.f * sg * rho * a.scale;
-            loss_part += rho * rho;
-            y = g;
-          }
-          csum += y;
-        }
+        const int rbase = row0 + (wm * TM + i) * 32 + 4 * hh;
+        if (full) epilogue_block<EPI, ACT, true>(a, acc[i][j], rbase, col, true, bcol, wsig, csum, loss_part);
+        else epilogue_block<EPI, ACT, false>(a, acc[i][j], rbase, col, cok, bcol, wsig, csum, loss_part);
       }
       if (a.colsum != nullptr && WM == 1) {
-        csum += __shfl_xor(csum, 32);
-        if (hh == 0 && cok) a.colsum[(size_t)blockIdx.x * a.Nout + col] = csum;
+        const float c2 = csum + __shfl_xor(csum, 32);
+        if (hh == 0 && cok) a.colsum[(size_t)blockIdx.x * a.Nout + col] = c2;
       }
     }
   }
@@ -201,11 +308,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int ldw, int nou
   reinterpret_cast<f32x4*>(out)[t] = v;
 }
 
-template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT>
+template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB>
 int launch_geo(const LinArgs& a, hipStream_t st) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
   dim3 grid(ceil_div(a.M, G::BM), ceil_div(a.Nout, G::BN));
-  hipLaunchKernelGGL((linear_kernel<TM, TN, WM, WN, KPANEL, EPI, ACT>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((linear_kernel<TM, TN, WM, WN, KPANEL, EPI, ACT, MINB>), grid, dim3(256), 0, st, a);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
@@ -214,9 +321,9 @@ template <int EPI, int ACT>
 int launch_epi(const LinArgs& a, hipStream_t st) {
   if (a.Nout <= 32) {
     ARDAE_CHECK_ARG(a.colsum == nullptr, "linear: colsum is not available in the narrow (Nout<=32) geometry");
-    return launch_geo<1, 1, 4, 1, 128, EPI, ACT>(a, st);
+    return launch_geo<1, 1, 4, 1, 128, EPI, ACT, 2>(a, st);
   }
-  return launch_geo<2, 2, 1, 4, 256, EPI, ACT>(a, st);
+  return launch_geo<2, 2, 1, 4, WIDE_KPANEL, EPI, ACT, WIDE_MINB>(a, st);
 }
 
 }  // namespace
