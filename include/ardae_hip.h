@@ -149,6 +149,40 @@ int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float*
                      const float* sigma, const float* ctx, int B, int S, float* workspace, size_t workspace_floats,
                      float* score_out, void* stream);
 
+
+/* ---- K2/K8: implicit-posterior VAE (models/ivae/mnist.py, models/ivae/toy.py enc_type='concat') ---------------
+ * Parameters: ONE flat fp32 buffer in the reference's named_parameters() order
+ *   kind 0 (MNISTIPVAE): encode.inp_encode.{layers.0..n_layers, fc}, encode.fc.{layers.0, fc}, decode.main.{layers.*, fc},
+ *                        decode.reparam.logit_fn;   Bernoulli decoder, x rescaled to 2x-1 inside the encoder
+ *   kind 1 (ToyIPVAE)  : encode.inp_encode.{layers.0..n_layers-2, fc}, encode.fc.{layers.0..n_layers-1, fc} (ContextConcatMLP:
+ *                        every layer eats [hidden, noise]), decode.main.*, decode.reparam.{mean_fn, logvar_fn}; Gaussian decoder */
+typedef struct ardae_model_desc {
+  int kind;
+  int input_dim, noise_dim, h_dim, z_dim;
+  int n_layers; /* --model-n-layers */
+  int act;      /* ARDAE_ACT_SOFTPLUS | ARDAE_ACT_RELU */
+} ardae_model_desc;
+size_t ardae_model_param_floats(const ardae_model_desc* d);
+size_t ardae_model_packed_floats(const ardae_model_desc* d);
+/* mode 0: encode only; mode 1: vae_forward + vae_backward */
+size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode);
+int ardae_model_pack(const ardae_model_desc* d, const float* params, float* packed, void* stream);
+/* Encoder.forward (ivae/mnist.py:102-121): z[B*nz, z] = f(x[B, input_dim], noise[B*nz, noise_dim]); noise NULL = zeros,
+ * i.e. encode(x, std=0) */
+int ardae_model_encode(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                       const float* noise, int B, int nz, float* workspace, size_t workspace_floats, float* z_out,
+                       void* stream);
+/* ImplicitPosteriorVAE.forward (ivae/mnist.py:267-301): z_out [B*nz, z]; losses[3] = {loss, recon.mean, prior.mean}
+ * (device); activations stay in `workspace` for the backward call */
+int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                            const float* noise, int B, int nz, float beta, float* workspace, size_t workspace_floats,
+                            float* z_out, float* losses, void* stream);
+/* grads = grads_beta*grads + d/dparams [ dloss*loss + <dz_extra, z> ]   (model_loss.backward() and
+ * latent.backward(seed), ivae_ardae.py:804,834).  Needs the workspace of the matching vae_forward call. */
+int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                             const float* noise, int B, int nz, float beta, float dloss, const float* dz_extra,
+                             float* workspace, size_t workspace_floats, float* grads, float grads_beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,11 @@ class CdaeDesc(ctypes.Structure):
                 ("h_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
 
 
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("input_dim", ctypes.c_int), ("noise_dim", ctypes.c_int), ("h_dim", ctypes.c_int),
+                ("z_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
+
+
 ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2}
 EPI_ACT, EPI_DACT, EPI_CHAIN, EPI_DAE_LOSS = 0, 1, 2, 3
 
@@ -89,6 +94,18 @@ EXPORTS = {
     "ardae_cdae_pack": (ctypes.c_int, [ctypes.POINTER(CdaeDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_cdae_loss_grads": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 4),
+    "ardae_model_param_floats": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc)]),
+    "ardae_model_packed_floats": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc)]),
+    "ardae_model_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(ModelDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ardae_model_pack": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "ardae_model_encode": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "ardae_model_vae_forward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "ardae_model_vae_backward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                 ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
     "ardae_cdae_score": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 2),
 }

@@ -32,4 +32,17 @@ int launch_adam_ref(float* p, const float* g, float* m, float* v, float* vmax, i
 int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, double lr, double alpha, double eps,
                    double momentum, hipStream_t st);
 
+// y = alpha*x + beta (the encoder's 2x-1 rescale, ivae/mnist.py:81)
+int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t st);
+// Row losses of ImplicitPosteriorVAE.loss (ivae/mnist.py:240-249, toy.py:777-786) and, when write_grads, their gradients:
+//   kind 0: rec = sum_d BCE_with_logits(o0, x)      (utils/vae.py:21-30);  do0 = gscale*(sigmoid(o0) - x)
+//   kind 1: rec = .5 sum_d (o1 + (x-o0)^2/exp(o1) + log 2pi) (utils/vae.py:36-52); do0 = -gscale (x-o0)/exp(o1), do1 = .5 gscale (1-(x-o0)^2/exp(o1))
+//   pri = .5 sum_d (z^2 + log 2pi) (utils/energy.py:69-77);  dzq = gscale*beta*z + dz_extra
+// x is [rows/nz, D] (row r belongs to image r/nz).
+int launch_vae_loss(int kind, const float* o0, const float* o1, const float* x, const float* z, int rows, int nz, int D, int zd,
+                    float beta, int write_grads, float gscale, const float* dz_extra, float* rec_row, float* pri_row, float* do0,
+                    float* do1, float* dzq, hipStream_t st);
+// losses[0] = mean(rec + beta*pri), losses[1] = mean(rec), losses[2] = mean(pri)
+int launch_vae_loss_finalize(const float* rec_row, const float* pri_row, int rows, float beta, float* losses, hipStream_t st);
+
 }  // namespace ardae

@@ -219,6 +219,84 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
   }
 }
 
+__global__ void affine_kernel(const float* __restrict__ x, int64_t n, float alpha, float beta, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = alpha * x[i] + beta;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one workgroup per row
+template <int KIND>
+__global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ o0, const float* __restrict__ o1,
+                                                       const float* __restrict__ x, const float* __restrict__ z, int nz, int D, int zd,
+                                                       float beta, int write_grads, float gscale, const float* __restrict__ dz_extra,
+                                                       float* __restrict__ rec_row, float* __restrict__ pri_row, float* __restrict__ do0,
+                                                       float* __restrict__ do1, float* __restrict__ dzq) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* xr = x + (size_t)(r / nz) * D;
+  const size_t base = (size_t)r * D;
+  const float LOG2PI = 1.8378770664093453f;
+  float acc = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float t = xr[d];
+    if (KIND == 0) {
+      const float l = o0[base + d];
+      const float e = __expf(-fabsf(l));
+      acc += fmaxf(l, 0.f) - l * t + (e < 1e-4f ? e * (1.f - 0.5f * e) : __logf(1.f + e));
+      if (write_grads) {
+        const float sg = l >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        do0[base + d] = gscale * (sg - t);
+      }
+    } else {
+      const float mu = o0[base + d], lv = o1[base + d];
+      const float iv = __expf(-lv), df = t - mu;
+      acc += 0.5f * (lv + df * df * iv + LOG2PI);
+      if (write_grads) {
+        do0[base + d] = -gscale * df * iv;
+        do1[base + d] = 0.5f * gscale * (1.f - df * df * iv);
+      }
+    }
+  }
+  const float rec = block_sum_256(acc, red);
+  float pa = 0.f;
+  for (int d = threadIdx.x; d < zd; d += 256) {
+    const float zv = z[(size_t)r * zd + d];
+    pa += 0.5f * (zv * zv + LOG2PI);
+    if (write_grads) dzq[(size_t)r * zd + d] = gscale * beta * zv + (dz_extra ? dz_extra[(size_t)r * zd + d] : 0.f);
+  }
+  const float pri = block_sum_256(pa, red);
+  if (threadIdx.x == 0) {
+    rec_row[r] = rec;
+    pri_row[r] = pri;
+  }
+}
+
+__global__ __launch_bounds__(256) void vae_loss_finalize_kernel(const float* __restrict__ rec_row, const float* __restrict__ pri_row,
+                                                                int rows, float beta, float* __restrict__ losses) {
+  __shared__ float red[4];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 256) {
+    a += rec_row[i];
+    b += pri_row[i];
+  }
+  const float ra = block_sum_256(a, red);
+  const float rb = block_sum_256(b, red);
+  if (threadIdx.x == 0) {
+    const float inv = 1.f / (float)rows;
+    losses[0] = (ra + beta * rb) * inv;
+    losses[1] = ra * inv;
+    losses[2] = rb * inv;
+  }
+}
+
 inline int grid_for(int64_t n, int cap = 4096) {
   int64_t g = (n + 255) / 256;
   if (g < 1) g = 1;
@@ -308,6 +386,36 @@ int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, d
   ARDAE_CHECK_ARG(p && g && sq && n > 0 && (momentum <= 0.0 || buf), "rmsprop: bad arguments");
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, sq, buf, n, (float)lr, (float)alpha, (float)eps,
                      (float)momentum);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t st) {
+  ARDAE_CHECK_ARG(x && y && n > 0, "affine: bad arguments");
+  hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, alpha, beta, y);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vae_loss(int kind, const float* o0, const float* o1, const float* x, const float* z, int rows, int nz, int D, int zd,
+                    float beta, int write_grads, float gscale, const float* dz_extra, float* rec_row, float* pri_row, float* do0,
+                    float* do1, float* dzq, hipStream_t st) {
+  ARDAE_CHECK_ARG(o0 && x && z && rec_row && pri_row && rows > 0 && nz > 0 && D > 0 && zd > 0, "vae_loss: bad arguments");
+  ARDAE_CHECK_ARG(kind == 0 || (kind == 1 && o1), "vae_loss: kind 1 needs the logvar head");
+  ARDAE_CHECK_ARG(!write_grads || (do0 && dzq && (kind == 0 || do1)), "vae_loss: gradient outputs missing");
+  if (kind == 0)
+    hipLaunchKernelGGL(vae_loss_kernel<0>, dim3(rows), dim3(256), 0, st, o0, o1, x, z, nz, D, zd, beta, write_grads, gscale, dz_extra,
+                       rec_row, pri_row, do0, do1, dzq);
+  else
+    hipLaunchKernelGGL(vae_loss_kernel<1>, dim3(rows), dim3(256), 0, st, o0, o1, x, z, nz, D, zd, beta, write_grads, gscale, dz_extra,
+                       rec_row, pri_row, do0, do1, dzq);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vae_loss_finalize(const float* rec_row, const float* pri_row, int rows, float beta, float* losses, hipStream_t st) {
+  ARDAE_CHECK_ARG(rec_row && pri_row && losses && rows > 0, "vae_loss_finalize: bad arguments");
+  hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_row, pri_row, rows, beta, losses);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,391 @@
+// Implicit-posterior VAE (sampler + decoder + ELBO pieces) on gfx950, orchestrated from the K1 / K6w kernels.
+//
+// Reference: models/ivae/mnist.py (kind 0) and models/ivae/toy.py with enc_type='concat' (kind 1).  Both are
+// described by one structure:
+//   inp  MLP : n_inp Linear->act on B rows                     (mnist: input is 2x-1, n_inp = n_layers+2; toy: n_layers)
+//   stack    : n_stack Linear over [hidden | noise] on R = B*nz rows, act on all but the last; the FIRST one's hidden
+//              part is the per-image `inp` (computed once per image and added as a row bias - the reference expands it to
+//              R rows, ivae/mnist.py:115-116), the noise part is missing where the reference does not concatenate
+//              (mnist: stack = [h <- h|noise, z <- h];  toy: every layer h|noise, models/layers.py:717-722)
+//   decoder  : n_dec Linear->act from z, then 1 (logits) or 2 (mean, logvar) linear heads
+#include <vector>
+
+#include "ardae_hip.h"
+#include "common.h"
+#include "elementwise.h"
+#include "linear.h"
+#include "wgrad.h"
+
+namespace ardae {
+namespace {
+
+struct Lin {
+  size_t w, b;
+  int out, in;
+};
+
+struct ModelLayout {
+  int kind, D, nd, h, zd, nl, act;
+  std::vector<Lin> inp, stack, dec, heads;
+  std::vector<bool> stack_noise;   // does stack[i] take the noise concat?
+  size_t total = 0;
+  explicit ModelLayout(const ardae_model_desc& d)
+      : kind(d.kind), D(d.input_dim), nd(d.noise_dim), h(d.h_dim), zd(d.z_dim), nl(d.n_layers), act(d.act) {
+    size_t off = 0;
+    auto add = [&](std::vector<Lin>& v, int out, int in) {
+      Lin l; l.out = out; l.in = in; l.w = off; off += (size_t)out * in; l.b = off; off += out;
+      v.push_back(l);
+    };
+    const int n_inp = kind == 0 ? nl + 2 : nl;
+    for (int l = 0; l < n_inp; ++l) add(inp, h, l == 0 ? D : h);
+    if (kind == 0) {
+      add(stack, h, h + nd); stack_noise.push_back(true);
+      add(stack, zd, h); stack_noise.push_back(false);
+    } else {
+      for (int l = 0; l < nl; ++l) { add(stack, h, h + nd); stack_noise.push_back(true); }
+      add(stack, zd, h + nd); stack_noise.push_back(true);
+    }
+    const int n_dec = kind == 0 ? nl + 1 : nl;
+    for (int l = 0; l < n_dec; ++l) add(dec, h, l == 0 ? zd : h);
+    add(heads, D, h);
+    if (kind == 1) add(heads, D, h);
+    total = off;
+  }
+};
+
+struct ModelPacked {
+  std::vector<size_t> inp_f, inp_b, sh_f, sh_b, sn_f, dec_f, dec_b, head_f, head_b;
+  size_t total = 0;
+  explicit ModelPacked(const ModelLayout& P) {
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
+    for (auto& l : P.inp) { inp_f.push_back(take(packed_floats(l.out, l.in))); inp_b.push_back(take(packed_floats(l.in, l.out))); }
+    for (size_t i = 0; i < P.stack.size(); ++i) {
+      sh_f.push_back(take(packed_floats(P.stack[i].out, P.h)));
+      sh_b.push_back(take(packed_floats(P.h, P.stack[i].out)));
+      sn_f.push_back(P.stack_noise[i] ? take(packed_floats(P.stack[i].out, P.nd)) : 0);
+    }
+    for (auto& l : P.dec) { dec_f.push_back(take(packed_floats(l.out, l.in))); dec_b.push_back(take(packed_floats(l.in, l.out))); }
+    for (auto& l : P.heads) { head_f.push_back(take(packed_floats(l.out, l.in))); head_b.push_back(take(packed_floats(l.in, l.out))); }
+    total = off;
+  }
+};
+
+struct Bump {
+  float* base; size_t cap; size_t off = 0; bool ok = true;
+  Bump(float* b, size_t c) : base(b), cap(c) {}
+  float* take(size_t n) {
+    size_t o = off; off += (n + 63) & ~size_t(63);
+    if (off > cap) { ok = false; return base; }
+    return base + o;
+  }
+};
+
+int desc_ok(const ardae_model_desc* d) {
+  ARDAE_CHECK_ARG(d != nullptr, "model: desc is NULL");
+  ARDAE_CHECK_ARG(d->kind == 0 || d->kind == 1, "model: kind must be 0 (MNISTIPVAE) or 1 (ToyIPVAE concat)");
+  ARDAE_CHECK_ARG(d->input_dim >= 1 && d->noise_dim >= 1 && d->h_dim >= 1 && d->z_dim >= 1 && d->n_layers >= 1 && d->n_layers <= 4,
+                  "model: bad dimensions");
+  ARDAE_CHECK_ARG(d->act == ACT_SOFTPLUS || d->act == ACT_RELU, "model: activation must be softplus or relu");
+  return 0;
+}
+
+// saved activations (in `workspace`, same carving in forward and backward)
+struct ModelWs {
+  float* x2;
+  std::vector<float*> e;    // e[l], l = 1..n_inp        [B,h]
+  float* rb;                // per-image part of the first stack layer (+ its bias) [B,h]
+  std::vector<float*> t;    // t[i], i = 1..n_stack-1    [R,h]
+  float* z;                 // sampler output            [R,zd]
+  std::vector<float*> dcd;  // dcd[l], l = 1..n_dec      [R,h]
+  std::vector<float*> o;    // heads                     [R,D]
+  float *rec_row, *pri_row;
+  // backward only
+  std::vector<float*> dox, ddec, dt, de;
+  float *dzq, *dz, *drb;
+};
+
+size_t al64(size_t n) { return (n + 63) & ~size_t(63); }
+
+size_t wgrad_scratch(const ModelLayout& P, int B, int R, std::vector<int>* splits_out) {
+  std::vector<int> sp;
+  size_t tot = 0;
+  const int nprob = (int)(P.heads.size() + P.dec.size() + 2 * P.stack.size() + P.inp.size());
+  auto one = [&](int M, int O, int I) {
+    const int s = wgrad_splits(M, O, I, nprob);
+    sp.push_back(s);
+    tot += al64((size_t)s * O * I) + al64((size_t)s * 2 * O);
+  };
+  for (auto& l : P.heads) one(R, l.out, l.in);
+  for (auto& l : P.dec) one(R, l.out, l.in);
+  for (size_t i = 0; i < P.stack.size(); ++i) {
+    one(i == 0 ? B : R, P.stack[i].out, P.h);              // hidden part
+    if (P.stack_noise[i]) one(R, P.stack[i].out, P.nd);    // noise part
+  }
+  for (auto& l : P.inp) one(B, l.out, l.in);
+  if (splits_out) *splits_out = sp;
+  return tot;
+}
+
+size_t workspace_floats(const ModelLayout& P, int B, int nz, int mode) {
+  const size_t R = (size_t)B * nz, h = P.h;
+  size_t t = al64((size_t)B * P.D) + P.inp.size() * al64((size_t)B * h) + al64((size_t)B * h);
+  t += (P.stack.size() - 1) * al64(R * h) + al64(R * P.zd);
+  if (mode == 0) return t;
+  t += P.dec.size() * al64(R * h) + P.heads.size() * al64(R * P.D) + 2 * al64(R);
+  t += P.heads.size() * al64(R * P.D) + P.dec.size() * al64(R * h) + (P.stack.size() - 1) * al64(R * h) + P.inp.size() * al64((size_t)B * h);
+  t += 2 * al64(R * P.zd) + al64((size_t)B * h);
+  t += wgrad_scratch(P, B, (int)R, nullptr);
+  return t;
+}
+
+void carve(const ModelLayout& P, Bump& ws, int B, int nz, int mode, ModelWs& W) {
+  const size_t R = (size_t)B * nz, h = P.h;
+  W.x2 = ws.take((size_t)B * P.D);
+  W.e.assign(P.inp.size() + 1, nullptr);
+  for (size_t l = 1; l <= P.inp.size(); ++l) W.e[l] = ws.take((size_t)B * h);
+  W.rb = ws.take((size_t)B * h);
+  W.t.assign(P.stack.size(), nullptr);
+  for (size_t i = 1; i < P.stack.size(); ++i) W.t[i] = ws.take(R * h);
+  W.z = ws.take(R * P.zd);
+  if (mode == 0) return;
+  W.dcd.assign(P.dec.size() + 1, nullptr);
+  for (size_t l = 1; l <= P.dec.size(); ++l) W.dcd[l] = ws.take(R * h);
+  for (size_t k = 0; k < P.heads.size(); ++k) W.o.push_back(ws.take(R * P.D));
+  W.rec_row = ws.take(R); W.pri_row = ws.take(R);
+  for (size_t k = 0; k < P.heads.size(); ++k) W.dox.push_back(ws.take(R * P.D));
+  W.ddec.assign(P.dec.size() + 1, nullptr);
+  for (size_t l = 1; l <= P.dec.size(); ++l) W.ddec[l] = ws.take(R * h);
+  W.dt.assign(P.stack.size(), nullptr);
+  for (size_t i = 1; i < P.stack.size(); ++i) W.dt[i] = ws.take(R * h);
+  W.de.assign(P.inp.size() + 1, nullptr);
+  for (size_t l = 1; l <= P.inp.size(); ++l) W.de[l] = ws.take((size_t)B * h);
+  W.dzq = ws.take(R * P.zd); W.dz = ws.take(R * P.zd); W.drb = ws.take((size_t)B * h);
+}
+
+int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
+  a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
+  a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;
+  return launch_linear(a, epi, st);
+}
+
+// sampler forward: fills W.e, W.rb, W.t, W.z (and copies z to z_out when given)
+int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* x,
+               const float* noise, int B, int nz, ModelWs& W, float* z_out, hipStream_t st) {
+  const int R = B * nz, h = P.h, act = P.act;
+  const float* x_in = x;
+  if (P.kind == 0) {
+    ARDAE_TRY(launch_affine(x, (int64_t)B * P.D, 2.f, -1.f, W.x2, st));
+    x_in = W.x2;
+  }
+  for (size_t l = 1; l <= P.inp.size(); ++l) {
+    LinArgs A{}; A.bias = params + P.inp[l - 1].b; A.Y = W.e[l]; A.ldY = h;
+    ARDAE_TRY(lin1(EPI_ACT, act, B, h, l == 1 ? x_in : W.e[l - 1], l == 1 ? P.D : h, P.inp[l - 1].in, packed + K.inp_f[l - 1], A, st));
+  }
+  {  // rb = inp . S_1[:, :h]^T + b_S1   (once per image)
+    LinArgs A{}; A.bias = params + P.stack[0].b; A.Y = W.rb; A.ldY = h;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.stack[0].out, W.e[P.inp.size()], h, h, packed + K.sh_f[0], A, st));
+  }
+  const size_t ns = P.stack.size();
+  for (size_t i = 0; i < ns; ++i) {
+    const bool last = i + 1 == ns;
+    const int out = P.stack[i].out;
+    LinArgs A{}; A.Y = last ? W.z : W.t[i + 1]; A.ldY = out; A.M = R; A.Nout = out; A.act = last ? ACT_NONE : act;
+    int n = 0;
+    if (i == 0) {
+      A.rowbias = W.rb; A.rowbias_ld = h; A.rows_per_group = nz;
+    } else {
+      A.bias = params + P.stack[i].b;
+      A.src[n].x = W.t[i]; A.src[n].ld = h; A.src[n].K = h; A.src[n].wp = packed + K.sh_f[i]; ++n;
+    }
+    if (P.stack_noise[i]) {
+      A.src[n].x = noise; A.src[n].ld = P.nd; A.src[n].K = P.nd; A.src[n].wp = packed + K.sn_f[i]; ++n;
+    }
+    A.nsrc = n;
+    ARDAE_TRY(launch_linear(A, EPI_ACT, st));
+  }
+  if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+}  // namespace
+}  // namespace ardae
+
+using namespace ardae;
+
+extern "C" {
+
+size_t ardae_model_param_floats(const ardae_model_desc* d) { return desc_ok(d) ? 0 : ModelLayout(*d).total; }
+size_t ardae_model_packed_floats(const ardae_model_desc* d) { return desc_ok(d) ? 0 : ModelPacked(ModelLayout(*d)).total; }
+size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
+  if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
+  const ModelLayout P(*d);
+  return workspace_floats(P, B, nz, mode) + (size_t)al64((size_t)B * nz * P.nd);   // + a zero-noise buffer for encode(std=0)
+}
+
+int ardae_model_pack(const ardae_model_desc* d, const float* params, float* packed, void* stream) {
+  ARDAE_TRY(desc_ok(d));
+  ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const ModelLayout P(*d);
+  const ModelPacked K(P);
+  for (size_t l = 0; l < P.inp.size(); ++l) {
+    ARDAE_TRY(launch_pack_weight(params + P.inp[l].w, P.inp[l].in, P.inp[l].out, P.inp[l].in, false, packed + K.inp_f[l], st));
+    ARDAE_TRY(launch_pack_weight(params + P.inp[l].w, P.inp[l].in, P.inp[l].in, P.inp[l].out, true, packed + K.inp_b[l], st));
+  }
+  for (size_t i = 0; i < P.stack.size(); ++i) {
+    const Lin& l = P.stack[i];
+    ARDAE_TRY(launch_pack_weight(params + l.w, l.in, l.out, P.h, false, packed + K.sh_f[i], st));
+    ARDAE_TRY(launch_pack_weight(params + l.w, l.in, P.h, l.out, true, packed + K.sh_b[i], st));
+    if (P.stack_noise[i]) ARDAE_TRY(launch_pack_weight(params + l.w + P.h, l.in, l.out, P.nd, false, packed + K.sn_f[i], st));
+  }
+  for (size_t l = 0; l < P.dec.size(); ++l) {
+    ARDAE_TRY(launch_pack_weight(params + P.dec[l].w, P.dec[l].in, P.dec[l].out, P.dec[l].in, false, packed + K.dec_f[l], st));
+    ARDAE_TRY(launch_pack_weight(params + P.dec[l].w, P.dec[l].in, P.dec[l].in, P.dec[l].out, true, packed + K.dec_b[l], st));
+  }
+  for (size_t k = 0; k < P.heads.size(); ++k) {
+    ARDAE_TRY(launch_pack_weight(params + P.heads[k].w, P.heads[k].in, P.heads[k].out, P.heads[k].in, false, packed + K.head_f[k], st));
+    ARDAE_TRY(launch_pack_weight(params + P.heads[k].w, P.heads[k].in, P.heads[k].in, P.heads[k].out, true, packed + K.head_b[k], st));
+  }
+  return 0;
+}
+
+static int model_common(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B, int nz,
+                        float* workspace, size_t wsf, int mode) {
+  ARDAE_TRY(desc_ok(d));
+  ARDAE_CHECK_ARG(params && packed && x && workspace, "model: null pointer argument");
+  ARDAE_CHECK_ARG(B > 0 && nz > 0 && (int64_t)B * nz < (int64_t)1 << 30, "model: bad batch (B=%d nz=%d)", B, nz);
+  const size_t need = ardae_model_workspace_floats(d, B, nz, mode);
+  ARDAE_CHECK_ARG(wsf >= need, "model: workspace too small (%zu < %zu floats)", wsf, need);
+  return 0;
+}
+
+int ardae_model_encode(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
+                       int B, int nz, float* workspace, size_t workspace_floats_, float* z_out, void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 0));
+  ARDAE_CHECK_ARG(z_out, "model_encode: z_out is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const ModelLayout P(*d);
+  const ModelPacked K(P);
+  Bump ws(workspace, workspace_floats_);
+  ModelWs W;
+  carve(P, ws, B, nz, 0, W);
+  const float* nz_ptr = noise;
+  if (!noise) {   // encode(x, std=0): the reference multiplies its draw by 0
+    float* zero = ws.take((size_t)B * nz * P.nd);
+    ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * nz * P.nd * sizeof(float), st));
+    nz_ptr = zero;
+  }
+  ARDAE_CHECK_ARG(ws.ok, "model_encode: internal workspace accounting error");
+  return encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, st);
+}
+
+int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
+                            int B, int nz, float beta, float* workspace, size_t workspace_floats_, float* z_out, float* losses,
+                            void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
+  ARDAE_CHECK_ARG(noise && z_out && losses, "model_vae_forward: null pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  const ModelLayout P(*d);
+  const ModelPacked K(P);
+  Bump ws(workspace, workspace_floats_);
+  ModelWs W;
+  carve(P, ws, B, nz, 1, W);
+  ARDAE_CHECK_ARG(ws.ok, "model_vae_forward: internal workspace accounting error");
+  const int R = B * nz, h = P.h, act = P.act;
+  ARDAE_TRY(encode_fwd(P, K, params, packed, x, noise, B, nz, W, z_out, st));
+  for (size_t l = 1; l <= P.dec.size(); ++l) {
+    LinArgs A{}; A.bias = params + P.dec[l - 1].b; A.Y = W.dcd[l]; A.ldY = h;
+    ARDAE_TRY(lin1(EPI_ACT, act, R, h, l == 1 ? W.z : W.dcd[l - 1], l == 1 ? P.zd : h, P.dec[l - 1].in, packed + K.dec_f[l - 1], A, st));
+  }
+  for (size_t k = 0; k < P.heads.size(); ++k) {
+    LinArgs A{}; A.bias = params + P.heads[k].b; A.Y = W.o[k]; A.ldY = P.D;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.D, W.dcd[P.dec.size()], h, h, packed + K.head_f[k], A, st));
+  }
+  ARDAE_TRY(launch_vae_loss(P.kind, W.o[0], P.kind == 1 ? W.o[1] : nullptr, x, W.z, R, nz, P.D, P.zd, beta, 0, 0.f, nullptr, W.rec_row,
+                            W.pri_row, nullptr, nullptr, nullptr, st));
+  return launch_vae_loss_finalize(W.rec_row, W.pri_row, R, beta, losses, st);
+}
+
+int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
+                             int B, int nz, float beta, float dloss, const float* dz_extra, float* workspace,
+                             size_t workspace_floats_, float* grads, float grads_beta, void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
+  ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  const ModelLayout P(*d);
+  const ModelPacked K(P);
+  Bump ws(workspace, workspace_floats_);
+  ModelWs W;
+  carve(P, ws, B, nz, 1, W);
+  const int R = B * nz, h = P.h, act = P.act;
+  const size_t ns = P.stack.size(), ndec = P.dec.size(), ninp = P.inp.size(), nh = P.heads.size();
+  const float gscale = dloss / (float)R;
+  ARDAE_TRY(launch_vae_loss(P.kind, W.o[0], P.kind == 1 ? W.o[1] : nullptr, x, W.z, R, nz, P.D, P.zd, beta, 1, gscale, dz_extra,
+                            W.rec_row, W.pri_row, W.dox[0], P.kind == 1 ? W.dox[1] : nullptr, W.dzq, st));
+  // decoder backward
+  {
+    LinArgs A{}; A.S = W.dcd[ndec]; A.ldS = h; A.Y = W.ddec[ndec]; A.ldY = h; A.M = R; A.Nout = h; A.act = act; A.nsrc = (int)nh;
+    for (size_t k = 0; k < nh; ++k) { A.src[k].x = W.dox[k]; A.src[k].ld = P.D; A.src[k].K = P.D; A.src[k].wp = packed + K.head_b[k]; }
+    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
+  }
+  for (size_t l = ndec; l >= 2; --l) {
+    LinArgs A{}; A.S = W.dcd[l - 1]; A.ldS = h; A.Y = W.ddec[l - 1]; A.ldY = h;
+    ARDAE_TRY(lin1(EPI_DACT, act, R, h, W.ddec[l], h, h, packed + K.dec_b[l - 1], A, st));
+  }
+  {  // dz = ddec_1 . D_1 + (prior + injected seed)      (act NONE: act' == 1, S is only a placeholder)
+    LinArgs A{}; A.S = W.dzq; A.ldS = P.zd; A.Q = W.dzq; A.ldQ = P.zd; A.Y = W.dz; A.ldY = P.zd;
+    ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, R, P.zd, W.ddec[1], h, h, packed + K.dec_b[0], A, st));
+  }
+  // sampler backward
+  for (size_t i = ns - 1; i >= 1; --i) {
+    LinArgs A{}; A.S = W.t[i]; A.ldS = h; A.Y = W.dt[i]; A.ldY = h;
+    const float* src = (i == ns - 1) ? W.dz : W.dt[i + 1];
+    const int kk = P.stack[i].out;
+    ARDAE_TRY(lin1(EPI_DACT, act, R, h, src, kk, kk, packed + K.sh_b[i], A, st));
+  }
+  ARDAE_TRY(launch_segment_sum(W.dt[1], h, B, nz, h, 1.0f, W.drb, h, st));
+  {
+    LinArgs A{}; A.S = W.e[ninp]; A.ldS = h; A.Y = W.de[ninp]; A.ldY = h;
+    ARDAE_TRY(lin1(EPI_DACT, act, B, h, W.drb, h, h, packed + K.sh_b[0], A, st));
+  }
+  for (size_t l = ninp; l >= 2; --l) {
+    LinArgs A{}; A.S = W.e[l - 1]; A.ldS = h; A.Y = W.de[l - 1]; A.ldY = h;
+    ARDAE_TRY(lin1(EPI_DACT, act, B, h, W.de[l], h, h, packed + K.inp_b[l - 1], A, st));
+  }
+  // weight gradients: one batched launch (problem order must match wgrad_scratch)
+  std::vector<int> splits;
+  wgrad_scratch(P, B, R, &splits);
+  std::vector<WgradProblem> probs;
+  auto push = [&](int M, int O, int I, const float* G, const float* X, int ldX, float* out, int ldout, float* out_bias) {
+    WgradProblem p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.O = O; p.I = I; p.npairs = 1;
+    p.G[0] = G; p.ldG[0] = O; p.X[0] = X; p.ldX[0] = ldX;
+    p.bias_pair = out_bias ? 0 : -1;
+    p.splits = splits[probs.size()];
+    p.partial = ws.take((size_t)p.splits * O * I);
+    p.partial_vec = ws.take((size_t)p.splits * 2 * O);
+    p.out = out; p.ldout = ldout; p.out_bias = out_bias; p.beta = grads_beta;
+    probs.push_back(p);
+  };
+  const float* x_in = P.kind == 0 ? W.x2 : x;
+  for (size_t k = 0; k < nh; ++k) push(R, P.D, h, W.dox[k], W.dcd[ndec], h, grads + P.heads[k].w, h, grads + P.heads[k].b);
+  for (size_t l = 1; l <= ndec; ++l)
+    push(R, h, P.dec[l - 1].in, W.ddec[l], l == 1 ? W.z : W.dcd[l - 1], l == 1 ? P.zd : h, grads + P.dec[l - 1].w, P.dec[l - 1].in,
+         grads + P.dec[l - 1].b);
+  for (size_t i = 0; i < ns; ++i) {
+    const Lin& L = P.stack[i];
+    const float* G = (i == ns - 1) ? W.dz : W.dt[i + 1];
+    if (i == 0) push(B, L.out, h, W.drb, W.e[ninp], h, grads + L.w, L.in, nullptr);        // per-image hidden part
+    else push(R, L.out, h, G, W.t[i], h, grads + L.w, L.in, P.stack_noise[i] ? nullptr : grads + L.b);
+    if (P.stack_noise[i]) push(R, L.out, P.nd, G, noise, P.nd, grads + L.w + h, L.in, grads + L.b);   // noise part (+ bias)
+  }
+  for (size_t l = 1; l <= ninp; ++l)
+    push(B, h, P.inp[l - 1].in, W.de[l], l == 1 ? x_in : W.e[l - 1], l == 1 ? P.D : h, grads + P.inp[l - 1].w, P.inp[l - 1].in,
+         grads + P.inp[l - 1].b);
+  ARDAE_CHECK_ARG(ws.ok, "model_vae_backward: internal workspace accounting error");
+  return launch_wgrad_batch(probs.data(), (int)probs.size(), st);
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+"""Fused train step: the loop body of the reference's `train()` (ivae_ardae.py:707-846) as a straight line of C-ABI calls.
+
+No autograd graph, no per-step allocation, no host synchronisation: every buffer is created once, noise comes from the
+engine's Philox stream (or is injected for parity tests), losses stay on the device until `.stats()` is called.
+Data parallel: the image batch is sharded over ranks, parameters are replicated, and the two flat gradient
+buffers are all-reduced (RCCL over xGMI via torch.distributed backend "nccl") before their optimiser steps.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+from . import rng
+
+
+@dataclass
+class TrainConfig:
+    """Loop constants (argparse defaults / run_vae_dbmnist.sh:36-37, run_vae_25gaussians.sh:3-12)."""
+    delta: float = 0.1            # --delta
+    std_scale: float = 1e4        # --std-scale
+    nz_cdae: int = 256            # --train-nz-cdae
+    nz_model: int = 1             # --train-nz-model
+    num_cdae_updates: int = 1     # --num-cdae-updates
+    beta: float = 1.0             # --beta-fin (no annealing in the shipped recipes)
+    m_lr: float = 1e-4            # --m-lr, Adam betas (m_beta1, 0.999)
+    m_beta1: float = 0.5
+    d_lr: float = 1e-4            # --d-lr, RMSprop momentum d_momentum
+    d_momentum: float = 0.5
+
+
+def annealing_func(val_init, val_fin, val_annealing, step):
+    """utils/msc.py:53-55."""
+    if val_annealing is None:
+        return float(val_fin)
+    return float(val_init + (val_fin - val_init) / float(val_annealing) * float(min(val_annealing, step)))
+
+
+class ArdaeEngine:
+    def __init__(self, model, cdae, cfg: TrainConfig, batch_size, process_group=None):
+        model._require_gpu()
+        cdae._require_gpu()
+        self.model, self.cdae, self.cfg = model, cdae, cfg
+        self.B = int(batch_size)                       # per-rank image batch
+        self.dev = model._flat.device
+        self.lib = L.lib()
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        md, cd = model._desc, cdae._desc
+        B, nzc, nzm = self.B, cfg.nz_cdae, cfg.nz_model
+        N = B * nzc
+        z, nd = model.z_dim, model.noise_dim
+        f = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
+        lib = self.lib
+        ws_floats = max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, nzc, 1),
+                        lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzc, 0))
+        self.ws = f(ws_floats)
+        self.ws_vae = f(lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzm, 1))
+        self.ws_small = f(max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, nzm, 0),
+                              lib.ardae_model_workspace_floats(ctypes.byref(md), B, 1, 0)))
+        self.z0, self.latent = f(B, z), f(N, z)
+        self.noise_s, self.xi, self.eps = f(N, nd), f(N), f(N, z)
+        self.xbar, self.sigma, self.std_b = f(N, z), f(N), f(B)
+        self.noise_v, self.zv, self.z0v, self.u, self.g = f(B * nzm, nd), f(B * nzm, z), f(B, z), f(B * nzm, z), f(B * nzm, z)
+        self.sigma0 = torch.zeros(B * nzm, device=self.dev)
+        self.loss_c, self.losses_m = f(1), f(3)
+        self.grads_c = torch.zeros_like(cdae._flat)
+        self.grads_m = torch.zeros_like(model._flat)
+        # optimiser state (flat; the cDAE's last tensor, neglogprob.fc.bias, gets no gradient in the reference and is skipped)
+        self.n_c = cdae._flat.numel() - (1 if cdae._kind == "grad" else 0)
+        self.sq_c, self.buf_c = torch.zeros_like(cdae._flat), torch.zeros_like(cdae._flat)
+        self.m_m, self.v_m = torch.zeros_like(model._flat), torch.zeros_like(model._flat)
+        self.step_count = 0
+        self.repack()
+
+    # ------------------------------------------------------------------------------------------------------------
+    def repack(self):
+        self.model._packed = None
+        self.cdae._packed = None
+        self.pk_m = self.model._packed_weights()
+        self.pk_c = self.cdae._packed_weights()
+
+    def _pack_model(self):
+        L.check(self.lib.ardae_model_pack(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.stream_ptr()))
+
+    def _pack_cdae(self):
+        L.check(self.lib.ardae_cdae_pack(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.stream_ptr()))
+
+    def _encode(self, x, noise, nz, out, ws):
+        L.check(self.lib.ardae_model_encode(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x),
+                                            L.ptr(noise) if noise is not None else None, x.size(0), nz, L.ptr(ws), ws.numel(),
+                                            L.ptr(out), L.stream_ptr()), "ardae_model_encode")
+
+    def _allreduce_mean(self, t):
+        if self.world > 1:
+            torch.distributed.all_reduce(t, group=self.pg)
+            t.mul_(1.0 / self.world)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def cdae_phase(self, x, noise=None, apply_update=True):
+        """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z])."""
+        cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
+        B, nz, z = self.B, cfg.nz_cdae, self.model.z_dim
+        self._encode(x, None, 1, self.z0, self.ws_small)                       # context == latent_mean (lt0)
+        ns = noise["sampler"] if noise else rng.normal(None, self.dev, out=self.noise_s)
+        self._encode(x, ns, nz, self.latent, self.ws)                          # forward_hidden
+        xi = noise["sigma"].reshape(-1) if noise else rng.normal(None, self.dev, out=self.xi)
+        eps = noise["eps"] if noise else rng.normal(None, self.dev, out=self.eps)
+        L.check(lib.ardae_latent_perturb(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, z, cfg.std_scale, cfg.delta,
+                                         L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb")
+        L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
+                                          L.ptr(self.sigma), L.ptr(eps), L.ptr(self.z0), B, nz, L.ptr(self.ws), self.ws.numel(),
+                                          L.ptr(self.loss_c), L.ptr(self.grads_c), None, st), "ardae_cdae_loss_grads")
+        self._allreduce_mean(self.grads_c[:self.n_c])
+        if apply_update:
+            L.check(lib.ardae_rmsprop_step(L.ptr(self.cdae._flat), L.ptr(self.grads_c), L.ptr(self.sq_c), L.ptr(self.buf_c), self.n_c,
+                                           cfg.d_lr, 0.99, 1e-8, cfg.d_momentum, st), "ardae_rmsprop_step")
+            self._pack_cdae()
+
+    def vae_phase(self, x, noise=None, beta=None, apply_update=True):
+        """ivae_ardae.py:781-846.  noise: optional dict(vae [B*nz_model, nd])."""
+        cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
+        beta = cfg.beta if beta is None else beta
+        B, nz, md = self.B, cfg.nz_model, self.model._desc
+        nv = noise["vae"] if noise else rng.normal(None, self.dev, out=self.noise_v)
+        L.check(lib.ardae_model_vae_forward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
+                                            float(beta), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.zv), L.ptr(self.losses_m), st),
+                "ardae_model_vae_forward")
+        self._encode(x, None, 1, self.z0v, self.ws_small)
+        L.check(lib.ardae_center_scale(L.ptr(self.zv), L.ptr(self.z0v), B, nz, self.model.z_dim, cfg.std_scale, L.ptr(self.u), st))
+        L.check(lib.ardae_cdae_score(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.u),
+                                     L.ptr(self.sigma0), L.ptr(self.z0v), B, nz, L.ptr(self.ws_small), self.ws_small.numel(),
+                                     L.ptr(self.g), st), "ardae_cdae_score")
+        # seed of (s (z - z0)).backward(beta g / (B nz)) w.r.t. z  (ivae_ardae.py:834); B is the per-rank batch because the
+        # ranks' gradients are averaged afterwards (mean over ranks of 1/B_local == 1/B_global sum)
+        self.g.mul_(cfg.std_scale * beta / float(B * nz))
+        L.check(lib.ardae_model_vae_backward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
+                                             float(beta), 1.0, L.ptr(self.g), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.grads_m),
+                                             0.0, st), "ardae_model_vae_backward")
+        self._allreduce_mean(self.grads_m)
+        if apply_update:
+            self.step_count += 1
+            L.check(lib.ardae_adam_ref_step(L.ptr(self.model._flat), L.ptr(self.grads_m), L.ptr(self.m_m), L.ptr(self.v_m), None,
+                                            self.model._flat.numel(), cfg.m_lr, cfg.m_beta1, 0.999, 1e-8, self.step_count, st),
+                    "ardae_adam_ref_step")
+            self._pack_model()
+
+    def step(self, x_cdae, x_vae, noise=None, beta=None):
+        """One iteration of the reference loop: num_cdae_updates cDAE updates (each on its own batch in the reference; the
+        caller passes a list of batches when num_cdae_updates > 1) followed by one VAE update."""
+        xs = x_cdae if isinstance(x_cdae, (list, tuple)) else [x_cdae] * self.cfg.num_cdae_updates
+        for xc in xs:
+            self.cdae_phase(xc, noise)
+        self.vae_phase(x_vae, noise, beta)
+
+    def stats(self):
+        """Host copy of the logged scalars of ivae_ardae.py:756-758,774,837-841 (this is the only synchronising call)."""
+        v = torch.cat([self.loss_c, self.losses_m, self.std_b.mean().reshape(1), self.std_b.max().reshape(1), self.std_b.min().reshape(1)]).tolist()
+        return dict(cdae_loss=v[0], model_loss=v[1], recon=v[2], prior=v[3], std_mean=v[4], std_max=v[5], std_min=v[6])

@@ -1,0 +1,54 @@
+"""Parameter names / shapes / flat-buffer offsets, identical to the reference's `named_parameters()` order.
+
+Reference: models/layers.py:477-515 (MLP: `layers.{i}.{weight,bias}`, `fc.{weight,bias}`), :681-724 (ContextConcatMLP),
+models/ivae/mnist.py:123-199, models/ivae/toy.py:154-194,694-737, models/graddae/mlp.py:342-378,
+models/resdae/mlp.py:287-326.  The C++ side (csrc/cdae.hip, csrc/model.hip) computes the same offsets; the ABI
+test checks `ardae_*_param_floats` against these totals.
+"""
+import math
+
+
+def _mlp(prefix, din, dh, dout, n_hidden, extra_in=0):
+    spec = []
+    for i in range(n_hidden):
+        spec += [(f"{prefix}layers.{i}.weight", (dh, (din if i == 0 else dh) + extra_in)), (f"{prefix}layers.{i}.bias", (dh,))]
+    spec += [(f"{prefix}fc.weight", (dout, (din if n_hidden == 0 else dh) + extra_in)), (f"{prefix}fc.bias", (dout,))]
+    return spec
+
+
+def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers):
+    if kind == "mnist":
+        s = _mlp("encode.inp_encode.", input_dim, h_dim, h_dim, n_layers + 1)
+        s += _mlp("encode.fc.", h_dim + noise_dim, h_dim, z_dim, 1)
+        s += _mlp("decode.main.", z_dim, h_dim, h_dim, n_layers)
+        s += [("decode.reparam.logit_fn.weight", (input_dim, h_dim)), ("decode.reparam.logit_fn.bias", (input_dim,))]
+    elif kind == "toy":
+        s = _mlp("encode.inp_encode.", input_dim, h_dim, h_dim, n_layers - 1)
+        s += _mlp("encode.fc.", h_dim, h_dim, z_dim, n_layers, extra_in=noise_dim)
+        s += _mlp("decode.main.", z_dim, h_dim, h_dim, n_layers - 1)
+        s += [("decode.reparam.mean_fn.weight", (input_dim, h_dim)), ("decode.reparam.mean_fn.bias", (input_dim,)),
+              ("decode.reparam.logvar_fn.weight", (input_dim, h_dim)), ("decode.reparam.logvar_fn.bias", (input_dim,))]
+    else:
+        raise NotImplementedError(kind)
+    return s
+
+
+def cdae_spec(kind, input_dim, context_dim, h_dim, n_layers):
+    s = _mlp("ctx_encode.", context_dim, h_dim, h_dim, n_layers - 1)
+    s += _mlp("inp_encode.", input_dim, h_dim, h_dim, n_layers - 1)
+    if kind == "grad":
+        s += _mlp("neglogprob.", 2 * h_dim + 1, h_dim, 1, n_layers)
+    elif kind == "res":
+        s += _mlp("dae.", 2 * h_dim + 1, h_dim, input_dim, n_layers)
+    else:
+        raise NotImplementedError(kind)
+    return s
+
+
+def offsets(spec):
+    out, off = {}, 0
+    for name, shape in spec:
+        n = math.prod(shape)
+        out[name] = (off, n, shape)
+        off += n
+    return out, off

@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's model / cDAE object surface, backed by the HIP library.
+
+    net.MNISTIPVAE / net.ToyIPVAE        <- models/ivae/mnist.py:201-301, models/ivae/toy.py:739-873 (enc_type='concat')
+    net.MLPGradCARDAE / net.MLPResCARDAE <- models/graddae/mlp.py:341-483, models/resdae/mlp.py:286-413
+
+Same constructor kwargs, same `state_dict()` keys and `[out, in]` layouts (reference checkpoints load), same method
+names and argument meaning, same exception types.  Parameters are `nn.Parameter` views into ONE flat fp32 buffer
+(the layout the C ABI consumes); forward/backward are `torch.autograd.Function`s that call the ABI.  There is no
+PyTorch fallback: on a CPU tensor or without the built library these modules raise.
+"""
+import ctypes
+import math
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import layout
+from . import rng
+
+
+class _Box(nn.Module):
+    """Name-only container (gives parameters their dotted reference names)."""
+
+
+class _EncodeBox(_Box):
+    """`model.encode(x, std=0)` -> [B, nz, z] (Encoder.forward, ivae/mnist.py:102-121).  Holds the `encode.*` parameters by
+    name; the computation is the owning model's sampler (the owner is kept out of the module tree on purpose)."""
+
+    def forward(self, x, noise=None, std=None, nz=1):
+        o = self._owner_ref()
+        return o._sample(o._x(x), nz, std, noise)
+
+
+class FlatParamModule(nn.Module):
+    def _build_params(self, spec, boxes=None):
+        boxes = boxes or {}
+        self._spec = spec
+        self._offs, total = layout.offsets(spec)
+        self.register_buffer("_flat", torch.zeros(total), persistent=False)
+        for name, (off, n, shape) in self._offs.items():
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, boxes.get(p, _Box)() if mod is self else _Box())
+                mod = mod._modules[p]
+            mod.register_parameter(parts[-1], nn.Parameter(self._flat[off:off + n].view(shape)))
+        self._packed = None
+        self._packed_version = -1
+
+    # keep the parameters views of the flat buffer across .to()/.cuda()/.float()
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._relink()
+        return self
+
+    def _relink(self):
+        flat = self._flat
+        for name, p in self.named_parameters():
+            off, n, shape = self._offs[name]
+            p.data = flat[off:off + n].view(shape)
+        self._packed = None
+        self._packed_version = -1
+
+    def flat_params(self):
+        return self._flat
+
+    def _default_init(self):
+        """nn.Linear's default init (kaiming_uniform(a=sqrt 5) == U(+-1/sqrt(fan_in)) for weight and bias)."""
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("weight"):
+                    fan_in = p.shape[1]
+                else:
+                    fan_in = dict(self._spec)[name[:-len("bias")] + "weight"][1]
+                bound = 1.0 / math.sqrt(fan_in)
+                p.uniform_(-bound, bound)
+
+    def _require_gpu(self, *tensors):
+        if not self._flat.is_cuda:
+            raise RuntimeError(f"{type(self).__name__}: parameters are on {self._flat.device}; the HIP engine needs .to('cuda') "
+                               "(there is no CPU path)")
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError(f"{type(self).__name__}: got a {t.device} tensor; inputs must be on the GPU")
+
+    def _version(self):
+        # in-place updates through a parameter bump that parameter's own counter (p.data views do not share the base's)
+        return self._flat._version + sum(p._version for p in self.parameters())
+
+    def _ws(self, nfloats):
+        return torch.empty(nfloats, device=self._flat.device, dtype=torch.float32)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conditional AR-DAE
+# ---------------------------------------------------------------------------------------------------------------
+class _CdaeLossFn(torch.autograd.Function):
+    """forward = ConditionalARDAE.forward's loss; the double backward runs in the same ABI call, so backward() only scales."""
+
+    @staticmethod
+    def forward(ctx, mod, xbar, sigma, eps, context, B, S, *params):
+        lib = L.lib()
+        d = mod._desc
+        ws = mod._ws(lib.ardae_cdae_workspace_floats(ctypes.byref(d), B, S, 1))
+        loss = torch.empty(1, device=xbar.device)
+        grads = torch.zeros_like(mod._flat)
+        L.check(lib.ardae_cdae_loss_grads(ctypes.byref(d), L.ptr(mod._flat), L.ptr(mod._packed_weights()), L.ptr(xbar), L.ptr(sigma),
+                                          L.ptr(eps), L.ptr(context), B, S, L.ptr(ws), ws.numel(), L.ptr(loss), L.ptr(grads), None,
+                                          L.stream_ptr()), "ardae_cdae_loss_grads")
+        ctx.mod, ctx.grads = mod, grads
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        mod = ctx.mod
+        out = []
+        for name, p in mod.named_parameters():
+            if name in mod._no_grad_names:
+                out.append(None)      # the reference leaves .grad = None here
+                continue
+            off, n, shape = mod._offs[name]
+            out.append(ctx.grads[off:off + n].view(shape) * gloss)
+        return (None,) * 7 + tuple(out)
+
+
+class ConditionalARDAE(FlatParamModule):
+    _kind = None
+
+    def __init__(self, input_dim=2, h_dim=128, context_dim=2, std=0.01, num_hidden_layers=1, nonlinearity="tanh",
+                 noise_type="gaussian", enc_input=True, enc_ctx=True, std_method="default"):
+        super().__init__()
+        if noise_type != "gaussian":
+            raise NotImplementedError            # reference: graddae/mlp.py:392-393 for unknown types; only gaussian is on the path
+        if not (enc_input and enc_ctx):
+            raise NotImplementedError("enc_input=enc_ctx=True is the only configuration ivae_ardae.py:583-606 constructs")
+        if nonlinearity not in ("softplus", "relu") or (self._kind == "grad" and nonlinearity != "softplus"):
+            raise NotImplementedError(f"nonlinearity {nonlinearity!r}: the HIP engine implements softplus (and relu for mlp-res)")
+        self.input_dim, self.h_dim, self.context_dim, self.std = input_dim, h_dim, context_dim, std
+        self.num_hidden_layers, self.nonlinearity, self.noise_type = num_hidden_layers, nonlinearity, noise_type
+        self.enc_input, self.enc_ctx = enc_input, enc_ctx
+        self._desc = L.CdaeDesc(0 if self._kind == "grad" else 1, input_dim, context_dim, h_dim, num_hidden_layers, L.ACT[nonlinearity])
+        self._build_params(layout.cdae_spec(self._kind, input_dim, context_dim, h_dim, num_hidden_layers))
+        self._no_grad_names = {"neglogprob.fc.bias"} if self._kind == "grad" else set()
+        self._default_init()
+
+    def _packed_weights(self):
+        if self._packed is None or self._packed_version != self._version():
+            lib = L.lib()
+            if self._packed is None:
+                self._packed = self._ws(lib.ardae_cdae_packed_floats(ctypes.byref(self._desc)))
+            L.check(lib.ardae_cdae_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_cdae_pack")
+            self._packed_version = self._version()
+        return self._packed
+
+    def _prep(self, input, context, std):
+        assert input.dim() == 3      # bsz x ssz x x_dim   (graddae/mlp.py:402)
+        assert context.dim() == 3    # bsz x 1 x ctx_dim   (graddae/mlp.py:403)
+        B, S = input.size(0), input.size(1)
+        self._require_gpu(input, context)
+        if std is None:
+            std = input.new_zeros(B, S, 1)
+        else:
+            assert torch.is_tensor(std)
+        x = _f32c(input).view(B * S, self.input_dim)
+        c = _f32c(context).view(B, self.context_dim)
+        s = _f32c(std).reshape(B * S)
+        return B, S, x, c, s
+
+    def forward(self, input, context, std=None, scale=None, eps=None):
+        """-> (None, loss) like the reference.  `scale` is accepted and ignored (graddae/mlp.py:410-411).
+        `eps` injects the Gaussian perturbation draw ([B*S, x_dim]); default: the library's Philox stream."""
+        B, S, x, c, s = self._prep(input, context, std)
+        if eps is None:
+            eps = rng.normal((B * S, self.input_dim), x.device)
+        eps = _f32c(eps).view(B * S, self.input_dim)
+        xbar = torch.addcmul(x, s[:, None], eps)         # add_gaussian_noise (graddae/mlp.py:21-23)
+        loss = _CdaeLossFn.apply(self, xbar, s, eps, c, B, S, *self.parameters())
+        return None, loss
+
+    def glogprob(self, input, context, std=None, scale=None):
+        B, S, x, c, s = self._prep(input, context, std)
+        lib = L.lib()
+        ws = self._ws(lib.ardae_cdae_workspace_floats(ctypes.byref(self._desc), B, S, 0))
+        out = torch.empty(B * S, self.input_dim, device=x.device)
+        L.check(lib.ardae_cdae_score(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(x), L.ptr(s),
+                                     L.ptr(c), B, S, L.ptr(ws), ws.numel(), L.ptr(out), L.stream_ptr()), "ardae_cdae_score")
+        return out.view(B, S, self.input_dim)
+
+
+class MLPGradCARDAE(ConditionalARDAE):
+    """models/graddae/mlp.py::ConditionalARDAE (`--cdae mlp-grad`)."""
+    _kind = "grad"
+
+
+class MLPResCARDAE(ConditionalARDAE):
+    """models/resdae/mlp.py::ConditionalARDAE (`--cdae mlp-res`)."""
+    _kind = "res"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# implicit-posterior VAE
+# ---------------------------------------------------------------------------------------------------------------
+def normal_energy_func(x, mu=0., logvar=0.):
+    """utils/energy.py:74-77 (the only prior energy the HIP engine implements)."""
+    x = x.view(x.size(0), -1)
+    return torch.sum(0.5 * (logvar + (x - mu) ** 2 / math.exp(logvar) + math.log(2. * math.pi)), dim=1)
+
+
+class _VaeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, noise, beta, nz, *params):
+        lib = L.lib()
+        d = mod._desc
+        B = x.size(0)
+        ws = mod._ws(lib.ardae_model_workspace_floats(ctypes.byref(d), B, nz, 1))
+        z = torch.empty(B * nz, mod.z_dim, device=x.device)
+        losses = torch.empty(3, device=x.device)
+        L.check(lib.ardae_model_vae_forward(ctypes.byref(d), L.ptr(mod._flat), L.ptr(mod._packed_weights()), L.ptr(x), L.ptr(noise), B, nz,
+                                            float(beta), L.ptr(ws), ws.numel(), L.ptr(z), L.ptr(losses), L.stream_ptr()),
+                "ardae_model_vae_forward")
+        ctx.mod, ctx.ws, ctx.x, ctx.noise, ctx.beta, ctx.nz = mod, ws, x, noise, float(beta), nz
+        ctx.mark_non_differentiable(losses)
+        return z.view(B, nz, mod.z_dim), losses[0].clone(), losses
+
+    @staticmethod
+    def backward(ctx, dz, dloss, _dlosses):
+        mod, lib = ctx.mod, L.lib()
+        B = ctx.x.size(0)
+        grads = torch.empty_like(mod._flat)
+        dl = float(dloss) if dloss is not None else 0.0
+        dzc = _f32c(dz).view(B * ctx.nz, mod.z_dim) if dz is not None else None
+        L.check(lib.ardae_model_vae_backward(ctypes.byref(mod._desc), L.ptr(mod._flat), L.ptr(mod._packed_weights()), L.ptr(ctx.x),
+                                             L.ptr(ctx.noise), B, ctx.nz, ctx.beta, dl, L.ptr(dzc), L.ptr(ctx.ws), ctx.ws.numel(),
+                                             L.ptr(grads), 0.0, L.stream_ptr()), "ardae_model_vae_backward")
+        out = []
+        for name, _ in mod.named_parameters():
+            off, n, shape = mod._offs[name]
+            out.append(grads[off:off + n].view(shape))
+        return (None,) * 5 + tuple(out)
+
+
+class ImplicitPosteriorVAE(FlatParamModule):
+    _kind = None
+
+    def __init__(self, energy_func=normal_energy_func, input_dim=784, noise_dim=100, h_dim=300, z_dim=32, nonlinearity="softplus",
+                 num_hidden_layers=1, init="gaussian", enc_type="concat"):
+        super().__init__()
+        assert enc_type in ["concat"]                    # ivae/mnist.py:224; the other toy encoders are out of scope
+        if energy_func is not normal_energy_func:
+            raise NotImplementedError("only utils.normal_energy_func is implemented on the HIP path")
+        if nonlinearity not in ("softplus", "relu"):
+            raise NotImplementedError(f"nonlinearity {nonlinearity!r}")
+        self.energy_func = energy_func
+        self.input_dim, self.noise_dim, self.h_dim, self.z_dim = input_dim, noise_dim, h_dim, z_dim
+        self.latent_dim = z_dim
+        self.nonlinearity, self.num_hidden_layers, self.init, self.enc_type = nonlinearity, num_hidden_layers, init, enc_type
+        self._desc = L.ModelDesc(0 if self._kind == "mnist" else 1, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, L.ACT[nonlinearity])
+        self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers), {"encode": _EncodeBox})
+        object.__setattr__(self.encode, "_owner_ref", weakref.ref(self))   # `model.encode(x, std=0)` (ivae_ardae.py:735)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._default_init()
+        with torch.no_grad():
+            p = dict(self.named_parameters())
+            if self._kind == "mnist":                     # decode.apply(weight_init): xavier-uniform W, zero b (ivae/mnist.py:20-25,235)
+                for name, t in p.items():
+                    if name.startswith("decode."):
+                        nn.init.xavier_uniform_(t) if t.dim() == 2 else t.zero_()
+            else:                                         # ivae/toy.py:719-720
+                if self.init == "gaussian":
+                    p["decode.reparam.mean_fn.weight"].normal_()
+            if self.init == "gaussian":                   # ivae/mnist.py:158-159
+                p["encode.fc.fc.weight"].normal_()
+
+    def _packed_weights(self):
+        if self._packed is None or self._packed_version != self._version():
+            lib = L.lib()
+            if self._packed is None:
+                self._packed = self._ws(lib.ardae_model_packed_floats(ctypes.byref(self._desc)))
+            L.check(lib.ardae_model_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_model_pack")
+            self._packed_version = self._version()
+        return self._packed
+
+    def _x(self, input):
+        self._require_gpu(input)
+        return _f32c(input).view(input.size(0), self.input_dim)
+
+    def _sample(self, x, nz, std, noise):
+        """z = f(x, std*eps) without autograd (the reference loop detaches every use: ivae_ardae.py:735,748-750)."""
+        B = x.size(0)
+        if noise is None and std is not None and float(std) == 0.0:
+            nptr = None                                   # encode(x, std=0): the draw is multiplied by zero
+        else:
+            if noise is None:
+                noise = rng.normal((B * nz, self.noise_dim), x.device)
+                if std is not None:
+                    noise = noise * float(std)
+            noise = _f32c(noise).view(B * nz, self.noise_dim)
+            nptr = L.ptr(noise)
+        lib = L.lib()
+        ws = self._ws(lib.ardae_model_workspace_floats(ctypes.byref(self._desc), B, nz, 0))
+        z = torch.empty(B * nz, self.z_dim, device=x.device)
+        L.check(lib.ardae_model_encode(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(x), nptr, B, nz,
+                                       L.ptr(ws), ws.numel(), L.ptr(z), L.stream_ptr()), "ardae_model_encode")
+        return z.view(B, nz, self.z_dim)
+
+    def forward_hidden(self, input, std=None, nz=1, noise=None):
+        return self._sample(self._x(input), nz, std, noise)
+
+    def forward(self, input, beta=1.0, eta=0.0, lmbd=0.0, std=None, nz=1, noise=None):
+        """-> (None, None, z, loss, recon.detach(), prior.detach()).  The first two entries (a decoder sample and its mean,
+        used only by the reference's visualisation code) are not produced by the training engine."""
+        if lmbd > 0:
+            raise NotImplementedError                     # ivae/mnist.py:288-290
+        x = self._x(input)
+        B = x.size(0)
+        if noise is None:
+            noise = rng.normal((B * nz, self.noise_dim), x.device)
+            if std is not None:
+                noise = noise * float(std)
+        noise = _f32c(noise).view(B * nz, self.noise_dim)
+        z, loss, losses = _VaeFn.apply(self, x, noise, beta, nz, *self.parameters())
+        return None, None, z, loss, losses[1].detach(), losses[2].detach()
+
+
+class MNISTIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/mnist.py::ImplicitPosteriorVAE (`--model mnist-concat`)."""
+    _kind = "mnist"
+
+
+class ToyIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/toy.py::ImplicitPosteriorVAE with enc_type='concat' (`--model mlp-concat`)."""
+    _kind = "toy"
+
+    def __init__(self, energy_func=normal_energy_func, input_dim=2, noise_dim=2, h_dim=64, z_dim=2, nonlinearity="tanh",
+                 num_hidden_layers=1, init="gaussian", enc_type="scale"):
+        if enc_type != "concat":
+            raise NotImplementedError(f"enc_type {enc_type!r}: only 'concat' is on the BASELINE path (SURVEY 2 #5)")
+        super().__init__(energy_func, input_dim, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, init, enc_type)
