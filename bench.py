@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- AR-DAE-VAE train-steps/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): BASELINE config #2 -- MNISTIPVAE (784 -> z=32, h=256, 2 layers, softplus) with the
+mlp-grad conditional AR-DAE (h=256, L=3), GLOBAL batch 512 images x nz_cdae 256 Monte-Carlo rows, synthetic
+dynamically-binarised images generated on the device.  One step = the loop body of the reference's train()
+(ivae_ardae.py:707-846): one cDAE update (RMSprop) + one VAE update (Adam), nothing skipped.  With N GPUs the image
+batch is sharded (512/N per rank, strong scaling), gradients all-reduced over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task description) including
+  roofline     -- the dominant kernel, timed live with HIP events on the launch stream in a second, instrumented pass
+  cpu_baseline -- the oracle's restatement of the same step timed on this box's host cores (bounded sample)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense FP32 matrix peak (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops_per_step(B, nz, z=32, h=256, L=3, D=784, nd=100):
+    """2*[N*3(F_inp + F_neg + S) + B*3 F_ctx] + sampler forward on N rows (+ the VAE update on B rows)."""
+    N = B * nz
+    F_inp = z * h + (L - 1) * h * h
+    F_ctx = z * h + (L - 1) * h * h
+    F_neg = (2 * h + 1) * h + (L - 1) * h * h + h
+    S = h + (L - 1) * h * h + h * h + (L - 1) * h * h + z * h
+    cdae = 2 * (N * 3 * (F_inp + F_neg + S) + B * 3 * F_ctx)
+    sampler = 2 * N * (nd * h + h * z)
+    F_vae = D * h + 3 * h * h + (h + nd) * h + h * z + z * h + 2 * h * h + h * D
+    return cdae + sampler + 2 * B * 3 * F_vae
+
+
+def cpu_baseline(steps=2, warm=1):
+    """The oracle (a restatement of the reference's op sequence, pinned against it) on this box's host cores."""
+    from oracle import ardae_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    mc = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
+    cc = O.CdaeCfg("grad", 32, 32, 256, 3)
+    tc = O.TrainCfg(nz_cdae=256)
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc))
+    pc = O.init_params(O.cdae_param_spec(cc), 1)
+    st_m, st_c = {}, {}
+    gen = torch.Generator().manual_seed(0)
+    p = (torch.rand(784, generator=gen) < 0.2).float() * 0.6 + 0.03
+    times = []
+    for t in range(warm + steps):
+        xc = torch.bernoulli(p.expand(512, -1), generator=gen)
+        xv = torch.bernoulli(p.expand(512, -1), generator=gen)
+        noise = O.draw_step_noise(mc, tc, 512, gen)
+        t0 = time.perf_counter()
+        O.train_step(mc, cc, tc, pm, pc, st_m, st_c, xc, xv, noise)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[warm:]) / steps
+    return {"value": 1.0 / dt, "unit": "train-steps/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full steps (B=512, nz_cdae=256) after {warm} warm-up, oracle/ardae_oracle.py (PyTorch CPU autograd)",
+            "s_per_step": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=5, help="instrumented steps for the live roofline numbers")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import ardae_amd as net
+    from ardae_amd import _lib as L
+    import ctypes
+
+    GLOBAL_B, NZ = 512, 256
+    assert GLOBAL_B % world == 0, "the global batch must divide over the ranks"
+    B = GLOBAL_B // world
+    torch.manual_seed(0)                                  # identical parameters on every rank
+    model = net.MNISTIPVAE(input_dim=784, noise_dim=100, h_dim=256, num_hidden_layers=2, nonlinearity="softplus",
+                           enc_type="concat", z_dim=32).to(dev)
+    cdae = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=256, num_hidden_layers=3, nonlinearity="softplus",
+                             noise_type="gaussian", enc_ctx=True, enc_input=True).to(dev)
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=B)
+    net.manual_seed(42 + rank)                            # different noise / images per rank (different shards)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    pimg = ((torch.rand(784, generator=g) < 0.2).float() * 0.6 + 0.03).to(dev)
+    xc, xv = torch.empty(B, 784, device=dev), torch.empty(B, 784, device=dev)
+    lib = L.lib()
+    state = {"i": 0}
+
+    def one_step():
+        # dynamic binarisation on the device (datasets/mnist.py:36-40): two fresh batches per step
+        i = state["i"]; state["i"] += 1
+        L.check(lib.ardae_bernoulli(L.ptr(pimg), B, 784, L.ptr(xc), ctypes.c_uint64(1000 + rank), ctypes.c_uint64(2 * i), L.stream_ptr()))
+        L.check(lib.ardae_bernoulli(L.ptr(pimg), B, 784, L.ptr(xv), ctypes.c_uint64(1000 + rank), ctypes.c_uint64(2 * i + 1), L.stream_ptr()))
+        eng.step(xc, xv)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    stats = eng.stats()
+
+    # ---- live per-kernel timing (HIP events on the launch stream), separate from the throughput region
+    roofline = None
+    if rank == 0:
+        lib.ardae_profile_enable(1)
+        for _ in range(args.prof_steps):
+            one_step()
+        rep = L.profile_report()
+        lib.ardae_profile_enable(0)
+        rep.sort(key=lambda e: -e["total_ms"])
+        top = rep[0]
+        ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get(top["name"], {}).get("hbm_bytes_per_launch")
+        roofline = {"bound": "mfma", "kernel": top["name"], "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "avg_launch_us": 1e3 * top["total_ms"] / top["calls"], "launches_per_step": top["calls"] / args.prof_steps,
+                    "algorithmic_gflop_per_launch": top["flops"] / top["calls"] / 1e9,
+                    "algorithmic_mbytes_per_launch": top["bytes"] / top["calls"] / 1e6,
+                    "kernels": [{"name": e["name"], "calls_per_step": e["calls"] / args.prof_steps,
+                                 "ms_per_step": e["total_ms"] / args.prof_steps,
+                                 "tflops": e["flops"] / (e["total_ms"] * 1e-3) / 1e12 if e["total_ms"] > 0 else 0.0} for e in rep[:8]]}
+    barrier()
+
+    if rank == 0:
+        steps_per_s = args.steps / dt
+        flop = algorithmic_flops_per_step(GLOBAL_B, NZ)
+        out = {
+            "metric": "AR-DAE-VAE train-steps/sec (batch 512, nz_cdae 256) on dbMNIST", "value": steps_per_s, "unit": "train-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config #2: MNISTIPVAE mlp z=32 h=256 + cDAE mlp-grad h=256 L=3, global batch 512, "
+                                   "nz_cdae 256 (131072 rows), dynamic binarisation on device, 1 cDAE + 1 VAE update per step",
+                       "global_batch": GLOBAL_B, "nz_cdae": NZ, "per_gpu_batch": B, "parallelism": f"dp{world}"},
+            "algorithmic_tflop_per_step": flop / 1e12,
+            "whole_step_tflops": flop * steps_per_s / 1e12,
+            "whole_step_frac_of_fp32_mfma_peak": flop * steps_per_s / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+            "losses": stats,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

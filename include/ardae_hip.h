@@ -183,6 +183,19 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
                              const float* noise, int B, int nz, float beta, float dloss, const float* dz_extra,
                              float* workspace, size_t workspace_floats, float* grads, float grads_beta, void* stream);
 
+
+/* ---- live per-kernel timing (bench.py roofline): HIP events around every launch on the launch stream ---------- */
+typedef struct ardae_profile_entry {
+  char name[96];   /* kernel name as rocprofv3 prints it (template arguments included)                         */
+  int calls;
+  double total_ms; /* sum of event-to-event durations                                                         */
+  double flops;    /* algorithmic FLOPs (2*MAC) of those launches                                             */
+  double bytes;    /* algorithmic HBM bytes of those launches (operands read once + results written once)     */
+} ardae_profile_entry;
+int ardae_profile_enable(int on);
+/* synchronises, aggregates by kernel, clears the log; returns the number of distinct kernels */
+int ardae_profile_report(ardae_profile_entry* entries, int max_entries);
+
 #ifdef __cplusplus
 }
 #endif

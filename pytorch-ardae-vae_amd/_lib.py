@@ -60,6 +60,11 @@ class CdaeDesc(ctypes.Structure):
                 ("h_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
 
 
+class ProfileEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 96), ("calls", ctypes.c_int), ("total_ms", ctypes.c_double), ("flops", ctypes.c_double),
+                ("bytes", ctypes.c_double)]
+
+
 class ModelDesc(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("input_dim", ctypes.c_int), ("noise_dim", ctypes.c_int), ("h_dim", ctypes.c_int),
                 ("z_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
@@ -106,6 +111,8 @@ EXPORTS = {
     "ardae_model_vae_backward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                  ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
+    "ardae_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "ardae_profile_report": (ctypes.c_int, [ctypes.POINTER(ProfileEntry), ctypes.c_int]),
     "ardae_cdae_score": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 2),
 }
@@ -151,3 +158,11 @@ def ptr(t):
 def stream_ptr():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_report(max_entries=64):
+    """Per-kernel (name, calls, total_ms, flops, bytes) since ardae_profile_enable(1); synchronises and clears the log."""
+    buf = (ProfileEntry * max_entries)()
+    n = lib().ardae_profile_report(buf, max_entries)
+    return [dict(name=buf[i].name.decode(), calls=buf[i].calls, total_ms=buf[i].total_ms, flops=buf[i].flops, bytes=buf[i].bytes)
+            for i in range(min(n, max_entries))]

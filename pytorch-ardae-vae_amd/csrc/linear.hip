@@ -13,6 +13,7 @@
 //  * the epilogue works on the accumulator layout directly (col = l&31, row = (r&3)+8*(r>>2)+4*hh):
 //    every dword load/store instruction touches two full 128-B lines.
 #include "linear.h"
+#include "profile.h"
 
 namespace ardae {
 
@@ -312,7 +313,18 @@ template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB
 int launch_geo(const LinArgs& a, hipStream_t st) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
   dim3 grid(ceil_div(a.M, G::BM), ceil_div(a.Nout, G::BN));
+  if (g_prof_enabled) {
+    char name[96];
+    snprintf(name, sizeof(name), "linear_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", TM, TN, WM, WN, KPANEL, EPI, ACT, MINB);
+    double ksum = 0;
+    for (int s = 0; s < a.nsrc; ++s) ksum += a.src[s].K;
+    // algorithmic bytes: X read once, Y (+Y2) written once, S/R/Q read once, weights once
+    double tensors = 1.0 + (a.Y2 ? 1 : 0) + ((EPI == EPI_DACT || EPI == EPI_CHAIN) ? 1 : 0) + ((EPI == EPI_CHAIN) ? 1 : 0) +
+                     ((EPI == EPI_DACT && a.Q) ? 1 : 0);
+    prof_begin(st, name, 2.0 * a.M * (double)a.Nout * ksum, 4.0 * ((double)a.M * ksum + tensors * a.M * (double)a.Nout + ksum * a.Nout));
+  }
   hipLaunchKernelGGL((linear_kernel<TM, TN, WM, WN, KPANEL, EPI, ACT, MINB>), grid, dim3(256), 0, st, a);
+  prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

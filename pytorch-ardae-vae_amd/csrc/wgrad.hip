@@ -6,6 +6,7 @@
 // kk=l>>5) supplies A[o=c][k=kk] = G[m0+kk][o] and B[k=kk][i=c] = X[m0+kk][i], i.e. both fragment reads are
 // 32 consecutive floats per half-wave - conflict-free ds_read_b32).
 #include "wgrad.h"
+#include "profile.h"
 
 namespace ardae {
 namespace {
@@ -226,7 +227,16 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
     if (el > max_elems) max_elems = el;
   }
   b.wg_begin[nprob] = total;
+  if (g_prof_enabled) {
+    double fl = 0, by = 0;
+    for (int i = 0; i < nprob; ++i) {
+      fl += 2.0 * probs[i].npairs * (double)probs[i].M * probs[i].O * probs[i].I;
+      by += 4.0 * (probs[i].npairs * (double)probs[i].M * (probs[i].O + probs[i].I) + (double)probs[i].splits * probs[i].O * probs[i].I);
+    }
+    prof_begin(st, "wgrad_kernel", fl, by);
+  }
   hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(256), 0, st, b);
+  prof_end(st);
   ARDAE_LAUNCH_CHECK();
   const int rb = (int)ceil_div64((int64_t)max_elems, 256);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb < 1024 ? rb : 1024, nprob), dim3(256), 0, st, b);

@@ -11,6 +11,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib as L
+from . import dist
 from . import rng
 
 
@@ -45,9 +46,7 @@ class ArdaeEngine:
         self.dev = model._flat.device
         self.lib = L.lib()
         self.pg = process_group
-        self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world = torch.distributed.get_world_size(process_group)
+        self.world = dist.world_size(process_group)
         md, cd = model._desc, cdae._desc
         B, nzc, nzm = self.B, cfg.nz_cdae, cfg.nz_model
         N = B * nzc
@@ -94,9 +93,7 @@ class ArdaeEngine:
                                             L.ptr(out), L.stream_ptr()), "ardae_model_encode")
 
     def _allreduce_mean(self, t):
-        if self.world > 1:
-            torch.distributed.all_reduce(t, group=self.pg)
-            t.mul_(1.0 / self.world)
+        dist.allreduce_mean_(t, self.pg)
 
     # ------------------------------------------------------------------------------------------------------------
     def cdae_phase(self, x, noise=None, apply_update=True):
@@ -135,7 +132,7 @@ class ArdaeEngine:
                                      L.ptr(self.g), st), "ardae_cdae_score")
         # seed of (s (z - z0)).backward(beta g / (B nz)) w.r.t. z  (ivae_ardae.py:834); B is the per-rank batch because the
         # ranks' gradients are averaged afterwards (mean over ranks of 1/B_local == 1/B_global sum)
-        self.g.mul_(cfg.std_scale * beta / float(B * nz))
+        self.g.mul_(dist.entropy_seed_scale(cfg.std_scale, beta, B, nz))
         L.check(lib.ardae_model_vae_backward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
                                              float(beta), 1.0, L.ptr(self.g), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.grads_m),
                                              0.0, st), "ardae_model_vae_backward")

@@ -1,0 +1,97 @@
+"""The C-ABI library loads and exports every symbol include/ardae_hip.h declares (no compute: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import ardae_amd
+from ardae_amd import _lib as L
+from ardae_amd import layout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ardae_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ardae_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    h = ctypes.CDLL(L.LIB_PATH)
+    for s in syms:
+        assert hasattr(h, s), f"{s} declared in include/ardae_hip.h but not exported by libardae_hip.so"
+        assert s in L.EXPORTS, f"{s} has no ctypes binding in _lib.EXPORTS"
+    assert sorted(L.EXPORTS) == syms
+
+
+def test_abi_version_and_error_channel():
+    lib = L.lib()
+    assert lib.ardae_abi_version() == 1
+    a = L.LinearArgs()
+    assert lib.ardae_linear(ctypes.byref(a), 0, None) < 0          # argument validation happens before any HIP call
+    assert b"empty problem" in lib.ardae_last_error()
+    with pytest.raises(ValueError):
+        L.check(lib.ardae_pack_weight(None, 0, 0, 0, 0, None, None))
+
+
+@pytest.mark.parametrize("kind,args", [("mnist", (784, 100, 256, 32, 2)), ("toy", (2, 10, 256, 2, 2)), ("mnist", (24, 10, 64, 8, 2))])
+def test_model_layout_matches_c_side(kind, args):
+    spec = layout.model_spec(kind, *args)
+    _, total = layout.offsets(spec)
+    d = L.ModelDesc(0 if kind == "mnist" else 1, *args, 2)
+    assert L.lib().ardae_model_param_floats(ctypes.byref(d)) == total
+    assert L.lib().ardae_model_packed_floats(ctypes.byref(d)) > total
+    assert L.lib().ardae_model_workspace_floats(ctypes.byref(d), 8, 16, 1) > 0
+
+
+@pytest.mark.parametrize("kind,args", [("grad", (32, 32, 256, 3)), ("res", (32, 32, 1024, 6)), ("grad", (2, 2, 256, 3)), ("grad", (32, 32, 512, 4))])
+def test_cdae_layout_matches_c_side(kind, args):
+    spec = layout.cdae_spec(kind, *args)
+    _, total = layout.offsets(spec)
+    d = L.CdaeDesc(0 if kind == "grad" else 1, *args, 2)
+    assert L.lib().ardae_cdae_param_floats(ctypes.byref(d)) == total
+    assert L.lib().ardae_cdae_workspace_floats(ctypes.byref(d), 4, 8, 1) > L.lib().ardae_cdae_workspace_floats(ctypes.byref(d), 4, 8, 0) > 0
+
+
+def test_survey_parameter_counts():
+    """839 472 / 543 489 (cfg #2), 271 386 / 528 129 (cfg #1), 2 923 521 (cfg #4 cDAE), 17 943 584 (cfg #5 cDAE)."""
+    tot = lambda spec: layout.offsets(spec)[1]
+    assert tot(layout.model_spec("mnist", 784, 100, 256, 32, 2)) == 839472
+    assert tot(layout.cdae_spec("grad", 32, 32, 256, 3)) == 543489
+    assert tot(layout.model_spec("toy", 2, 10, 256, 2, 2)) == 271386
+    assert tot(layout.cdae_spec("grad", 2, 2, 256, 3)) == 528129
+    assert tot(layout.cdae_spec("grad", 32, 32, 512, 4)) == 2923521
+    assert tot(layout.cdae_spec("res", 32, 32, 1024, 6)) == 17943584
+
+
+def test_modules_refuse_cpu_execution():
+    """No silent fallback: the HIP path is the only path."""
+    import torch
+    m = ardae_amd.MNISTIPVAE(input_dim=24, noise_dim=10, h_dim=64, num_hidden_layers=2, nonlinearity="softplus", enc_type="concat", z_dim=8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.encode(torch.zeros(2, 24), std=0)
+    c = ardae_amd.MLPGradCARDAE(input_dim=8, context_dim=8, std=1., h_dim=64, num_hidden_layers=3, nonlinearity="softplus")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        c(torch.zeros(2, 3, 8), torch.zeros(2, 1, 8))
+    with pytest.raises(NotImplementedError):
+        ardae_amd.MLPGradCARDAE(input_dim=8, context_dim=8, h_dim=64, num_hidden_layers=3, nonlinearity="softplus", noise_type="laplace")
+    with pytest.raises(NotImplementedError):
+        ardae_amd.ToyIPVAE(enc_type="scale")
+
+
+def test_state_dict_roundtrip_keeps_flat_views():
+    import torch
+    m = ardae_amd.MNISTIPVAE(input_dim=24, noise_dim=10, h_dim=64, num_hidden_layers=2, nonlinearity="softplus", enc_type="concat", z_dim=8)
+    sd = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    off = 0
+    for n, p in m.named_parameters():
+        assert p.data_ptr() == m.flat_params().data_ptr() + 4 * off      # still views of the one flat buffer
+        assert torch.equal(p, sd[n])
+        off += p.numel()
+    m2 = m.double().float()                                               # _apply keeps the views linked
+    assert all(p.data_ptr() >= m2.flat_params().data_ptr() for p in m2.parameters())

@@ -1,0 +1,98 @@
+"""Oracle (CPU restatement) against the golden vectors generated from the reference (oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ardae_oracle as O
+
+CASES = {
+    "tiny_mnist_grad": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, torch.float32),
+    "tiny_mnist_grad_f64": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, torch.float64),
+    "tiny_mnist_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("res", 8, 8, 64, 3), 8, torch.float32),
+    "tiny_toy_grad": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3), 8, torch.float32),
+}
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_step_matches_reference_fixture(golden_dir, name):
+    mc, cc, nz, dt = CASES[name]
+    fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    tc = O.TrainCfg(nz_cdae=nz)
+    tol = 2e-4 if dt == torch.float32 else 1e-9    # another CPU/BLAS than the one that wrote the fixture: fp32 noise x 1e4 (std_scale)
+    pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
+    pc = {n: torch.tensor(fx["pc/" + n]) for n, _ in O.cdae_param_spec(cc)}
+    for t in range(int(fx["meta_steps"])):
+        pre = f"s{t}/"
+        noise = {k: torch.tensor(fx[pre + "noise/" + k]) for k in ("sampler", "sigma", "eps", "vae")}
+        xc, xv = torch.tensor(fx[pre + "x_cdae"]), torch.tensor(fx[pre + "x_vae"])
+        closs, gc, std = O.cdae_update_grads(mc, cc, tc, pm, pc, xc, noise)
+        assert abs(float(closs) - float(fx[pre + "cdae_loss"])) / float(fx[pre + "cdae_loss"]) < tol
+        assert rel_l2(std, torch.tensor(fx[pre + "std"])) < tol
+        for n, _ in O.cdae_param_spec(cc):
+            if pre + "cdae_grads/" + n + "/none" in fx:
+                assert gc[n] is None
+            else:
+                assert rel_l2(gc[n], torch.tensor(fx[pre + "cdae_grads/" + n])) < 20 * tol, n
+        pc = {n: torch.tensor(fx[pre + "cdae_params_after/" + n]) for n, _ in O.cdae_param_spec(cc)}
+        mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, tc, pm, pc, xv, noise)
+        assert abs(float(mloss) - float(fx[pre + "model_loss"])) / float(fx[pre + "model_loss"]) < tol
+        assert abs(float(rec) - float(fx[pre + "recon"])) / float(fx[pre + "recon"]) < tol
+        assert rel_l2(g, torch.tensor(fx[pre + "score"])) < 20 * tol
+        for n, _ in O.model_param_spec(mc):
+            assert rel_l2(gm[n], torch.tensor(fx[pre + "model_grads/" + n])) < 20 * tol, n
+        pm = {n: torch.tensor(fx[pre + "model_params_after/" + n]) for n, _ in O.model_param_spec(mc)}
+
+
+def test_oracle_optimizers_match_reference_fixture(golden_dir):
+    mc, cc, nz, _ = CASES["tiny_mnist_grad"]
+    fx = dict(np.load(os.path.join(golden_dir, "tiny_mnist_grad.npz")))
+    pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
+    pc = {n: torch.tensor(fx["pc/" + n]) for n, _ in O.cdae_param_spec(cc)}
+    st_m, st_c = {}, {}
+    for t in range(int(fx["meta_steps"])):
+        pre = f"s{t}/"
+        gc = {n: (None if pre + "cdae_grads/" + n + "/none" in fx else torch.tensor(fx[pre + "cdae_grads/" + n])) for n in pc}
+        gm = {n: torch.tensor(fx[pre + "model_grads/" + n]) for n in pm}
+        O.rmsprop_step(pc, gc, st_c, 1e-4, 0.5)
+        O.adam_ref_step(pm, gm, st_m, 1e-4, 0.5)
+        for n in pc:
+            assert torch.allclose(pc[n], torch.tensor(fx[pre + "cdae_params_after/" + n]), rtol=3e-7, atol=1e-9), n
+        for n in pm:
+            assert torch.allclose(pm[n], torch.tensor(fx[pre + "model_params_after/" + n]), rtol=3e-7, atol=1e-9), n
+        pc = {n: torch.tensor(fx[pre + "cdae_params_after/" + n]) for n in pc}
+        pm = {n: torch.tensor(fx[pre + "model_params_after/" + n]) for n in pm}
+    assert "neglogprob.fc.bias" not in st_c            # no gradient -> no optimiser state
+
+
+def test_oracle_iwae_matches_reference_fixture(golden_dir):
+    fx = dict(np.load(os.path.join(golden_dir, "iwae_tiny.npz")))
+    mc = O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus")
+    pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
+    got = O.iwae_logprob(mc, pm, torch.tensor(fx["x"]), int(fx["meta_k"]), torch.tensor(fx["enc_noise"]), torch.tensor(fx["prop_noise"]))
+    assert abs(float(got) - float(fx["logprob"])) / abs(float(fx["logprob"])) < 1e-9
+
+
+def test_closed_form_known_answer_one_layer_score():
+    """Analytic score of a 1-layer softplus energy (known-answer test): with L=1 the cDAE is
+    E = w . sp(W1a sp(A1 x + b1) + ...), whose input-gradient is checked against autograd in float64."""
+    cc = O.CdaeCfg("grad", 3, 2, 5, 1)
+    p = O.init_params(O.cdae_param_spec(cc), 11, dtype=torch.float64)
+    x = torch.randn(4, 3, dtype=torch.float64, requires_grad=True)
+    ctx = torch.randn(4, 2, dtype=torch.float64)
+    sig = torch.rand(4, 1, dtype=torch.float64)
+    g = O.cdae_score(cc, p, x, ctx, sig, create_graph=False)
+    A1, b1 = p["inp_encode.fc.weight"], p["inp_encode.fc.bias"]
+    C1, c1 = p["ctx_encode.fc.weight"], p["ctx_encode.fc.bias"]
+    W1, d1, w = p["neglogprob.layers.0.weight"], p["neglogprob.layers.0.bias"], p["neglogprob.fc.weight"]
+    a = torch.nn.functional.softplus(x.detach() @ A1.T + b1)
+    c = torch.nn.functional.softplus(ctx @ C1.T + c1)
+    q = torch.cat([a, c, sig], 1) @ W1.T + d1
+    e = -w * torch.sigmoid(q)                                           # e_L = -w (.) s(q_L)
+    r = (e @ W1[:, :5]) * torch.sigmoid(x.detach() @ A1.T + b1)         # r_L = (W1a^T e) (.) s(p_L)
+    assert torch.allclose(g, r @ A1, rtol=1e-12, atol=1e-14)            # g = A1^T r
