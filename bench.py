@@ -45,7 +45,8 @@ def algorithmic_flops_per_step(B, nz, z=32, h=256, L=3, D=784, nd=100):
 def cpu_baseline(steps=2, warm=1):
     """The oracle (a restatement of the reference's op sequence, pinned against it) on this box's host cores."""
     from oracle import ardae_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # a one-GPU box grants 16 host cores (the driver's CPU share); more threads than that only oversubscribe
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     mc = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
     cc = O.CdaeCfg("grad", 32, 32, 256, 3)
     tc = O.TrainCfg(nz_cdae=256)

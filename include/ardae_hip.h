@@ -73,7 +73,7 @@ int ardae_abi_version(void);
  * replaces models/layers.py:501-515 (MLP.forward) and the autograd passes over it.                          */
 size_t ardae_packed_floats(int nout, int k);
 int ardae_linear_row_tiles(int M, int nout);
-int ardae_linear_col_panels(int nout);
+int ardae_linear_col_panels(int M, int nout);
 /* M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]  ->  MFMA-lane-linear image (out: ardae_packed_floats) */
 int ardae_pack_weight(const float* W, int ldw, int nout, int k, int transpose, float* out, void* stream);
 int ardae_linear(const ardae_linear_args* args, int epilogue, void* stream);

@@ -79,7 +79,7 @@ EXPORTS = {
     "ardae_abi_version": (ctypes.c_int, []),
     "ardae_packed_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "ardae_linear_row_tiles": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
-    "ardae_linear_col_panels": (ctypes.c_int, [ctypes.c_int]),
+    "ardae_linear_col_panels": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "ardae_pack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_linear": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_void_p]),

@@ -26,7 +26,7 @@ int ardae_abi_version(void) { return ARDAE_ABI_VERSION; }
 
 size_t ardae_packed_floats(int nout, int k) { return packed_floats(nout, k); }
 int ardae_linear_row_tiles(int M, int nout) { return linear_row_tiles(M, nout); }
-int ardae_linear_col_panels(int nout) { return linear_col_panels(nout); }
+int ardae_linear_col_panels(int M, int nout) { return linear_col_panels(M, nout); }
 
 int ardae_pack_weight(const float* W, int ldw, int nout, int k, int transpose, float* out, void* stream) {
   return launch_pack_weight(W, ldw, nout, k, transpose != 0, out, (hipStream_t)stream);

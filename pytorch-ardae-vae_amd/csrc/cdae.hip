@@ -136,7 +136,7 @@ size_t workspace_floats(const CdaeLayout& P, int B, int S, bool need_grads) {
   t += (size_t)(P.L) * al((size_t)B * h) + al((size_t)B * h);            // c_l, cb
   t += (size_t)(need_grads ? 8 : 4) * P.L * al(N * h);                   // a,hh,e,r (+ tau,taup,pbar,qbar)
   t += 2 * al(N * P.z);                                                  // gbar, g
-  t += al((size_t)linear_row_tiles((int)N, P.z) * linear_col_panels(P.z));
+  t += al((size_t)linear_row_tiles((int)N, P.z) * linear_col_panels((int)N, P.z));
   if (need_grads) {
     t += al((size_t)B * h) + (size_t)P.L * al((size_t)B * h);            // Qsum, chat_l
     t += al((size_t)linear_row_tiles((int)N, P.h) * h);                  // colsum of tau'_L
@@ -200,7 +200,7 @@ int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed
     for (int l = 1; l <= L; ++l) { tau[l] = ws.take(Nh); taup[l] = ws.take(Nh); pbar[l] = ws.take(Nh); qbar[l] = ws.take(Nh); }
   float* gbar = ws.take((size_t)N * z);
   float* gbuf = ws.take((size_t)N * z);
-  const int ltiles = linear_row_tiles(N, z) * linear_col_panels(z);
+  const int ltiles = linear_row_tiles(N, z) * linear_col_panels(N, z);
   float* tile_loss = ws.take(ltiles);
   float* g = score_out ? score_out : gbuf;
 

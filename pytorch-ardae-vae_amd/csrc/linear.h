@@ -22,9 +22,9 @@ enum Epi : int {
 // number of floats of the packed image of an [nout, k] matrix
 size_t packed_floats(int nout, int k);
 // rows per row-tile of the geometry launch_linear() picks for this Nout (colsum / tile_loss sizing)
-int linear_row_tile(int nout);
+int linear_row_tile(int M, int nout);
 int linear_row_tiles(int M, int nout);
-int linear_col_panels(int nout);
+int linear_col_panels(int M, int nout);
 
 // M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]
 int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose, float* out, hipStream_t st);

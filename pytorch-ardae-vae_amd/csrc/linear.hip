@@ -21,11 +21,11 @@ namespace {
 
 // wide geometry: K panel staged in LDS per pass and the workgroups/CU it is compiled for
 #ifndef ARDAE_WIDE_KPANEL
-#define ARDAE_WIDE_KPANEL 128
+#define ARDAE_WIDE_KPANEL 64
 #endif
 constexpr int WIDE_KPANEL = ARDAE_WIDE_KPANEL;
 #ifndef ARDAE_WIDE_MINB
-#define ARDAE_WIDE_MINB ((ARDAE_WIDE_KPANEL <= 128) ? 3 : 2)
+#define ARDAE_WIDE_MINB 3
 #endif
 constexpr int WIDE_MINB = ARDAE_WIDE_MINB;
 
@@ -34,91 +34,95 @@ struct Geo {
   static constexpr int BM = TM * WM * 32;
   static constexpr int BN = TN * WN * 32;
   static constexpr int LDW = KPANEL + 4;
-  static constexpr int LDS_FLOATS = BM * LDW;
+  static constexpr int LDS_FLOATS = 2 * BM * LDW;   // double-buffered K panels
 };
 
 // Epilogue of one 32x32 accumulator block (16 registers per lane).  All operand loads of the block are issued
 // first, into registers, and only then the math + stores run: outputs may alias inputs (Y == Q in place), so the
 // compiler cannot hoist loads over stores by itself and an element-at-a-time epilogue serialises on HBM latency.
-template <int EPI, int ACT, bool FULL>
-__device__ __forceinline__ void epilogue_block(const LinArgs& a, const f32x16& acc, int rbase, int col, bool cok, float bcol,
-                                               float wsig, float& csum, float& loss_part) {
-  int rowv[16];
-  bool ok[16];
+template <int EPI, int ACT, bool FULL, int R0>
+__device__ __forceinline__ void epilogue_half(const LinArgs& a, const f32x16& acc16, int rbase, int col, bool cok, float bcol,
+                                              float wsig, float& csum, float& loss_part) {
+  // registers R0..R0+7 of the 32x32 block: rows rbase + {0..3} + 8*(R0/4 + {0,1})
+  float acc[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int raw = rbase + (r & 3) + 8 * (r >> 2);
+  for (int r = 0; r < 8; ++r) acc[r] = acc16[R0 + r];
+  int rowv[8];
+  bool ok[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int raw = rbase + ((R0 + r) & 3) + 8 * ((R0 + r) >> 2);
     ok[r] = FULL ? true : (cok && raw < a.M);
     rowv[r] = FULL ? raw : min(raw, a.M - 1);
   }
-  float y[16];
+  float y[8];
   if (EPI == EPI_ACT) {
-    float rb[16], rs[16];
+    float rb[8], rs[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rb[r] = 0.f, rs[r] = 0.f;
+    for (int r = 0; r < 8; ++r) rb[r] = 0.f, rs[r] = 0.f;
     if (a.rowbias) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rb[r] = a.rowbias[(size_t)(rowv[r] / a.rows_per_group) * a.rowbias_ld + col];
+      for (int r = 0; r < 8; ++r) rb[r] = a.rowbias[(size_t)(rowv[r] / a.rows_per_group) * a.rowbias_ld + col];
     }
     if (a.rowscale) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rs[r] = a.rowscale[rowv[r]];
+      for (int r = 0; r < 8; ++r) rs[r] = a.rowscale[rowv[r]];
     }
     const float wv = a.Y2 ? a.R[col] : 0.f;   // R is the [Nout] vector w here
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = act_fwd<ACT>(acc[r] + bcol + rb[r] + rs[r] * wsig);
+    for (int r = 0; r < 8; ++r) y[r] = act_fwd<ACT>(acc[r] + bcol + rb[r] + rs[r] * wsig);
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < 8; ++r)
       if (ok[r]) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
     if (a.Y2) {   // seed of the score pass: e_L = -w (.) act'(pre)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
+      for (int r = 0; r < 8; ++r)
         if (ok[r]) a.Y2[(size_t)rowv[r] * a.ldY2 + col] = -wv * act_d1<ACT>(y[r]);
     }
   } else if (EPI == EPI_DACT) {
-    float sv[16], qv[16];
+    float sv[8], qv[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
+    for (int r = 0; r < 8; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
     if (a.Q) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) qv[r] = a.Q[(size_t)rowv[r] * a.ldQ + col];
+      for (int r = 0; r < 8; ++r) qv[r] = a.Q[(size_t)rowv[r] * a.ldQ + col];
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) qv[r] = 0.f;
+      for (int r = 0; r < 8; ++r) qv[r] = 0.f;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = acc[r] * act_d1<ACT>(sv[r]) + qv[r];
+    for (int r = 0; r < 8; ++r) y[r] = acc[r] * act_d1<ACT>(sv[r]) + qv[r];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < 8; ++r)
       if (ok[r]) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
   } else if (EPI == EPI_CHAIN) {
-    float sv[16], rv[16];
+    float sv[8], rv[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
+    for (int r = 0; r < 8; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rv[r] = a.R[(size_t)rowv[r] * a.ldR + col];
-    float y2[16];
+    for (int r = 0; r < 8; ++r) rv[r] = a.R[(size_t)rowv[r] * a.ldR + col];
+    float y2[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       // softplus: s = 1 - exp(-a) and 1 - s = exp(-a) are both formed without cancellation
       const float em = (ACT == ACT_SOFTPLUS) ? __expf(-sv[r]) : 0.f;
       y[r] = acc[r] * act_d1<ACT>(sv[r]);
       y2[r] = acc[r] * rv[r] * em;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < 8; ++r)
       if (ok[r]) {
         a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
         a.Y2[(size_t)rowv[r] * a.ldY2 + col] = y2[r];
       }
   } else {  // EPI_DAE_LOSS
-    float sg[16], ev[16];
+    float sg[8], ev[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sg[r] = a.sigma[rowv[r]];
+    for (int r = 0; r < 8; ++r) sg[r] = a.sigma[rowv[r]];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ev[r] = a.eps[(size_t)rowv[r] * a.ldeps + col];
+    for (int r = 0; r < 8; ++r) ev[r] = a.eps[(size_t)rowv[r] * a.ldeps + col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       y[r] = acc[r] + bcol;
       const float rho = sg[r] * y[r] + ev[r];
       if (ok[r]) {
@@ -129,7 +133,14 @@ __device__ __forceinline__ void epilogue_block(const LinArgs& a, const f32x16& a
     }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) csum += ok[r] ? y[r] : 0.f;
+  for (int r = 0; r < 8; ++r) csum += ok[r] ? y[r] : 0.f;
+}
+
+template <int EPI, int ACT, bool FULL>
+__device__ __forceinline__ void epilogue_block(const LinArgs& a, const f32x16& acc, int rbase, int col, bool cok, float bcol,
+                                               float wsig, float& csum, float& loss_part) {
+  epilogue_half<EPI, ACT, FULL, 0>(a, acc, rbase, col, cok, bcol, wsig, csum, loss_part);
+  epilogue_half<EPI, ACT, FULL, 8>(a, acc, rbase, col, cok, bcol, wsig, csum, loss_part);
 }
 
 template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB>
@@ -157,103 +168,153 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int s = 0; s < a.nsrc; ++s) {
-    const float* __restrict__ x = a.src[s].x;
-    const float* __restrict__ wp = a.src[s].wp;
-    const int ld = a.src[s].ld, K = a.src[s].K;
-    const int kchunks = (K + 7) >> 3;
-    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    for (int k0 = 0; k0 < K; k0 += KPANEL) {
-      const int kw = min(KPANEL, K - k0);
-      const int kw8 = (kw + 7) & ~7;
-      const int c4n = kw8 >> 2;
-      __syncthreads();
-      // ---- stage X[row0:row0+BM, k0:k0+kw8] into LDS (zero fill outside M x K) ----
-      if (vec && rows_full && kw8 == kw && (c4n & (c4n - 1)) == 0) {
-        // fast path: whole float4s, power-of-two row length -> shift/mask indexing, loads batched 4 deep
-        const int sh = 31 - __clz(c4n);
-        const int rpp = 256 >> sh;                     // rows covered per pass
-        const int passes = BM / rpp;                   // BM and rpp are powers of two, rpp <= BM since c4n >= 2... (K >= 8)
-        const int r0 = tid >> sh, c = (tid & (c4n - 1)) << 2;
-        const float* p = x + (size_t)(row0 + r0) * ld + k0 + c;
-        float* q = &lds[r0 * LDW + c];
-        const size_t gstep = (size_t)rpp * ld;
-        const int lstep = rpp * LDW;
-        if (rpp <= BM) {
-          for (int p0 = 0; p0 < passes; p0 += 4) {
-            f32x4 v[4];
+  // ---- K loop: (source, K panel) items, LDS double-buffered.  While the MFMAs of panel t run, the global loads of
+  //      panel t+1 are in flight into registers; they are written to the other LDS buffer after the MFMA loop, so
+  //      there is ONE barrier per panel and HBM latency hides behind 128 MFMAs per wave.
+  constexpr int MAXP = (BM * KPANEL / 4 + 255) / 256;   // float4 per thread per full panel
+  struct Panel {
+    const float* x; const float* wp;
+    int ld, K, k0, kw8, c4n, kchunks;
+    bool fast;
+  };
+  auto make_panel = [&](int s, int k0) {
+    Panel p;
+    p.x = a.src[s].x; p.wp = a.src[s].wp; p.ld = a.src[s].ld; p.K = a.src[s].K; p.k0 = k0;
+    const int kw = min(KPANEL, p.K - k0);
+    p.kw8 = (kw + 7) & ~7;
+    p.c4n = p.kw8 >> 2;
+    p.kchunks = (p.K + 7) >> 3;
+    const bool vec = ((p.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    p.fast = vec && rows_full && p.kw8 == kw && (p.c4n & (p.c4n - 1)) == 0 && (256 / p.c4n) <= BM;
+    return p;
+  };
+  f32x4 pv[MAXP];
+  // fast path: whole float4s, power-of-two row length -> shift/mask indexing
+  auto panel_load = [&](const Panel& p) {
+    const int sh = 31 - __clz(p.c4n);
+    const int rpp = 256 >> sh, passes = BM / rpp;
+    const float* src = p.x + (size_t)(row0 + (tid >> sh)) * p.ld + p.k0 + ((tid & (p.c4n - 1)) << 2);
+    const size_t gstep = (size_t)rpp * p.ld;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (p0 + u < passes) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(p0 + u) * gstep);
+    for (int u = 0; u < MAXP; ++u)
+      if (u < passes) pv[u] = *reinterpret_cast<const f32x4*>(src + (size_t)u * gstep);
+  };
+  auto panel_store = [&](const Panel& p, float* buf) {
+    const int sh = 31 - __clz(p.c4n);
+    const int rpp = 256 >> sh, passes = BM / rpp;
+    float* dst = buf + (tid >> sh) * LDW + ((tid & (p.c4n - 1)) << 2);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (p0 + u < passes) *reinterpret_cast<f32x4*>(q + (p0 + u) * lstep) = v[u];
-          }
-        } else if (r0 < BM) {
-          *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(p);
-        }
-      } else {
-        for (int idx = tid; idx < BM * c4n; idx += 256) {
-          const int r = idx / c4n;
-          const int c = (idx - r * c4n) << 2;
-          const int grow = row0 + r, gcol = k0 + c;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (grow < a.M) {
-            const float* p = x + (size_t)grow * ld + gcol;
-            if (vec && gcol + 4 <= K) {
-              v = *reinterpret_cast<const f32x4*>(p);
-            } else {
+    for (int u = 0; u < MAXP; ++u)
+      if (u < passes) *reinterpret_cast<f32x4*>(dst + u * rpp * LDW) = pv[u];
+  };
+  // generic path: ragged rows / K, unaligned or tiny rows (zero fill outside M x K)
+  auto panel_stage_slow = [&](const Panel& p, float* buf) {
+    const bool vec = ((p.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    for (int idx = tid; idx < BM * p.c4n; idx += 256) {
+      const int r = idx / p.c4n;
+      const int c = (idx - r * p.c4n) << 2;
+      const int grow = row0 + r, gcol = p.k0 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (grow < a.M) {
+        const float* q = p.x + (size_t)grow * p.ld + gcol;
+        if (vec && gcol + 4 <= p.K) {
+          v = *reinterpret_cast<const f32x4*>(q);
+        } else {
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (gcol + j < K) v[j] = p[j];
-            }
-          }
-          *reinterpret_cast<f32x4*>(&lds[r * LDW + c]) = v;
+          for (int j = 0; j < 4; ++j)
+            if (gcol + j < p.K) v[j] = q[j];
         }
       }
-      __syncthreads();
-      // ---- MFMA over this panel: weight fragments prefetched two chunks ahead straight from L2 ----
-      if (wave_active) {
-        const int nch = kw8 >> 3, kc0 = k0 >> 3;
-        const float* arow[TM];
+      *reinterpret_cast<f32x4*>(&buf[r * LDW + c]) = v;
+    }
+  };
+  auto next_item = [&](int& s, int& k0) {   // -> false when the sequence is exhausted
+    k0 += KPANEL;
+    if (k0 >= a.src[s].K) { ++s; k0 = 0; }
+    return s < a.nsrc;
+  };
+
+#ifdef ARDAE_STAMPS
+  const unsigned long long T0 = __builtin_amdgcn_s_memtime();
+#endif
+  int cs = 0, ck0 = 0;
+  Panel cur = make_panel(0, 0);
+  if (cur.fast) { panel_load(cur); panel_store(cur, lds); } else panel_stage_slow(cur, lds);
+  __syncthreads();
+#ifdef ARDAE_STAMPS
+  const unsigned long long T1 = __builtin_amdgcn_s_memtime();
+#endif
+  int bufsel = 0;
+  while (true) {
+    int ns = cs, nk0 = ck0;
+    const bool has_next = next_item(ns, nk0);
+    Panel nxt = cur;
+    if (has_next) {
+      nxt = make_panel(ns, nk0);
+      if (nxt.fast) panel_load(nxt);          // in flight during the MFMA loop
+    }
+    if (wave_active) {
+      const float* lbuf = lds + bufsel * (BM * LDW);
+      const int nch = cur.kw8 >> 3, kc0 = cur.k0 >> 3;
+      const float* arow[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) arow[i] = &lds[((wm * TM + i) * 32 + l31) * LDW + hh * 4];
-        const float* bptr[TN];
+      for (int i = 0; i < TM; ++i) arow[i] = &lbuf[((wm * TM + i) * 32 + l31) * LDW + hh * 4];
+      const float* bptr[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int nb = min(nb0 + j, nblk_total - 1);   // clamp: out-of-range blocks are masked at the store
-          bptr[j] = wp + ((size_t)nb * kchunks + kc0) * 256 + lane * 4;
-        }
-        f32x4 b0[TN], b1[TN];
+      for (int j = 0; j < TN; ++j) {
+        const int nb = min(nb0 + j, nblk_total - 1);   // clamp: out-of-range blocks are masked at the store
+        bptr[j] = cur.wp + ((size_t)nb * cur.kchunks + kc0) * 256 + lane * 4;
+      }
+      // weight fragments: two register sets, the other one is always in flight (L2 latency behind 16 MFMAs)
+      f32x4 be[TN], bo[TN], av[TM];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          b0[j] = *reinterpret_cast<const f32x4*>(bptr[j]);
-          b1[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)min(1, nch - 1) * 256);
-        }
-        for (int kc = 0; kc < nch; ++kc) {
-          f32x4 av[TM], bn[TN];
-          const int kn = min(kc + 2, nch - 1);
+      for (int j = 0; j < TN; ++j) be[j] = *reinterpret_cast<const f32x4*>(bptr[j]);
+      int kc = 0;
+      for (; kc + 1 < nch; kc += 2) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bn[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)kn * 256);
+        for (int j = 0; j < TN; ++j) bo[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)(kc + 1) * 256);
 #pragma unroll
-          for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc * 8);
+        for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc * 8);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], b0[j][q], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], be[j][q], acc[i][j], 0, 0, 0);
+        const int kn = min(kc + 2, nch - 1);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            b0[j] = b1[j];
-            b1[j] = bn[j];
-          }
-        }
+        for (int j = 0; j < TN; ++j) be[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)kn * 256);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const f32x4*>(arow[i] + (kc + 1) * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bo[j][q], acc[i][j], 0, 0, 0);
+      }
+      if (kc < nch) {   // odd tail (be holds chunk kc)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], be[j][q], acc[i][j], 0, 0, 0);
       }
     }
+    if (!has_next) break;
+    float* obuf = lds + (bufsel ^ 1) * (BM * LDW);
+    if (nxt.fast) panel_store(nxt, obuf); else panel_stage_slow(nxt, obuf);
+    __syncthreads();
+    bufsel ^= 1;
+    cur = nxt; cs = ns; ck0 = nk0;
   }
 
+#ifdef ARDAE_STAMPS
+  const unsigned long long T2 = __builtin_amdgcn_s_memtime();
+#endif
   // ------------------------------------------------------------------ epilogue
   float loss_part = 0.f;
   if (wave_active) {
@@ -278,6 +339,14 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
       }
     }
   }
+#ifdef ARDAE_STAMPS
+  if (a.tile_loss != nullptr && EPI != EPI_DAE_LOSS && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long T3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(a.tile_loss) + ((size_t)blockIdx.x * 4 + wave) * 4;
+    o[0] = T0; o[1] = T1; o[2] = T2; o[3] = T3;
+  }
+#endif
   if (EPI == EPI_DAE_LOSS && a.tile_loss != nullptr) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) loss_part += __shfl_xor(loss_part, off);
@@ -329,21 +398,39 @@ int launch_geo(const LinArgs& a, hipStream_t st) {
   return 0;
 }
 
+// 0 = narrow (Nout <= 32: 128 rows x 32 cols per workgroup), 1 = small-M (32 x 128: per-image B-row problems, where the
+// wide tiling would occupy a handful of CUs and serialise 512 MFMAs per wave), 2 = wide (64 x 256)
+int pick_geometry(int M, int nout) {
+  if (nout <= 32) return 0;
+  if ((int64_t)ceil_div(M, 64) * ceil_div(nout, 256) < 128) return 1;
+  return 2;
+}
+
 template <int EPI, int ACT>
 int launch_epi(const LinArgs& a, hipStream_t st) {
-  if (a.Nout <= 32) {
-    ARDAE_CHECK_ARG(a.colsum == nullptr, "linear: colsum is not available in the narrow (Nout<=32) geometry");
-    return launch_geo<1, 1, 4, 1, 128, EPI, ACT, 2>(a, st);
+  switch (pick_geometry(a.M, a.Nout)) {
+    case 0:
+      ARDAE_CHECK_ARG(a.colsum == nullptr, "linear: colsum is not available in the narrow (Nout<=32) geometry");
+      return launch_geo<1, 1, 4, 1, 64, EPI, ACT, 2>(a, st);
+    case 1:
+      return launch_geo<1, 1, 1, 4, 64, EPI, ACT, 4>(a, st);
+    default:
+      return launch_geo<2, 2, 1, 4, WIDE_KPANEL, EPI, ACT, WIDE_MINB>(a, st);
   }
-  return launch_geo<2, 2, 1, 4, WIDE_KPANEL, EPI, ACT, WIDE_MINB>(a, st);
 }
 
 }  // namespace
 
 size_t packed_floats(int nout, int k) { return (size_t)ceil_div(nout, 32) * ceil_div(k, 8) * 256; }
-int linear_row_tile(int nout) { return nout <= 32 ? 128 : 64; }
-int linear_row_tiles(int M, int nout) { return ceil_div(M, linear_row_tile(nout)); }
-int linear_col_panels(int nout) { return nout <= 32 ? 1 : ceil_div(nout, 256); }
+int linear_row_tile(int M, int nout) {
+  const int g = pick_geometry(M, nout);
+  return g == 0 ? 128 : g == 1 ? 32 : 64;
+}
+int linear_row_tiles(int M, int nout) { return ceil_div(M, linear_row_tile(M, nout)); }
+int linear_col_panels(int M, int nout) {
+  const int g = pick_geometry(M, nout);
+  return g == 0 ? 1 : ceil_div(nout, g == 1 ? 128 : 256);
+}
 
 int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose, float* out, hipStream_t st) {
   ARDAE_CHECK_ARG(W && out && nout > 0 && k > 0 && ldw > 0, "pack_weight: bad arguments");

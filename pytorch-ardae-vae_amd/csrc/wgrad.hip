@@ -74,53 +74,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradBatchDev batch
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f}, rsum = {0.f, 0.f, 0.f, 0.f};
   const bool want_vec = (P.bias_pair >= 0) && (it == 0) && (P.partial_vec != nullptr);
 
-  for (int pr = 0; pr < P.npairs; ++pr) {
+  // Software pipeline over (pair, row chunk): the global loads of chunk t+1 are issued into registers right before the
+  // MFMA loop of chunk t and written to LDS after it, so HBM latency hides behind 128 MFMAs per wave.
+  const int nchunks = (m_end - m_begin + RC - 1) / RC;
+  const int total = nchunks > 0 ? P.npairs * nchunks : 0;
+  const int gc = (tid & 31) << 2, gr = tid >> 5;   // G chunk: 32 rows x 128 cols, 4 float4 per thread
+  const int xc = (tid & 63) << 2, xr = tid >> 6;   // X chunk: 32 rows x 256 cols, 8 float4 per thread
+  f32x4 gv[4], xv[8];
+  float rsv[4];
+  auto fetch = [&](int t) {
+    const int pr = t / nchunks, m0 = m_begin + (t - pr * nchunks) * RC;
     const float* __restrict__ G = P.G[pr];
     const float* __restrict__ X = P.X[pr];
     const int ldG = P.ldG[pr], ldX = P.ldX[pr];
     const bool vecG = ((ldG & 3) == 0) && ((reinterpret_cast<uintptr_t>(G) & 15) == 0);
     const bool vecX = ((ldX & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const bool acc_vec = want_vec && pr == P.bias_pair;
-    for (int m0 = m_begin; m0 < m_end; m0 += RC) {
-      __syncthreads();
-      {  // G chunk: 32 rows x 128 cols
-        const int c = (tid & 31) << 2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = (tid >> 5) + 8 * j;
-          const f32x4 v = load4_guard(G, ldG, m0 + r, o_base + c, m_end, P.O, vecG);
-          *reinterpret_cast<f32x4*>(&Gs[r * BO + c]) = v;
-          if (acc_vec) {
-            bsum += v;
-            if (P.rowscale && m0 + r < m_end) rsum += v * P.rowscale[m0 + r];
-          }
-        }
-      }
-      {  // X chunk: 32 rows x 256 cols
-        const int c = (tid & 63) << 2;
+    for (int j = 0; j < 4; ++j) gv[j] = load4_guard(G, ldG, m0 + gr + 8 * j, o_base + gc, m_end, P.O, vecG);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = (tid >> 6) + 4 * j;
-          *reinterpret_cast<f32x4*>(&Xs[r * BI + c]) = load4_guard(X, ldX, m0 + r, i_base + c, m_end, P.I, vecX);
-        }
+    for (int j = 0; j < 8; ++j) xv[j] = load4_guard(X, ldX, m0 + xr + 4 * j, i_base + xc, m_end, P.I, vecX);
+    if (want_vec && pr == P.bias_pair && P.rowscale) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rsv[j] = (m0 + gr + 8 * j < m_end) ? P.rowscale[m0 + gr + 8 * j] : 0.f;
+    }
+  };
+  if (total > 0) fetch(0);
+  for (int t = 0; t < total; ++t) {
+    const int pr = t / nchunks;
+    __syncthreads();   // every wave is done reading the previous chunk
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&Gs[(gr + 8 * j) * BO + gc]) = gv[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(&Xs[(xr + 4 * j) * BI + xc]) = xv[j];
+    if (want_vec && pr == P.bias_pair) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bsum += gv[j];
+        if (P.rowscale) rsum += gv[j] * rsv[j];
       }
-      __syncthreads();
-      if (nib > 0 && nob > 0) {
-        const float* ga = &Gs[hh * BO + wo * 64 + l31];
-        const float* xb = &Xs[hh * BI + wi * 128 + l31];
+    }
+    __syncthreads();
+    if (t + 1 < total) fetch(t + 1);   // in flight during the MFMA loop below
+    if (nib > 0 && nob > 0) {
+      const float* ga = &Gs[hh * BO + wo * 64 + l31];
+      const float* xb = &Xs[hh * BI + wi * 128 + l31];
 #pragma unroll 4
-        for (int ks = 0; ks < RC / 2; ++ks) {
-          float av[2], bv[4];
+      for (int ks = 0; ks < RC / 2; ++ks) {
+        float av[2], bv[4];
 #pragma unroll
-          for (int a = 0; a < 2; ++a) av[a] = ga[ks * 2 * BO + a * 32];
+        for (int a = 0; a < 2; ++a) av[a] = ga[ks * 2 * BO + a * 32];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) bv[b] = xb[ks * 2 * BI + b * 32];
+        for (int b = 0; b < 4; ++b) bv[b] = xb[ks * 2 * BI + b * 32];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            if (b < nib) {
+        for (int b = 0; b < 4; ++b) {
+          if (b < nib) {
 #pragma unroll
-              for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-            }
+            for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
           }
         }
       }

@@ -139,7 +139,7 @@ def test_linear_dae_loss(z):
     rho = sig.double()[:, None] * gref + eps.double()
     scale = 1.0 / (M * z)
     Y = torch.empty(M, z, device="cuda"); Y2 = torch.empty(M, z, device="cuda")
-    tiles = L.lib().ardae_linear_row_tiles(M, z) * L.lib().ardae_linear_col_panels(z)
+    tiles = L.lib().ardae_linear_row_tiles(M, z) * L.lib().ardae_linear_col_panels(M, z)
     tl = torch.zeros(tiles, device="cuda")
     run_linear(L.EPI_DAE_LOSS, M, z, [(X.cuda(), pack(W.cuda()))], sigma=sig.cuda(), eps=eps.cuda(), scale=scale, Y=Y, Y2=Y2, tile_loss=tl)
     assert relerr(Y, gref) < 2e-5
