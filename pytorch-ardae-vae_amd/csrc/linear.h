@@ -29,5 +29,8 @@ int linear_col_panels(int M, int nout);
 // M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]
 int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose, float* out, hipStream_t st);
 int launch_linear(const LinArgs& a, int epi, hipStream_t st);
+// warp-specialised persistent variant (linear_ws.hip) for the big N-row layers
+bool linear_ws_eligible(const LinArgs& a, int epi);
+int launch_linear_ws(const LinArgs& a, int epi, hipStream_t st);
 
 }  // namespace ardae

@@ -12,6 +12,8 @@
 //    A and B agree);
 //  * the epilogue works on the accumulator layout directly (col = l&31, row = (r&3)+8*(r>>2)+4*hh):
 //    every dword load/store instruction touches two full 128-B lines.
+#include <stdlib.h>
+
 #include "linear.h"
 #include "profile.h"
 
@@ -449,6 +451,14 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
     ARDAE_CHECK_ARG(a.src[s].x && a.src[s].wp && a.src[s].K > 0 && a.src[s].ld >= a.src[s].K,
                     "linear: bad source %d (K=%d ld=%d)", s, a.src[s].K, a.src[s].ld);
   ARDAE_CHECK_ARG(a.Y || epi == EPI_DAE_LOSS, "linear: Y is null");
+  // The warp-specialised persistent kernel (linear_ws.hip) is opt-in (ARDAE_WS=1) until its weight fragments come from LDS:
+  // streaming them from L2 inside the MFMA wave queues behind the producers' HBM traffic ("what was measured").
+  static const bool use_ws = getenv("ARDAE_WS") != nullptr;
+  if (use_ws && linear_ws_eligible(a, epi)) {
+    if (epi == EPI_DACT) ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT needs S");
+    if (epi == EPI_CHAIN) ARDAE_CHECK_ARG(a.S && a.R && a.Y2, "linear: EPI_CHAIN needs S, R and Y2");
+    return launch_linear_ws(a, epi, st);
+  }
   switch (epi) {
     case EPI_ACT:
       ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");

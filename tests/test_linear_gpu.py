@@ -54,7 +54,9 @@ def d1(act, a):
 
 
 @pytest.mark.parametrize("M,K,Nout", [(64, 256, 256), (200, 100, 256), (131, 37, 96), (512, 784, 256),
-                                      (96, 256, 32), (300, 64, 8), (64, 2, 64), (1024, 512, 512), (70, 266, 2)])
+                                      (96, 256, 32), (300, 64, 8), (64, 2, 64), (1024, 512, 512), (70, 266, 2),
+                                      # big-M shapes take the warp-specialised persistent kernel (linear_ws.hip)
+                                      (4096, 256, 256), (8192, 32, 256), (4128, 256, 64), (4096, 64, 192)])
 @pytest.mark.parametrize("act", ["none", "relu", "softplus"])
 def test_linear_act(M, K, Nout, act):
     g = torch.Generator().manual_seed(M * 7 + K * 3 + Nout)
@@ -97,6 +99,39 @@ def test_linear_transposed_pack_and_two_sources():
     assert relerr(Y, ref) < 2e-5
     run_linear(L.EPI_ACT, M, Nout, [(X1.cuda(), pack(Wt.cuda(), transpose=True))], act=0, Y=Y)
     assert relerr(Y, X1.double() @ Wt.double()) < 2e-5
+
+
+@pytest.mark.parametrize("M,K,Nout", [(4096, 256, 256), (12288, 32, 256), (4096, 256, 128)])
+@pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
+def test_linear_warp_specialised_epilogues(M, K, Nout, epi):
+    """Same operators on the persistent warp-specialised kernel (M >= 4096, K % 32 == 0)."""
+    g = torch.Generator().manual_seed(M + K + Nout)
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5
+    S = torch.nn.functional.softplus(torch.randn(M, Nout, generator=g) * 3)
+    Q = torch.randn(M, Nout, generator=g); R = torch.randn(M, Nout, generator=g)
+    v = X.double() @ W.double().T
+    s1 = d1("softplus", S.double())
+    Y = torch.full((M, Nout), float("nan"), device="cuda"); Y2 = torch.full((M, Nout), float("nan"), device="cuda")
+    wpk = pack(W.cuda())
+    if epi == "dact":
+        run_linear(L.EPI_DACT, M, Nout, [(X.cuda(), wpk)], act=2, S=S.cuda(), Y=Y)
+        assert relerr(Y, v * s1) < 2e-5
+    elif epi == "dact_q":
+        Qd = Q.cuda()
+        run_linear(L.EPI_DACT, M, Nout, [(X.cuda(), wpk)], act=2, S=S.cuda(), Q=Qd, Y=Qd)       # in place, as the backward uses it
+        assert relerr(Qd, v * s1 + Q.double()) < 2e-5
+    elif epi == "chain":
+        run_linear(L.EPI_CHAIN, M, Nout, [(X.cuda(), wpk)], act=2, S=S.cuda(), R=R.cuda(), Y=Y, Y2=Y2)
+        assert relerr(Y, v * s1) < 2e-5
+        assert relerr(Y2, v * R.double() * (1 - s1)) < 2e-5
+    else:
+        w = torch.randn(Nout, generator=g); b = torch.randn(Nout, generator=g)
+        rb = torch.randn(M // 16, Nout, generator=g); sig = torch.randn(M, generator=g); wsig = torch.randn(Nout, generator=g)
+        pre = v + b.double() + rb.double().repeat_interleave(16, 0) + sig.double()[:, None] * wsig.double()
+        run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), wpk)], act=2, bias=b.cuda(), rowbias=rb.cuda(), rows_per_group=16,
+                   rowscale=sig.cuda(), rowscale_w=wsig.cuda(), R=w.cuda(), Y=Y, Y2=Y2)
+        assert relerr(Y, torch.nn.functional.softplus(pre)) < 2e-5
+        assert relerr(Y2, -w.double() * torch.sigmoid(pre)) < 2e-5
 
 
 @pytest.mark.parametrize("act", ["relu", "softplus"])
