@@ -32,5 +32,7 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st);
 // warp-specialised persistent variant (linear_ws.hip) for the big N-row layers
 bool linear_ws_eligible(const LinArgs& a, int epi);
 int launch_linear_ws(const LinArgs& a, int epi, hipStream_t st);
+bool linear_ws2_eligible(const LinArgs& a, int epi);
+int launch_linear_ws2(const LinArgs& a, int epi, hipStream_t st);
 
 }  // namespace ardae
