@@ -164,7 +164,7 @@ typedef struct ardae_model_desc {
 } ardae_model_desc;
 size_t ardae_model_param_floats(const ardae_model_desc* d);
 size_t ardae_model_packed_floats(const ardae_model_desc* d);
-/* mode 0: encode only; mode 1: vae_forward + vae_backward */
+/* mode 0: encode only; mode 1: vae_forward + vae_backward; mode 2: decode only (B = rows, nz = 1) */
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode);
 int ardae_model_pack(const ardae_model_desc* d, const float* params, float* packed, void* stream);
 /* Encoder.forward (ivae/mnist.py:102-121): z[B*nz, z] = f(x[B, input_dim], noise[B*nz, noise_dim]); noise NULL = zeros,
@@ -177,6 +177,14 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
 int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
                             const float* noise, int B, int nz, float beta, float* workspace, size_t workspace_floats,
                             float* z_out, float* losses, void* stream);
+/* Decoder.forward (ivae/mnist.py:188-199, toy.py:725-737) without the sample: head outputs for z [R, z_dim]:
+ * out0 = logits (kind 0) / mean (kind 1) [R, input_dim], out1 = logvar (kind 1) or NULL.  Workspace: mode 2.
+ * Used by the IWAE evaluator (ivae/mnist.py:420-425). */
+int ardae_model_decode(const ardae_model_desc* d, const float* params, const float* packed, const float* z, int R,
+                       float* workspace, size_t workspace_floats, float* out0, float* out1, void* stream);
+/* per-row -log p(x|z) and prior energy (utils/vae.py:21-30,36-52; utils/energy.py:69-77): rows = B*nz, x [B, input_dim] */
+int ardae_model_loss_rows(const ardae_model_desc* d, const float* out0, const float* out1, const float* x, const float* z,
+                          int rows, int nz, float* recon_row, float* prior_row, void* stream);
 /* grads = grads_beta*grads + d/dparams [ dloss*loss + <dz_extra, z> ]   (model_loss.backward() and
  * latent.backward(seed), ivae_ardae.py:804,834).  Needs the workspace of the matching vae_forward call. */
 int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,

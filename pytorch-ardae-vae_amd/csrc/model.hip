@@ -220,6 +220,7 @@ size_t ardae_model_packed_floats(const ardae_model_desc* d) { return desc_ok(d) 
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
   if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
   const ModelLayout P(*d);
+  if (mode == 2) return P.dec.size() * al64((size_t)B * nz * P.h);
   return workspace_floats(P, B, nz, mode) + (size_t)al64((size_t)B * nz * P.nd);   // + a zero-noise buffer for encode(std=0)
 }
 
@@ -278,6 +279,38 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   }
   ARDAE_CHECK_ARG(ws.ok, "model_encode: internal workspace accounting error");
   return encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, st);
+}
+
+int ardae_model_decode(const ardae_model_desc* d, const float* params, const float* packed, const float* z, int R, float* workspace,
+                       size_t workspace_floats_, float* out0, float* out1, void* stream) {
+  ARDAE_TRY(desc_ok(d));
+  ARDAE_CHECK_ARG(params && packed && z && workspace && out0 && R > 0, "model_decode: bad arguments");
+  const ModelLayout P(*d);
+  const ModelPacked K(P);
+  ARDAE_CHECK_ARG(P.kind == 0 || out1, "model_decode: the Gaussian decoder needs out1 (logvar)");
+  ARDAE_CHECK_ARG(workspace_floats_ >= P.dec.size() * al64((size_t)R * P.h), "model_decode: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  Bump ws(workspace, workspace_floats_);
+  const int h = P.h;
+  const float* cur = z;
+  for (size_t l = 1; l <= P.dec.size(); ++l) {
+    float* nxt = ws.take((size_t)R * h);
+    LinArgs A{}; A.bias = params + P.dec[l - 1].b; A.Y = nxt; A.ldY = h;
+    ARDAE_TRY(lin1(EPI_ACT, P.act, R, h, cur, l == 1 ? P.zd : h, P.dec[l - 1].in, packed + K.dec_f[l - 1], A, st));
+    cur = nxt;
+  }
+  for (size_t k = 0; k < P.heads.size(); ++k) {
+    LinArgs A{}; A.bias = params + P.heads[k].b; A.Y = k == 0 ? out0 : out1; A.ldY = P.D;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.D, cur, h, h, packed + K.head_f[k], A, st));
+  }
+  return 0;
+}
+
+int ardae_model_loss_rows(const ardae_model_desc* d, const float* out0, const float* out1, const float* x, const float* z, int rows,
+                          int nz, float* recon_row, float* prior_row, void* stream) {
+  ARDAE_TRY(desc_ok(d));
+  return launch_vae_loss(d->kind, out0, out1, x, z, rows, nz, d->input_dim, d->z_dim, 1.f, 0, 0.f, nullptr, recon_row, prior_row, nullptr,
+                         nullptr, nullptr, (hipStream_t)stream);
 }
 
 int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,

@@ -331,6 +331,56 @@ class ImplicitPosteriorVAE(FlatParamModule):
         return None, None, z, loss, losses[1].detach(), losses[2].detach()
 
 
+    # ---- evaluation --------------------------------------------------------------------------------
+    def decode_params(self, z):
+        """Decoder heads for z [R, z_dim] -> (logits,) or (mean, logvar)."""
+        self._require_gpu(z)
+        z = _f32c(z).view(-1, self.z_dim)
+        R, lib = z.size(0), L.lib()
+        ws = self._ws(lib.ardae_model_workspace_floats(ctypes.byref(self._desc), R, 1, 2))
+        o0 = torch.empty(R, self.input_dim, device=z.device)
+        o1 = torch.empty(R, self.input_dim, device=z.device) if self._kind == "toy" else None
+        L.check(lib.ardae_model_decode(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(z), R, L.ptr(ws),
+                                       ws.numel(), L.ptr(o0), L.ptr(o1), L.stream_ptr()), "ardae_model_decode")
+        return (o0,) if o1 is None else (o0, o1)
+
+    def generate(self, batch_size=1):
+        """-> (None, decoder mean, z) with z ~ N(0, I) (ivae/mnist.py:303-316; the relaxed sample is not produced)."""
+        z = rng.normal((batch_size, self.z_dim), self._flat.device)
+        out = self.decode_params(z)
+        return None, (torch.sigmoid(out[0]) if self._kind == "mnist" else out[0]), z
+
+    def logprob(self, input, sample_size=128, z=None, std=None, enc_noise=None, prop_noise=None):
+        """IWAE-k bound with a full-covariance Gaussian fitted to the encoder samples as proposal
+        (logprob_w_cov_gaussian_posterior, ivae/mnist.py:378-437).  All images are processed at once: sampler and decoder
+        are the HIP kernels, the k x z covariance / Cholesky / log-mean-exp glue is batched torch (off the timed path).
+        enc_noise [B, k, noise_dim] / prop_noise [B, k, z] inject the two draws."""
+        x = self._x(input)
+        B, k, zd = x.size(0), sample_size, self.z_dim
+        assert sample_size >= 2 * self.z_dim                 # ivae/mnist.py:382
+        with torch.no_grad():
+            zs = self._sample(x, k, std, enc_noise.reshape(B * k, self.noise_dim) if enc_noise is not None else None)   # [B,k,z]
+            mu = zs.mean(1)
+            zc = zs - mu.unsqueeze(1)
+            cov = zc.transpose(1, 2) @ zc / (k - 1)           # utils/stat.py:127-158
+            try:
+                Lc = torch.linalg.cholesky(cov)
+            except RuntimeError:                              # no device solver in this build: 32x32 factorisations on the host
+                Lc = torch.linalg.cholesky(cov.cpu()).to(cov.device)
+            if prop_noise is None:
+                prop_noise = rng.normal((B, k, zd), x.device)
+            e = _f32c(prop_noise).view(B, k, zd)
+            newz = (mu.unsqueeze(1) + e @ Lc.transpose(1, 2)).contiguous()
+            logq = -0.5 * (e ** 2).sum(2) - torch.log(torch.diagonal(Lc, dim1=1, dim2=2)).sum(1, keepdim=True) - 0.5 * zd * math.log(2 * math.pi)
+            out = self.decode_params(newz.view(B * k, zd))
+            rec = torch.empty(B * k, device=x.device); pri = torch.empty(B * k, device=x.device)
+            L.check(L.lib().ardae_model_loss_rows(ctypes.byref(self._desc), L.ptr(out[0]), L.ptr(out[1]) if len(out) > 1 else None, L.ptr(x),
+                                                  L.ptr(newz), B * k, k, L.ptr(rec), L.ptr(pri), L.stream_ptr()), "ardae_model_loss_rows")
+            lw = -rec.view(B, k) - pri.view(B, k) - logq
+            m, _ = lw.max(1, keepdim=True)
+            return (torch.log(torch.mean((lw - m).exp(), 1, keepdim=True) + 1e-10) + m).mean()
+
+
 class MNISTIPVAE(ImplicitPosteriorVAE):
     """models/ivae/mnist.py::ImplicitPosteriorVAE (`--model mnist-concat`)."""
     _kind = "mnist"

@@ -242,3 +242,21 @@ def test_philox_normal_moments():
     assert abs(float((a ** 4).mean()) - 3) < 0.05
     net.manual_seed(123)
     assert torch.equal(a, net.rng.normal((1 << 20,), "cuda"))                    # reproducible from (seed, offset)
+
+
+def test_iwae_logprob_golden(golden_dir):
+    """model.logprob (IWAE-k, full-covariance Gaussian proposal) against the reference's value with injected draws."""
+    fx = dict(np.load(os.path.join(golden_dir, "iwae_tiny.npz")))
+    mc = O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus")
+    model, _ = build(mc, O.CdaeCfg("grad", 8, 8, 32, 2))
+    model.load_state_dict({n: torch.tensor(fx["pm/" + n]).float() for n, _ in O.model_param_spec(mc)})
+    model = model.to("cuda")
+    k = int(fx["meta_k"])
+    got = model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=k, enc_noise=torch.tensor(fx["enc_noise"]).float().cuda(),
+                        prop_noise=torch.tensor(fx["prop_noise"]).float().cuda())
+    ref = float(fx["logprob"])
+    assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
+    with pytest.raises(AssertionError):
+        model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=8)      # needs sample_size >= 2 z_dim (ivae/mnist.py:382)
+    _, mean, z = model.generate(5)
+    assert mean.shape == (5, 24) and z.shape == (5, 8) and bool((mean >= 0).all() and (mean <= 1).all())
