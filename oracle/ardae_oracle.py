@@ -46,7 +46,7 @@ LOG2PI = math.log(2.0 * math.pi)
 @dataclass
 class ModelCfg:
     """Implicit-posterior VAE hyper-parameters (ivae_ardae.py:295-314)."""
-    kind: str = "mnist"          # "mnist" (MNISTIPVAE) | "toy" (ToyIPVAE, enc_type='concat')
+    kind: str = "mnist"          # "mnist" (MNISTIPVAE) | "toy" (ToyIPVAE, enc_type='concat') | "conv" (ConvIPVAE, 28x28x1)
     input_dim: int = 784
     noise_dim: int = 100
     h_dim: int = 256
@@ -114,6 +114,17 @@ def model_param_spec(c: ModelCfg):
         s += [("decode.reparam.logit_fn.weight", (c.input_dim, c.h_dim)),
               ("decode.reparam.logit_fn.bias", (c.input_dim,))]
         return s
+    if c.kind == "conv":   # models/ivae/conv.py:44-136 + models/vae/conv.py:79-136 (28x28x1 only: the decoder is hard-wired to it)
+        s = [("encode.conv1.weight", (16, 1, 5, 5)), ("encode.conv1.bias", (16,)),
+             ("encode.conv2.weight", (32, 16, 5, 5)), ("encode.conv2.bias", (32,)),
+             ("encode.conv3.weight", (32, 32, 5, 5)), ("encode.conv3.bias", (32,)),
+             ("encode.fc4.weight", (800, 512 + c.noise_dim)), ("encode.fc4.bias", (800,)),
+             ("encode.fc5.weight", (c.z_dim, 800)), ("encode.fc5.bias", (c.z_dim,))]
+        s += _mlp_spec("decode.fc.", c.z_dim, 300, 512, 1)
+        s += [("decode.deconv1.weight", (32, 32, 5, 5)), ("decode.deconv1.bias", (32,)),
+              ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
+              ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
+        return s
     if c.kind == "toy":
         s = _mlp_spec("encode.inp_encode.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
         s += _ctxcat_mlp_spec("encode.fc.", c.h_dim, c.noise_dim, c.h_dim, c.z_dim, c.n_layers)
@@ -152,19 +163,20 @@ def init_params(spec, seed, special=None, dtype=torch.float32):
     special = special or {}
     out = {}
     for name, shape in spec:
-        fan_in = shape[1] if len(shape) == 2 else None
+        fan_in = shape[1] if len(shape) == 2 else (shape[1] * shape[2] * shape[3] if len(shape) == 4 else None)
         kind = special.get(name, ("default",))[0]
         if kind == "normal":
             a = rng.standard_normal(shape)
         elif kind == "zeros":
             a = np.zeros(shape)
         elif kind == "xavier":
-            bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+            rf = shape[2] * shape[3] if len(shape) == 4 else 1
+            bound = math.sqrt(6.0 / ((shape[0] + shape[1]) * rf))
             a = rng.uniform(-bound, bound, shape)
         else:
             if fan_in is None:  # bias: bound uses the fan_in of the matching weight
-                wname = name[:-len("bias")] + "weight"
-                fan_in = dict(spec)[wname][1]
+                wshape = dict(spec)[name[:-len("bias")] + "weight"]
+                fan_in = wshape[1] if len(wshape) == 2 else wshape[1] * wshape[2] * wshape[3]
             bound = 1.0 / math.sqrt(fan_in)
             a = rng.uniform(-bound, bound, shape)
         out[name] = torch.tensor(a, dtype=dtype)
@@ -175,6 +187,12 @@ def model_init_special(c: ModelCfg):
     """Init overrides of the reference constructors."""
     sp = {}
     spec = model_param_spec(c)
+    if c.kind == "conv":   # self.apply(weight_init): xavier-uniform on every Conv2d/Linear (NOT ConvTranspose2d), zero biases
+        for name, shape in spec:
+            if "deconv" in name or "logit_fn" in name:
+                continue
+            sp[name] = ("xavier",) if name.endswith("weight") else ("zeros",)
+        return sp
     for name, _ in spec:
         if name.startswith("decode.") and c.kind == "mnist":
             sp[name] = ("xavier",) if name.endswith("weight") else ("zeros",)
@@ -232,6 +250,13 @@ def encode(c: ModelCfg, p, x, noise, nz):
         inp = mlp(p, "encode.inp_encode.", 2 * x - 1, c.n_layers + 1, c.nonlin, True)
         hin = torch.cat([expand_rows(inp, nz), noise], 1)
         z = mlp(p, "encode.fc.", hin, 1, c.nonlin, False)
+    elif c.kind == "conv":
+        f = act(c.nonlin)
+        h = (2 * x - 1).view(B, 1, 28, 28)
+        for i in (1, 2, 3):
+            h = f(F.conv2d(h, p[f"encode.conv{i}.weight"], p[f"encode.conv{i}.bias"], stride=2, padding=2))
+        hin = torch.cat([expand_rows(h.reshape(B, -1), nz), noise], 1)
+        z = F.linear(f(F.linear(hin, p["encode.fc4.weight"], p["encode.fc4.bias"])), p["encode.fc5.weight"], p["encode.fc5.bias"])
     elif c.kind == "toy":
         inp = mlp(p, "encode.inp_encode.", x, c.n_layers - 1, c.nonlin, True)
         z = ctxcat_mlp(p, "encode.fc.", expand_rows(inp, nz), noise, c.n_layers, c.nonlin)
@@ -245,6 +270,13 @@ def decode(c: ModelCfg, p, z):
     if c.kind == "mnist":
         h = mlp(p, "decode.main.", z, c.n_layers, c.nonlin, True)
         return (F.linear(h, p["decode.reparam.logit_fn.weight"], p["decode.reparam.logit_fn.bias"]),)
+    if c.kind == "conv":
+        f = act(c.nonlin)
+        h = mlp(p, "decode.fc.", z, 1, c.nonlin, True).view(-1, 32, 4, 4)
+        h = F.pad(f(F.conv_transpose2d(h, p["decode.deconv1.weight"], p["decode.deconv1.bias"], stride=2, padding=2)), (0, 1, 0, 1))
+        h = f(F.conv_transpose2d(h, p["decode.deconv2.weight"], p["decode.deconv2.bias"], stride=2, padding=2))
+        logit = F.conv_transpose2d(h, p["decode.reparam.logit_fn.weight"], p["decode.reparam.logit_fn.bias"], stride=2, padding=2)
+        return (logit[:, :, :28, :28].reshape(z.size(0), 784),)
     h = mlp(p, "decode.main.", z, c.n_layers - 1, c.nonlin, True)
     mu = F.linear(h, p["decode.reparam.mean_fn.weight"], p["decode.reparam.mean_fn.bias"])
     logvar = F.linear(h, p["decode.reparam.logvar_fn.weight"], p["decode.reparam.logvar_fn.bias"])
@@ -252,7 +284,7 @@ def decode(c: ModelCfg, p, z):
 
 
 def recon_rows(c: ModelCfg, dist, target):
-    if c.kind == "mnist":
+    if c.kind in ("mnist", "conv"):
         (logit,) = dist
         return F.binary_cross_entropy_with_logits(logit, target, reduction="none").sum(1)
     mu, logvar = dist

@@ -58,7 +58,9 @@ def import_reference():
 
 
 def build_reference(net, mc, cc, pm, pc, dtype):
-    if mc.kind == "mnist":
+    if mc.kind == "conv":
+        model = net.ConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, noise_dim=mc.noise_dim, nonlinearity=mc.nonlin)
+    elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
                                num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
     else:
@@ -141,7 +143,7 @@ def rel_l2(a, b):
 
 def synth_x(mc, B, seed):
     g = torch.Generator().manual_seed(seed)
-    if mc.kind == "mnist":
+    if mc.kind in ("mnist", "conv"):
         p = (torch.rand(mc.input_dim, generator=g) < 0.2).float() * 0.6 + 0.03
         return torch.bernoulli(p.expand(B, -1), generator=g)
     mu = (torch.randint(0, 5, (B, mc.input_dim), generator=g).float() - 2) * 2
@@ -281,6 +283,10 @@ def main():
     cfg1_m = O.ModelCfg("toy", 2, 10, 256, 2, 2, "relu")
     cfg1_c = O.CdaeCfg("grad", 2, 2, 256, 3)
     run_case(net, rutils, "cfg1_b8_nz16", cfg1_m, cfg1_c, O.TrainCfg(nz_cdae=16), B=8, steps=2, dtype=f32, store_full=False)
+    # BASELINE config #4 model (ConvIPVAE) with a small cDAE; the conv trunk / transposed-conv decoder are fixed-size
+    conv_m = O.ModelCfg("conv", 784, 100, 800, 32, 1, "softplus")
+    conv_c = O.CdaeCfg("grad", 32, 32, 64, 2)
+    run_case(net, rutils, "conv_b4_nz8", conv_m, conv_c, O.TrainCfg(nz_cdae=8), B=4, steps=2, dtype=f32, store_full=False)
     run_iwae_case(net, "iwae_tiny", tiny_m, B=3, k=16, dtype=f64)
 
 

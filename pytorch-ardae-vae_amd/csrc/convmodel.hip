@@ -1,0 +1,433 @@
+// ConvIPVAE (models/ivae/conv.py:44-245 + models/vae/conv.py:79-136; `--model mnist-conv`, BASELINE config #4) on gfx950.
+//
+// The reference hard-wires the architecture (28x28x1 input; conv 1->16->32->32, k5 s2 p2: 28->14->7->4; fc4 (512+noise)->800,
+// fc5 800->z; decoder MLP z->300->512, ConvTranspose2d 32->32 (4->7, zero-padded to 8), 32->16 (8->15), 16->1 (15->29,
+// cropped to 28)), so this file does too.  Every (transposed) convolution is im2col / col2im (two small gather kernels,
+// NHWC activations as [rows = b*H*W, C]) around the FP32-MFMA linear and wgrad kernels; the conv trunk runs on B rows only,
+// fc4's image half enters as a per-image row bias exactly like the MLP sampler (csrc/model.hip).
+#include <vector>
+
+#include "ardae_hip.h"
+#include "common.h"
+#include "convmodel.h"
+#include "elementwise.h"
+#include "linear.h"
+#include "wgrad.h"
+
+namespace ardae {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ data-movement kernels
+// cols[(b*OH+oh)*OW+ow][c*25+kh*5+kw] = x[b][2oh-2+kh][2ow-2+kw][c]  (0 outside H x W); x is NHWC [B,H,W,C]
+__global__ void im2col_s2_kernel(const float* __restrict__ x, int H, int W, int C, int OH, int OW, float* __restrict__ cols, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int J = C * 25;
+  const int j = (int)(e % J);
+  const int64_t row = e / J;
+  const int ow = (int)(row % OW), oh = (int)((row / OW) % OH);
+  const int64_t b = row / ((int64_t)OW * OH);
+  const int c = j / 25, kk = j - c * 25, kh = kk / 5, kw = kk - kh * 5;
+  const int h = 2 * oh - 2 + kh, w = 2 * ow - 2 + kw;
+  cols[e] = (h >= 0 && h < H && w >= 0 && w < W) ? x[((b * H + h) * W + w) * C + c] : 0.f;
+}
+
+// out[b][oh][ow][o] = f( bias[o] + sum_{kh,kw} cols[(b*IH+ih)*IW+iw][o*25+kh*5+kw] ),  ih = (oh+2-kh)/2 exact and in range;
+// positions with oh >= VH or ow >= VW are written as 0 (the reference's ZeroPad2d after the activation).  `mulS`: multiply
+// by act'(S) instead of applying an activation (backward-data of a convolution followed by the previous layer's act').
+__global__ void col2im_s2_kernel(const float* __restrict__ cols, int IH, int IW, int O, int OH, int OW, int VH, int VW,
+                                 const float* __restrict__ bias, int act, const float* __restrict__ mulS, float* __restrict__ out,
+                                 int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int o = (int)(e % O);
+  const int64_t pix = e / O;
+  const int ow = (int)(pix % OW), oh = (int)((pix / OW) % OH);
+  const int64_t b = pix / ((int64_t)OW * OH);
+  float v = 0.f;
+  if (oh < VH && ow < VW) {
+    v = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+      const int th = oh + 2 - kh;
+      if (th < 0 || (th & 1)) continue;
+      const int ih = th >> 1;
+      if (ih >= IH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int tw = ow + 2 - kw;
+        if (tw < 0 || (tw & 1)) continue;
+        const int iw = tw >> 1;
+        if (iw >= IW) continue;
+        v += cols[((b * IH + ih) * IW + iw) * (int64_t)(O * 25) + o * 25 + kh * 5 + kw];
+      }
+    }
+    if (mulS) v *= act_d1_rt(act, mulS[e]);
+    else v = act_fwd_rt(act, v);
+  }
+  out[e] = v;
+}
+
+// [B, HW, C] (NHWC rows) <-> [B, C*HW] (PyTorch's .view(B,-1) of NCHW)
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int HW, int C, float* __restrict__ out, int64_t total, int reverse) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const int hw = (int)((e / C) % HW);
+  const int64_t b = e / ((int64_t)C * HW);
+  const int64_t nchw = (b * C + c) * HW + hw;
+  if (reverse) out[e] = in[nchw]; else out[nchw] = in[e];
+}
+
+__global__ void mul_dact_kernel(const float* __restrict__ x, const float* __restrict__ S, int act, float* __restrict__ y, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) y[e] = x[e] * act_d1_rt(act, S[e]);
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] = v;
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// ------------------------------------------------------------------------------------------------ layout
+struct Lin { size_t w, b; int out, in; };   // weight viewed as [out, in] (convs: [O, C*25]; deconvs: [in_ch, out_ch*25])
+
+struct ConvLayout {
+  int nd, zd, act;
+  Lin conv[3], fc4, fc5, dfc[2], dcv[3];
+  size_t total;
+  explicit ConvLayout(const ardae_model_desc& d) : nd(d.noise_dim), zd(d.z_dim), act(d.act) {
+    size_t off = 0;
+    auto add = [&](Lin& l, int out, int in, int nbias) { l.out = out; l.in = in; l.w = off; off += (size_t)out * in; l.b = off; off += nbias; };
+    add(conv[0], 16, 1 * 25, 16); add(conv[1], 32, 16 * 25, 32); add(conv[2], 32, 32 * 25, 32);
+    add(fc4, 800, 512 + nd, 800); add(fc5, zd, 800, zd);
+    add(dfc[0], 300, zd, 300); add(dfc[1], 512, 300, 512);
+    add(dcv[0], 32, 32 * 25, 32); add(dcv[1], 32, 16 * 25, 16); add(dcv[2], 16, 1 * 25, 1);
+    total = off;
+  }
+};
+
+size_t al64(size_t n) { return (n + 63) & ~size_t(63); }
+
+struct ConvPacked {
+  size_t conv_f[3], conv_b[3], fc4i_f, fc4i_b, fc4n_f, fc5_f, fc5_b, dfc_f[2], dfc_b[2], dcv_f[3], dcv_b[3], total;
+  explicit ConvPacked(const ConvLayout& P) {
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += al64(n); return o; };
+    for (int i = 0; i < 3; ++i) { conv_f[i] = take(packed_floats(P.conv[i].out, P.conv[i].in)); conv_b[i] = take(packed_floats(P.conv[i].in, P.conv[i].out)); }
+    fc4i_f = take(packed_floats(800, 512)); fc4i_b = take(packed_floats(512, 800)); fc4n_f = take(packed_floats(800, P.nd));
+    fc5_f = take(packed_floats(P.zd, 800)); fc5_b = take(packed_floats(800, P.zd));
+    for (int i = 0; i < 2; ++i) { dfc_f[i] = take(packed_floats(P.dfc[i].out, P.dfc[i].in)); dfc_b[i] = take(packed_floats(P.dfc[i].in, P.dfc[i].out)); }
+    for (int i = 0; i < 3; ++i) { dcv_f[i] = take(packed_floats(P.dcv[i].in, P.dcv[i].out)); dcv_b[i] = take(packed_floats(P.dcv[i].out, P.dcv[i].in)); }
+    total = off;
+  }
+};
+
+struct Bump {
+  float* base; size_t cap; size_t off = 0; bool ok = true;
+  Bump(float* b, size_t c) : base(b), cap(c) {}
+  float* take(size_t n) { size_t o = off; off += al64(n); if (off > cap) { ok = false; return base; } return base + o; }
+};
+
+// spatial sizes: encoder 28 -> 14 -> 7 -> 4; decoder grids 4 -> 8 (7 valid) -> 15 -> 28 (of 29)
+struct ConvWs {
+  // encoder (B rows)
+  float *x2, *cols[3], *hcv[3], *inp, *rb, *t1, *z;
+  // decoder (R rows)
+  float *d1, *d2, *g0, *c1, *u1, *c2, *u2, *c3, *logit, *rec_row, *pri_row;
+  // backward
+  float *dlogit, *dc3, *dp2, *dc2, *dp1, *dc1, *dg0, *dd2, *dd1, *dzq, *dz, *dt1, *drb, *dinp, *dinp_t, *dh3, *dcols3, *dh2, *dcols2, *dh1, *ones;
+};
+
+constexpr int EH[4] = {28, 14, 7, 4};      // encoder spatial sizes
+constexpr int ECH[4] = {1, 16, 32, 32};    // encoder channels
+
+void carve(const ConvLayout& P, Bump& ws, int B, int nz, int mode, ConvWs& W) {
+  const size_t R = (size_t)B * nz;
+  W.x2 = ws.take((size_t)B * 784);
+  for (int i = 0; i < 3; ++i) {
+    W.cols[i] = ws.take((size_t)B * EH[i + 1] * EH[i + 1] * ECH[i] * 25);
+    W.hcv[i] = ws.take((size_t)B * EH[i + 1] * EH[i + 1] * ECH[i + 1]);
+  }
+  W.inp = ws.take((size_t)B * 512); W.rb = ws.take((size_t)B * 800);
+  W.t1 = ws.take(R * 800); W.z = ws.take(R * P.zd);
+  if (mode == 0) return;
+  W.d1 = ws.take(R * 300); W.d2 = ws.take(R * 512); W.g0 = ws.take(R * 512);
+  W.c1 = ws.take(R * 16 * 800); W.u1 = ws.take(R * 64 * 32);
+  W.c2 = ws.take(R * 64 * 400); W.u2 = ws.take(R * 225 * 16);
+  W.c3 = ws.take(R * 225 * 25); W.logit = ws.take(R * 784);
+  W.rec_row = ws.take(R); W.pri_row = ws.take(R);
+  if (mode == 2) return;
+  W.dlogit = ws.take(R * 784); W.dc3 = ws.take(R * 225 * 25); W.dp2 = ws.take(R * 225 * 16);
+  W.dc2 = ws.take(R * 64 * 400); W.dp1 = ws.take(R * 64 * 32); W.dc1 = ws.take(R * 16 * 800);
+  W.dg0 = ws.take(R * 512); W.dd2 = ws.take(R * 512); W.dd1 = ws.take(R * 300);
+  W.dzq = ws.take(R * P.zd); W.dz = ws.take(R * P.zd); W.dt1 = ws.take(R * 800);
+  W.drb = ws.take((size_t)B * 800); W.dinp = ws.take((size_t)B * 512); W.dinp_t = ws.take((size_t)B * 512);
+  W.dh3 = ws.take((size_t)B * 512); W.dcols3 = ws.take((size_t)B * 16 * 800); W.dh2 = ws.take((size_t)B * 49 * 32);
+  W.dcols2 = ws.take((size_t)B * 49 * 400); W.dh1 = ws.take((size_t)B * 196 * 16);
+  W.ones = ws.take(R * 784);
+}
+
+constexpr int N_WGRAD = 18;   // problems of one backward (see conv_vae_backward)
+
+size_t wgrad_scratch(const ConvLayout& P, int B, int R, std::vector<int>* out) {
+  std::vector<int> sp; size_t tot = 0;
+  auto one = [&](int M, int O, int I) { const int s = wgrad_splits(M, O, I, N_WGRAD); sp.push_back(s); tot += al64((size_t)s * O * I) + al64((size_t)s * 2 * O); };
+  one(R * 225, 16, 25); one(R * 784, 1, 1);          // deconv3 weight, bias
+  one(R * 64, 32, 400); one(R * 225, 16, 1);         // deconv2
+  one(R * 16, 32, 800); one(R * 64, 32, 1);          // deconv1
+  one(R, 512, 300); one(R, 300, P.zd);               // decoder fc
+  one(R, P.zd, 800); one(R, 800, P.nd); one(B, 800, 512);   // fc5, fc4 noise half (+bias), fc4 image half
+  one(B * 16, 32, 800); one(B * 49, 32, 400); one(B * 196, 16, 25);   // conv3, conv2, conv1
+  if (out) *out = sp;
+  return tot;
+}
+
+size_t conv_workspace(const ConvLayout& P, int B, int nz, int mode) {
+  // run the carve on a null arena to count
+  Bump b(nullptr, ~size_t(0));
+  ConvWs W;
+  carve(P, b, B, nz, mode, W);
+  size_t t = b.off + al64((size_t)B * nz * P.nd);    // + zero-noise buffer for encode(std=0)
+  if (mode == 1) t += wgrad_scratch(P, B, B * nz, nullptr);
+  return t;
+}
+
+int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
+  a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
+  a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;
+  return launch_linear(a, epi, st);
+}
+
+int im2col(const float* x, int Bn, int H, int Wd, int C, int OH, int OW, float* cols, hipStream_t st) {
+  const int64_t total = (int64_t)Bn * OH * OW * C * 25;
+  hipLaunchKernelGGL(im2col_s2_kernel, dim3(nblk(total)), dim3(256), 0, st, x, H, Wd, C, OH, OW, cols, total);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+int col2im(const float* cols, int Bn, int IH, int IW, int O, int OH, int OW, int VH, int VW, const float* bias, int act, const float* mulS,
+           float* out, hipStream_t st) {
+  const int64_t total = (int64_t)Bn * OH * OW * O;
+  hipLaunchKernelGGL(col2im_s2_kernel, dim3(nblk(total)), dim3(256), 0, st, cols, IH, IW, O, OH, OW, VH, VW, bias, act, mulS, out, total);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+int transpose_hw_c(const float* in, int Bn, int HW, int C, float* out, bool to_nchw, hipStream_t st) {
+  const int64_t total = (int64_t)Bn * HW * C;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk(total)), dim3(256), 0, st, in, HW, C, out, total, to_nchw ? 0 : 1);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int conv_encode_fwd(const ConvLayout& P, const ConvPacked& K, const float* params, const float* packed, const float* x, const float* noise,
+                    int B, int nz, ConvWs& W, float* z_out, hipStream_t st) {
+  const int R = B * nz, act = P.act;
+  ARDAE_TRY(launch_affine(x, (int64_t)B * 784, 2.f, -1.f, W.x2, st));           // ivae/conv.py:81
+  const float* cur = W.x2;
+  for (int i = 0; i < 3; ++i) {                                                 // conv_i = im2col + Linear([O, C*25]) + act
+    const int OH = EH[i + 1], Kc = ECH[i] * 25;
+    ARDAE_TRY(im2col(cur, B, EH[i], EH[i], ECH[i], OH, OH, W.cols[i], st));
+    LinArgs A{}; A.bias = params + P.conv[i].b; A.Y = W.hcv[i]; A.ldY = ECH[i + 1];
+    ARDAE_TRY(lin1(EPI_ACT, act, B * OH * OH, ECH[i + 1], W.cols[i], Kc, Kc, packed + K.conv_f[i], A, st));
+    cur = W.hcv[i];
+  }
+  ARDAE_TRY(transpose_hw_c(W.hcv[2], B, 16, 32, W.inp, true, st));              // h3.view(B,-1) of NCHW
+  {
+    LinArgs A{}; A.bias = params + P.fc4.b; A.Y = W.rb; A.ldY = 800;            // image half of fc4, once per image
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 800, W.inp, 512, 512, packed + K.fc4i_f, A, st));
+  }
+  {
+    LinArgs A{}; A.rowbias = W.rb; A.rowbias_ld = 800; A.rows_per_group = nz; A.Y = W.t1; A.ldY = 800;
+    ARDAE_TRY(lin1(EPI_ACT, act, R, 800, noise, P.nd, P.nd, packed + K.fc4n_f, A, st));
+  }
+  {
+    LinArgs A{}; A.bias = params + P.fc5.b; A.Y = W.z; A.ldY = P.zd;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.t1, 800, 800, packed + K.fc5_f, A, st));
+  }
+  if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int conv_decode_fwd(const ConvLayout& P, const ConvPacked& K, const float* params, const float* packed, const float* z, int R, ConvWs& W,
+                    hipStream_t st) {
+  const int act = P.act;
+  { LinArgs A{}; A.bias = params + P.dfc[0].b; A.Y = W.d1; A.ldY = 300; ARDAE_TRY(lin1(EPI_ACT, act, R, 300, z, P.zd, P.zd, packed + K.dfc_f[0], A, st)); }
+  { LinArgs A{}; A.bias = params + P.dfc[1].b; A.Y = W.d2; A.ldY = 512; ARDAE_TRY(lin1(EPI_ACT, act, R, 512, W.d1, 300, 300, packed + K.dfc_f[1], A, st)); }
+  ARDAE_TRY(transpose_hw_c(W.d2, R, 16, 32, W.g0, false, st));                  // h1.view(R,32,4,4) -> NHWC rows
+  // deconv1 32->32: 4x4 -> 7x7, activation, zero-pad to 8x8
+  { LinArgs A{}; A.Y = W.c1; A.ldY = 800; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R * 16, 800, W.g0, 32, 32, packed + K.dcv_f[0], A, st)); }
+  ARDAE_TRY(col2im(W.c1, R, 4, 4, 32, 8, 8, 7, 7, params + P.dcv[0].b, act, nullptr, W.u1, st));
+  // deconv2 32->16: 8x8 -> 15x15, activation
+  { LinArgs A{}; A.Y = W.c2; A.ldY = 400; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R * 64, 400, W.u1, 32, 32, packed + K.dcv_f[1], A, st)); }
+  ARDAE_TRY(col2im(W.c2, R, 8, 8, 16, 15, 15, 15, 15, params + P.dcv[1].b, act, nullptr, W.u2, st));
+  // logit deconv 16->1: 15x15 -> 29x29, cropped to 28x28
+  { LinArgs A{}; A.Y = W.c3; A.ldY = 25; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R * 225, 25, W.u2, 16, 16, packed + K.dcv_f[2], A, st)); }
+  ARDAE_TRY(col2im(W.c3, R, 15, 15, 1, 28, 28, 28, 28, params + P.dcv[2].b, ACT_NONE, nullptr, W.logit, st));
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ entry points (kind == 2)
+size_t conv_model_param_floats(const ardae_model_desc& d) { return ConvLayout(d).total; }
+size_t conv_model_packed_floats(const ardae_model_desc& d) { return ConvPacked(ConvLayout(d)).total; }
+size_t conv_model_workspace_floats(const ardae_model_desc& d, int B, int nz, int mode) { return conv_workspace(ConvLayout(d), B, nz, mode); }
+
+int conv_model_pack(const ardae_model_desc& d, const float* params, float* packed, hipStream_t st) {
+  const ConvLayout P(d);
+  const ConvPacked K(P);
+  for (int i = 0; i < 3; ++i) {
+    ARDAE_TRY(launch_pack_weight(params + P.conv[i].w, P.conv[i].in, P.conv[i].out, P.conv[i].in, false, packed + K.conv_f[i], st));
+    ARDAE_TRY(launch_pack_weight(params + P.conv[i].w, P.conv[i].in, P.conv[i].in, P.conv[i].out, true, packed + K.conv_b[i], st));
+  }
+  const int ld4 = 512 + P.nd;
+  ARDAE_TRY(launch_pack_weight(params + P.fc4.w, ld4, 800, 512, false, packed + K.fc4i_f, st));
+  ARDAE_TRY(launch_pack_weight(params + P.fc4.w, ld4, 512, 800, true, packed + K.fc4i_b, st));
+  ARDAE_TRY(launch_pack_weight(params + P.fc4.w + 512, ld4, 800, P.nd, false, packed + K.fc4n_f, st));
+  ARDAE_TRY(launch_pack_weight(params + P.fc5.w, 800, P.zd, 800, false, packed + K.fc5_f, st));
+  ARDAE_TRY(launch_pack_weight(params + P.fc5.w, 800, 800, P.zd, true, packed + K.fc5_b, st));
+  for (int i = 0; i < 2; ++i) {
+    ARDAE_TRY(launch_pack_weight(params + P.dfc[i].w, P.dfc[i].in, P.dfc[i].out, P.dfc[i].in, false, packed + K.dfc_f[i], st));
+    ARDAE_TRY(launch_pack_weight(params + P.dfc[i].w, P.dfc[i].in, P.dfc[i].in, P.dfc[i].out, true, packed + K.dfc_b[i], st));
+  }
+  for (int i = 0; i < 3; ++i) {   // ConvTranspose2d weight [in, out*25]: forward = X . W (transposed pack), backward-data = dC . W^T (natural)
+    ARDAE_TRY(launch_pack_weight(params + P.dcv[i].w, P.dcv[i].in, P.dcv[i].in, P.dcv[i].out, true, packed + K.dcv_f[i], st));
+    ARDAE_TRY(launch_pack_weight(params + P.dcv[i].w, P.dcv[i].in, P.dcv[i].out, P.dcv[i].in, false, packed + K.dcv_b[i], st));
+  }
+  return 0;
+}
+
+static const float* zero_noise(Bump& ws, const ConvLayout& P, int B, int nz, hipStream_t st) {
+  float* zero = ws.take((size_t)B * nz * P.nd);
+  (void)hipMemsetAsync(zero, 0, (size_t)B * nz * P.nd * sizeof(float), st);
+  return zero;
+}
+
+int conv_model_encode(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B,
+                      int nz, float* workspace, size_t wsf, float* z_out, hipStream_t st) {
+  const ConvLayout P(d);
+  const ConvPacked K(P);
+  Bump ws(workspace, wsf);
+  ConvWs W;
+  carve(P, ws, B, nz, 0, W);
+  const float* nptr = noise ? noise : zero_noise(ws, P, B, nz, st);
+  ARDAE_CHECK_ARG(ws.ok, "conv_model_encode: workspace too small");
+  return conv_encode_fwd(P, K, params, packed, x, nptr, B, nz, W, z_out, st);
+}
+
+int conv_model_decode(const ardae_model_desc& d, const float* params, const float* packed, const float* z, int R, float* workspace,
+                      size_t wsf, float* out0, hipStream_t st) {
+  const ConvLayout P(d);
+  const ConvPacked K(P);
+  Bump ws(workspace, wsf);
+  ConvWs W;
+  carve(P, ws, R, 1, 2, W);
+  ARDAE_CHECK_ARG(ws.ok, "conv_model_decode: workspace too small");
+  ARDAE_TRY(conv_decode_fwd(P, K, params, packed, z, R, W, st));
+  ARDAE_HIP(hipMemcpyAsync(out0, W.logit, (size_t)R * 784 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int conv_model_vae_forward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B,
+                           int nz, float beta, float* workspace, size_t wsf, float* z_out, float* losses, hipStream_t st) {
+  const ConvLayout P(d);
+  const ConvPacked K(P);
+  Bump ws(workspace, wsf);
+  ConvWs W;
+  carve(P, ws, B, nz, 1, W);
+  ARDAE_CHECK_ARG(ws.ok, "conv_model_vae_forward: workspace too small");
+  const int R = B * nz;
+  ARDAE_TRY(conv_encode_fwd(P, K, params, packed, x, noise, B, nz, W, z_out, st));
+  ARDAE_TRY(conv_decode_fwd(P, K, params, packed, W.z, R, W, st));
+  ARDAE_TRY(launch_vae_loss(0, W.logit, nullptr, x, W.z, R, nz, 784, P.zd, beta, 0, 0.f, nullptr, W.rec_row, W.pri_row, nullptr, nullptr, nullptr, st));
+  return launch_vae_loss_finalize(W.rec_row, W.pri_row, R, beta, losses, st);
+}
+
+int conv_model_vae_backward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B,
+                            int nz, float beta, float dloss, const float* dz_extra, float* workspace, size_t wsf, float* grads,
+                            float grads_beta, hipStream_t st) {
+  const ConvLayout P(d);
+  const ConvPacked K(P);
+  Bump ws(workspace, wsf);
+  ConvWs W;
+  carve(P, ws, B, nz, 1, W);
+  const int R = B * nz, act = P.act;
+  const float gscale = dloss / (float)R;
+  ARDAE_TRY(launch_vae_loss(0, W.logit, nullptr, x, W.z, R, nz, 784, P.zd, beta, 1, gscale, dz_extra, W.rec_row, W.pri_row, W.dlogit, nullptr,
+                            W.dzq, st));
+  {
+    const int64_t n = (int64_t)R * 784;
+    hipLaunchKernelGGL(fill_kernel, dim3(nblk(n)), dim3(256), 0, st, W.ones, 1.0f, n);
+    ARDAE_LAUNCH_CHECK();
+  }
+  // ---- decoder backward.  d(cols) of a transposed conv = im2col of the output gradient over the deconv's INPUT grid.
+  ARDAE_TRY(im2col(W.dlogit, R, 28, 28, 1, 15, 15, W.dc3, st));                 // cropped row/col 28 has no gradient
+  { LinArgs A{}; A.S = W.u2; A.ldS = 16; A.Y = W.dp2; A.ldY = 16;               // dpre2 = (dc3 . W3^T) (.) act'(u2)
+    ARDAE_TRY(lin1(EPI_DACT, act, R * 225, 16, W.dc3, 25, 25, packed + K.dcv_b[2], A, st)); }
+  ARDAE_TRY(im2col(W.dp2, R, 15, 15, 16, 8, 8, W.dc2, st));
+  { LinArgs A{}; A.S = W.u1; A.ldS = 32; A.Y = W.dp1; A.ldY = 32;               // zero at the padded positions: act'(0) = 0
+    ARDAE_TRY(lin1(EPI_DACT, act, R * 64, 32, W.dc2, 400, 400, packed + K.dcv_b[1], A, st)); }
+  ARDAE_TRY(im2col(W.dp1, R, 8, 8, 32, 4, 4, W.dc1, st));
+  { LinArgs A{}; A.S = W.g0; A.ldS = 32; A.Y = W.dg0; A.ldY = 32;               // g0 is the (permuted) activated output of decode.fc
+    ARDAE_TRY(lin1(EPI_DACT, act, R * 16, 32, W.dc1, 800, 800, packed + K.dcv_b[0], A, st)); }
+  ARDAE_TRY(transpose_hw_c(W.dg0, R, 16, 32, W.dd2, true, st));                 // -> d(pre) of decode.fc.fc  [R,512]
+  { LinArgs A{}; A.S = W.d1; A.ldS = 300; A.Y = W.dd1; A.ldY = 300;
+    ARDAE_TRY(lin1(EPI_DACT, act, R, 300, W.dd2, 512, 512, packed + K.dfc_b[1], A, st)); }
+  { LinArgs A{}; A.S = W.dzq; A.ldS = P.zd; A.Q = W.dzq; A.ldQ = P.zd; A.Y = W.dz; A.ldY = P.zd;   // + prior + injected seed
+    ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, R, P.zd, W.dd1, 300, 300, packed + K.dfc_b[0], A, st)); }
+  // ---- sampler backward
+  { LinArgs A{}; A.S = W.t1; A.ldS = 800; A.Y = W.dt1; A.ldY = 800;
+    ARDAE_TRY(lin1(EPI_DACT, act, R, 800, W.dz, P.zd, P.zd, packed + K.fc5_b, A, st)); }
+  ARDAE_TRY(launch_segment_sum(W.dt1, 800, B, nz, 800, 1.0f, W.drb, 800, st));
+  { LinArgs A{}; A.Y = W.dinp; A.ldY = 512;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 512, W.drb, 800, 800, packed + K.fc4i_b, A, st)); }
+  ARDAE_TRY(transpose_hw_c(W.dinp, B, 16, 32, W.dinp_t, false, st));           // NCHW-flat -> NHWC rows
+  {
+    const int64_t n = (int64_t)B * 512;
+    hipLaunchKernelGGL(mul_dact_kernel, dim3(nblk(n)), dim3(256), 0, st, W.dinp_t, W.hcv[2], act, W.dh3, n);
+    ARDAE_LAUNCH_CHECK();
+  }
+  { LinArgs A{}; A.Y = W.dcols3; A.ldY = 800;                                   // conv3 backward-data: dcols = dpre . W3
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B * 16, 800, W.dh3, 32, 32, packed + K.conv_b[2], A, st)); }
+  ARDAE_TRY(col2im(W.dcols3, B, 4, 4, 32, 7, 7, 7, 7, nullptr, act, W.hcv[1], W.dh2, st));
+  { LinArgs A{}; A.Y = W.dcols2; A.ldY = 400;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B * 49, 400, W.dh2, 32, 32, packed + K.conv_b[1], A, st)); }
+  ARDAE_TRY(col2im(W.dcols2, B, 7, 7, 16, 14, 14, 14, 14, nullptr, act, W.hcv[0], W.dh1, st));
+  // ---- weight gradients (order must match wgrad_scratch)
+  std::vector<int> splits;
+  wgrad_scratch(P, B, R, &splits);
+  std::vector<WgradProblem> probs;
+  auto push = [&](int M, int O, int I, const float* G, const float* X, float* out, int ldout, float* out_bias) {
+    WgradProblem p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.O = O; p.I = I; p.npairs = 1;
+    p.G[0] = G; p.ldG[0] = O; p.X[0] = X; p.ldX[0] = I;
+    p.bias_pair = out_bias ? 0 : -1;
+    p.splits = splits[probs.size()];
+    p.partial = ws.take((size_t)p.splits * O * I);
+    p.partial_vec = ws.take((size_t)p.splits * 2 * O);
+    p.out = out; p.ldout = ldout; p.out_bias = out_bias; p.beta = grads_beta;
+    probs.push_back(p);
+  };
+  // ConvTranspose2d: dW[in][out*25] = sum_rows input[row][in] * dcols[row][out*25]; its bias = sum of the output gradient
+  push(R * 225, 16, 25, W.u2, W.dc3, grads + P.dcv[2].w, 25, nullptr);
+  push(R * 784, 1, 1, W.dlogit, W.ones, grads + P.dcv[2].b, 1, nullptr);
+  push(R * 64, 32, 400, W.u1, W.dc2, grads + P.dcv[1].w, 400, nullptr);
+  push(R * 225, 16, 1, W.dp2, W.ones, grads + P.dcv[1].b, 1, nullptr);
+  push(R * 16, 32, 800, W.g0, W.dc1, grads + P.dcv[0].w, 800, nullptr);
+  push(R * 64, 32, 1, W.dp1, W.ones, grads + P.dcv[0].b, 1, nullptr);
+  push(R, 512, 300, W.dd2, W.d1, grads + P.dfc[1].w, 300, grads + P.dfc[1].b);
+  push(R, 300, P.zd, W.dd1, W.z, grads + P.dfc[0].w, P.zd, grads + P.dfc[0].b);
+  push(R, P.zd, 800, W.dz, W.t1, grads + P.fc5.w, 800, grads + P.fc5.b);
+  push(R, 800, P.nd, W.dt1, noise, grads + P.fc4.w + 512, 512 + P.nd, grads + P.fc4.b);
+  push(B, 800, 512, W.drb, W.inp, grads + P.fc4.w, 512 + P.nd, nullptr);
+  push(B * 16, 32, 800, W.dh3, W.cols[2], grads + P.conv[2].w, 800, grads + P.conv[2].b);
+  push(B * 49, 32, 400, W.dh2, W.cols[1], grads + P.conv[1].w, 400, grads + P.conv[1].b);
+  push(B * 196, 16, 25, W.dh1, W.cols[0], grads + P.conv[0].w, 25, grads + P.conv[0].b);
+  ARDAE_CHECK_ARG(ws.ok, "conv_model_vae_backward: workspace too small");
+  return launch_wgrad_batch(probs.data(), (int)probs.size(), st);
+}
+
+}  // namespace ardae

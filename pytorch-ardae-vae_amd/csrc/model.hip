@@ -12,6 +12,7 @@
 
 #include "ardae_hip.h"
 #include "common.h"
+#include "convmodel.h"
 #include "elementwise.h"
 #include "linear.h"
 #include "wgrad.h"
@@ -83,7 +84,12 @@ struct Bump {
 
 int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d != nullptr, "model: desc is NULL");
-  ARDAE_CHECK_ARG(d->kind == 0 || d->kind == 1, "model: kind must be 0 (MNISTIPVAE) or 1 (ToyIPVAE concat)");
+  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 2, "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat) or 2 (ConvIPVAE)");
+  if (d->kind == 2) {
+    ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1, "model: ConvIPVAE is hard-wired to 28x28x1 inputs (input_dim 784)");
+    ARDAE_CHECK_ARG(d->act == ACT_SOFTPLUS || d->act == ACT_RELU, "model: activation must be softplus or relu");
+    return 0;
+  }
   ARDAE_CHECK_ARG(d->input_dim >= 1 && d->noise_dim >= 1 && d->h_dim >= 1 && d->z_dim >= 1 && d->n_layers >= 1 && d->n_layers <= 4,
                   "model: bad dimensions");
   ARDAE_CHECK_ARG(d->act == ACT_SOFTPLUS || d->act == ACT_RELU, "model: activation must be softplus or relu");
@@ -215,10 +221,17 @@ using namespace ardae;
 
 extern "C" {
 
-size_t ardae_model_param_floats(const ardae_model_desc* d) { return desc_ok(d) ? 0 : ModelLayout(*d).total; }
-size_t ardae_model_packed_floats(const ardae_model_desc* d) { return desc_ok(d) ? 0 : ModelPacked(ModelLayout(*d)).total; }
+size_t ardae_model_param_floats(const ardae_model_desc* d) {
+  if (desc_ok(d)) return 0;
+  return d->kind == 2 ? conv_model_param_floats(*d) : ModelLayout(*d).total;
+}
+size_t ardae_model_packed_floats(const ardae_model_desc* d) {
+  if (desc_ok(d)) return 0;
+  return d->kind == 2 ? conv_model_packed_floats(*d) : ModelPacked(ModelLayout(*d)).total;
+}
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
   if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
+  if (d->kind == 2) return conv_model_workspace_floats(*d, B, nz, mode);
   const ModelLayout P(*d);
   if (mode == 2) return P.dec.size() * al64((size_t)B * nz * P.h);
   return workspace_floats(P, B, nz, mode) + (size_t)al64((size_t)B * nz * P.nd);   // + a zero-noise buffer for encode(std=0)
@@ -228,6 +241,7 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
   for (size_t l = 0; l < P.inp.size(); ++l) {
@@ -266,6 +280,7 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 0));
   ARDAE_CHECK_ARG(z_out, "model_encode: z_out is NULL");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind == 2) return conv_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
   Bump ws(workspace, workspace_floats_);
@@ -285,6 +300,10 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
                        size_t workspace_floats_, float* out0, float* out1, void* stream) {
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed && z && workspace && out0 && R > 0, "model_decode: bad arguments");
+  if (d->kind == 2) {
+    ARDAE_CHECK_ARG(workspace_floats_ >= conv_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
+    return conv_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
+  }
   const ModelLayout P(*d);
   const ModelPacked K(P);
   ARDAE_CHECK_ARG(P.kind == 0 || out1, "model_decode: the Gaussian decoder needs out1 (logvar)");
@@ -309,7 +328,7 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
 int ardae_model_loss_rows(const ardae_model_desc* d, const float* out0, const float* out1, const float* x, const float* z, int rows,
                           int nz, float* recon_row, float* prior_row, void* stream) {
   ARDAE_TRY(desc_ok(d));
-  return launch_vae_loss(d->kind, out0, out1, x, z, rows, nz, d->input_dim, d->z_dim, 1.f, 0, 0.f, nullptr, recon_row, prior_row, nullptr,
+  return launch_vae_loss(d->kind == 1 ? 1 : 0, out0, out1, x, z, rows, nz, d->input_dim, d->z_dim, 1.f, 0, 0.f, nullptr, recon_row, prior_row, nullptr,
                          nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -319,6 +338,7 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && z_out && losses, "model_vae_forward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind == 2) return conv_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
   Bump ws(workspace, workspace_floats_);
@@ -346,6 +366,8 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind == 2)
+    return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
   Bump ws(workspace, workspace_floats_);

@@ -22,6 +22,16 @@ def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers):
         s += _mlp("encode.fc.", h_dim + noise_dim, h_dim, z_dim, 1)
         s += _mlp("decode.main.", z_dim, h_dim, h_dim, n_layers)
         s += [("decode.reparam.logit_fn.weight", (input_dim, h_dim)), ("decode.reparam.logit_fn.bias", (input_dim,))]
+    elif kind == "conv":   # models/ivae/conv.py:44-136 + models/vae/conv.py:79-136 (28x28x1, fixed architecture)
+        s = [("encode.conv1.weight", (16, 1, 5, 5)), ("encode.conv1.bias", (16,)),
+             ("encode.conv2.weight", (32, 16, 5, 5)), ("encode.conv2.bias", (32,)),
+             ("encode.conv3.weight", (32, 32, 5, 5)), ("encode.conv3.bias", (32,)),
+             ("encode.fc4.weight", (800, 512 + noise_dim)), ("encode.fc4.bias", (800,)),
+             ("encode.fc5.weight", (z_dim, 800)), ("encode.fc5.bias", (z_dim,))]
+        s += _mlp("decode.fc.", z_dim, 300, 512, 1)
+        s += [("decode.deconv1.weight", (32, 32, 5, 5)), ("decode.deconv1.bias", (32,)),
+              ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
+              ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
     elif kind == "toy":
         s = _mlp("encode.inp_encode.", input_dim, h_dim, h_dim, n_layers - 1)
         s += _mlp("encode.fc.", h_dim, h_dim, z_dim, n_layers, extra_in=noise_dim)

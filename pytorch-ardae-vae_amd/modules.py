@@ -71,10 +71,8 @@ class FlatParamModule(nn.Module):
         """nn.Linear's default init (kaiming_uniform(a=sqrt 5) == U(+-1/sqrt(fan_in)) for weight and bias)."""
         with torch.no_grad():
             for name, p in self.named_parameters():
-                if name.endswith("weight"):
-                    fan_in = p.shape[1]
-                else:
-                    fan_in = dict(self._spec)[name[:-len("bias")] + "weight"][1]
+                wshape = p.shape if name.endswith("weight") else dict(self._spec)[name[:-len("bias")] + "weight"]
+                fan_in = wshape[1] * (wshape[2] * wshape[3] if len(wshape) == 4 else 1)   # torch's fan_in for (transposed) convs too
                 bound = 1.0 / math.sqrt(fan_in)
                 p.uniform_(-bound, bound)
 
@@ -261,7 +259,8 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self.input_dim, self.noise_dim, self.h_dim, self.z_dim = input_dim, noise_dim, h_dim, z_dim
         self.latent_dim = z_dim
         self.nonlinearity, self.num_hidden_layers, self.init, self.enc_type = nonlinearity, num_hidden_layers, init, enc_type
-        self._desc = L.ModelDesc(0 if self._kind == "mnist" else 1, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, L.ACT[nonlinearity])
+        self._desc = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2}[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers,
+                                 L.ACT[nonlinearity])
         self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers), {"encode": _EncodeBox})
         object.__setattr__(self.encode, "_owner_ref", weakref.ref(self))   # `model.encode(x, std=0)` (ivae_ardae.py:735)
         self.reset_parameters()
@@ -270,6 +269,13 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self._default_init()
         with torch.no_grad():
             p = dict(self.named_parameters())
+            if self._kind == "conv":                      # self.apply(weight_init): xavier-uniform on Conv2d / Linear, zero biases;
+                if self.do_xavier:                        # ConvTranspose2d keeps torch's default init (vae/auxconv.py:18-23)
+                    for name, t in p.items():
+                        if "deconv" in name or "logit_fn" in name:
+                            continue
+                        nn.init.xavier_uniform_(t) if t.dim() >= 2 else t.zero_()
+                return
             if self._kind == "mnist":                     # decode.apply(weight_init): xavier-uniform W, zero b (ivae/mnist.py:20-25,235)
                 for name, t in p.items():
                     if name.startswith("decode."):
@@ -384,6 +390,19 @@ class ImplicitPosteriorVAE(FlatParamModule):
 class MNISTIPVAE(ImplicitPosteriorVAE):
     """models/ivae/mnist.py::ImplicitPosteriorVAE (`--model mnist-concat`)."""
     _kind = "mnist"
+
+
+class ConvIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/conv.py::ImplicitPosteriorVAE (`--model mnist-conv`, BASELINE config #4).  The reference's decoder only
+    produces 28x28 outputs (cfg #5 note), so input_height=28 / input_channels=1 are required."""
+    _kind = "conv"
+
+    def __init__(self, energy_func=normal_energy_func, input_height=28, input_channels=1, z_dim=32, noise_dim=100,
+                 nonlinearity="softplus", do_xavier=True):
+        if input_height != 28 or input_channels != 1:
+            raise NotImplementedError("ConvIPVAE: the reference decoder (models/vae/conv.py:79-136) is hard-wired to 28x28x1")
+        self.input_height, self.input_channels, self.do_xavier = input_height, input_channels, do_xavier
+        super().__init__(energy_func, input_height * input_height * input_channels, noise_dim, 800, z_dim, nonlinearity, 1, "none", "concat")
 
 
 class ToyIPVAE(ImplicitPosteriorVAE):

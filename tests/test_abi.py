@@ -38,11 +38,12 @@ def test_abi_version_and_error_channel():
         L.check(lib.ardae_pack_weight(None, 0, 0, 0, 0, None, None))
 
 
-@pytest.mark.parametrize("kind,args", [("mnist", (784, 100, 256, 32, 2)), ("toy", (2, 10, 256, 2, 2)), ("mnist", (24, 10, 64, 8, 2))])
+@pytest.mark.parametrize("kind,args", [("mnist", (784, 100, 256, 32, 2)), ("toy", (2, 10, 256, 2, 2)), ("mnist", (24, 10, 64, 8, 2)),
+                                       ("conv", (784, 100, 800, 32, 1))])
 def test_model_layout_matches_c_side(kind, args):
     spec = layout.model_spec(kind, *args)
     _, total = layout.offsets(spec)
-    d = L.ModelDesc(0 if kind == "mnist" else 1, *args, 2)
+    d = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2}[kind], *args, 2)
     assert L.lib().ardae_model_param_floats(ctypes.byref(d)) == total
     assert L.lib().ardae_model_packed_floats(ctypes.byref(d)) > total
     assert L.lib().ardae_model_workspace_floats(ctypes.byref(d), 8, 16, 1) > 0
@@ -65,6 +66,7 @@ def test_survey_parameter_counts():
     assert tot(layout.model_spec("toy", 2, 10, 256, 2, 2)) == 271386
     assert tot(layout.cdae_spec("grad", 2, 2, 256, 3)) == 528129
     assert tot(layout.cdae_spec("grad", 32, 32, 512, 4)) == 2923521
+    assert tot(layout.model_spec("conv", 784, 100, 800, 32, 1)) == 757773
     assert tot(layout.cdae_spec("res", 32, 32, 1024, 6)) == 17943584
 
 

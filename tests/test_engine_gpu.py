@@ -20,13 +20,17 @@ CASES = {
     "tiny_toy_grad": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3), 8, True),
     "cfg2_b8_nz16": (O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus"), O.CdaeCfg("grad", 32, 32, 256, 3), 16, False),
     "cfg1_b8_nz16": (O.ModelCfg("toy", 2, 10, 256, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 256, 3), 16, False),
+    "conv_b4_nz8": (O.ModelCfg("conv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 32, 64, 2), 8, False),   # cfg #4 model
 }
 
 
 def build(mc, cc):
-    ctor = net.MNISTIPVAE if mc.kind == "mnist" else net.ToyIPVAE
-    model = ctor(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
-                 nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
+    if mc.kind == "conv":
+        model = net.ConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, noise_dim=mc.noise_dim, nonlinearity=mc.nonlin)
+    else:
+        ctor = net.MNISTIPVAE if mc.kind == "mnist" else net.ToyIPVAE
+        model = ctor(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
+                     nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
     cctor = net.MLPGradCARDAE if cc.kind == "grad" else net.MLPResCARDAE
     cdae = cctor(input_dim=cc.input_dim, context_dim=cc.context_dim, std=1., h_dim=cc.h_dim, num_hidden_layers=cc.n_layers,
                  nonlinearity=cc.nonlin, noise_type="gaussian", enc_ctx=True, enc_input=True)
@@ -198,6 +202,32 @@ def test_module_surface_drop_in_loop(golden_dir):
         cdae(latent_sub_mean.view(-1, mc.z_dim), context)                      # graddae/mlp.py:402
     with pytest.raises(NotImplementedError):
         model(xv, lmbd=1.0)                                                     # ivae/mnist.py:288-290
+
+
+def test_conv_vae_phase_grads_vs_oracle(golden_dir):
+    """ConvIPVAE (BASELINE config #4 model): every conv / transposed-conv / fc gradient of the VAE phase against the
+    oracle (itself pinned to the reference's ConvIPVAE at 6e-7) on the fixture's inputs."""
+    mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, "conv_b4_nz8")
+    model, cdae = build(mc, cc)
+    model.load_state_dict(pm); cdae.load_state_dict(pc)
+    model, cdae = model.to("cuda"), cdae.to("cuda")
+    B = int(fx["meta_B"])
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=nz), batch_size=B)
+    noise = noise_of(fx, 0, "cuda")
+    xv = torch.tensor(fx["s0/x_vae"])
+    eng.vae_phase(xv.cuda(), noise=noise, apply_update=False)
+    mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, O.TrainCfg(nz_cdae=nz), pm, pc, xv, {k: v.cpu() for k, v in noise.items()})
+    s = eng.stats()
+    assert rel(s["model_loss"], mloss) < 1e-4 and rel(s["recon"], rec) < 2e-5 and rel(s["prior"], pri) < 2e-5
+    off = 0
+    for n, shp in O.model_param_spec(mc):
+        k = int(np.prod(shp))
+        assert rel_l2(eng.grads_m[off:off + k].cpu(), gm[n].reshape(-1)) < 2e-3, n
+        off += k
+    # decoder-only entry point (IWAE evaluator) agrees with the oracle's decoder
+    z = torch.randn(6, mc.z_dim)
+    (logit,) = model.decode_params(z.cuda())
+    assert rel_l2(logit, O.decode(mc, pm, z)[0]) < 1e-5
 
 
 @pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad"])
