@@ -47,9 +47,12 @@ void set_last_error(const char* fmt, ...);
 // ----------------------------------------------------------------------------------------------
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2 };
 
-// Both helpers use the hardware exp2/log2 units (v_exp_f32 / v_log_f32, ~1 ulp) plus a short series where the
-// direct form would cancel; absolute error <= 1.2e-7, relative error <= 2e-6 over the whole range.  The ocml
-// log1pf/expm1f they replace cost ~10x the VALU issue slots and kept the 16-element epilogue loops from unrolling.
+// Both helpers use the hardware exp2/log2 units (v_exp_f32 / v_log_f32, ~1 ulp) plus a short series where the direct
+// form would cancel, so that RELATIVE accuracy (<= 2e-6) holds down to saturated units with sigmoid ~ 1e-30: their
+// gradients are tiny but RMSprop/Adam normalise them to full-size updates in the first steps, and a unit whose
+// derivative underflowed to exactly 0 would silently stop moving (seen as a 13 % update mismatch on the tiny fixture when
+// the series was dropped).  VALU work is paid for in matrix time on gfx950 (scratch/mfma/coissue.hip: f32 MFMA and VALU
+// of co-resident waves serialise on a SIMD), so these are kept to ~12 instructions each.
 __device__ __forceinline__ float softplus_f(float x) {
   // max(x,0) + log1p(exp(-|x|)) is the overflow-free form of log(1+exp(x)); identity above the threshold
   const float t = __expf(-fabsf(x));

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(WS_THREADS, 3) void linear_ws2_kernel(const LinArgs
   // One loop per role (same number of barriers in each): the roles' register live ranges stay disjoint, so the kernel's
   // allocation is the maximum over the roles, not their union.
 #ifdef ARDAE_STAMPS
-  unsigned long long w_work = 0, w_wait = 0;
+  unsigned long long w_work = 0, w_wait = 0, w_x0 = 0, w_x1 = 0;
 #define W2_BEGIN() const unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define W2_MID() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = __builtin_amdgcn_s_memtime()
 #define W2_END() { const unsigned long long t2_ = __builtin_amdgcn_s_memtime(); w_work += t1_ - t0_; w_wait += t2_ - t1_; }
@@ -497,7 +497,16 @@ __global__ __launch_bounds__(WS_THREADS, 3) void linear_ws2_kernel(const LinArgs
     for (int g = 0; g < G; ++g) {
       W2_BEGIN();
       if (((g + 1) & 1) == par) {               // this pair owns panel g+1: write it to its slot, request panel g+3
+#ifdef ARDAE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
         stash((g + 1) & 1);
+#ifdef ARDAE_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        w_x0 += ta - t0_; w_x1 += tb - ta;
+#endif
         issue(g + 3);
       }
       W2_MID();
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(WS_THREADS, 3) void linear_ws2_kernel(const LinArgs
 #ifdef ARDAE_STAMPS
   if (a.tile_loss != nullptr && lane == 0) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(a.tile_loss) + ((size_t)blockIdx.x * 12 + wave) * 4;
-    o[0] = w_work; o[1] = w_wait; o[2] = (unsigned long long)G; o[3] = 0;
+    o[0] = w_work; o[1] = w_wait; o[2] = (unsigned long long)G; o[3] = (w_x0 << 32) | (w_x1 & 0xffffffffull);
   }
 #endif
 }

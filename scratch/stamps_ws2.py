@@ -24,3 +24,5 @@ t = st.cpu().numpy().reshape(256, 12, 4).astype(np.float64)
 G = t[0, 0, 2]
 r = lambda sl: (t[:, sl, :2].mean(axis=(0, 1)) / G).round(0)
 print("EPI", epi, "steps/WG", G, "per-step [work, barrier wait]: consumer", r(slice(0, 4)), "loaderE", r(slice(4, 6)), "loaderO", r(slice(6, 8)), "epilogue", r(slice(8, 12)))
+x = st.cpu().numpy().reshape(256, 12, 4)[:, 4:8, 3].astype(np.uint64)
+print("loader per ACTIVE step: wait-for-loads", ((x >> np.uint64(32)).astype(np.float64).mean() / (G / 2)).round(0), " stash", ((x & np.uint64(0xffffffff)).astype(np.float64).mean() / (G / 2)).round(0))
