@@ -28,6 +28,10 @@
 namespace ardae {
 namespace {
 
+// collect pack requests; flushed with one launch by PACK_FLUSH
+#define PACK_PUSH(W_, ldw_, nout_, k_, tr_, out_) pack_items__.push_back(PackItem{W_, ldw_, nout_, k_, (tr_) ? 1 : 0, out_})
+#define PACK_FLUSH(st_) ARDAE_TRY(launch_pack_batch(pack_items__.data(), (int)pack_items__.size(), st_))
+
 struct Lin {
   size_t w, b;   // offsets (floats) into the flat parameter buffer
   int out, in;
@@ -146,27 +150,29 @@ size_t workspace_floats(const CdaeLayout& P, int B, int S, bool need_grads) {
 }
 
 int cdae_pack_impl(const CdaeLayout& P, const PackedLayout& K, const float* params, float* packed, hipStream_t st) {
+  std::vector<PackItem> pack_items__;
   for (int l = 0; l < P.L; ++l) {
-    ARDAE_TRY(launch_pack_weight(params + P.ctx[l].w, P.ctx[l].in, P.ctx[l].out, P.ctx[l].in, false, packed + K.ctx_f[l], st));
-    ARDAE_TRY(launch_pack_weight(params + P.ctx[l].w, P.ctx[l].in, P.ctx[l].in, P.ctx[l].out, true, packed + K.ctx_b[l], st));
-    ARDAE_TRY(launch_pack_weight(params + P.inp[l].w, P.inp[l].in, P.inp[l].out, P.inp[l].in, false, packed + K.inp_f[l], st));
-    ARDAE_TRY(launch_pack_weight(params + P.inp[l].w, P.inp[l].in, P.inp[l].in, P.inp[l].out, true, packed + K.inp_b[l], st));
+    PACK_PUSH(params + P.ctx[l].w, P.ctx[l].in, P.ctx[l].out, P.ctx[l].in, false, packed + K.ctx_f[l]);
+    PACK_PUSH(params + P.ctx[l].w, P.ctx[l].in, P.ctx[l].in, P.ctx[l].out, true, packed + K.ctx_b[l]);
+    PACK_PUSH(params + P.inp[l].w, P.inp[l].in, P.inp[l].out, P.inp[l].in, false, packed + K.inp_f[l]);
+    PACK_PUSH(params + P.inp[l].w, P.inp[l].in, P.inp[l].in, P.inp[l].out, true, packed + K.inp_b[l]);
   }
   const float* W1 = params + P.neg[0].w;
   const int ld1 = 2 * P.h + 1;
-  ARDAE_TRY(launch_pack_weight(W1, ld1, P.h, P.h, false, packed + K.w1a_f, st));
-  ARDAE_TRY(launch_pack_weight(W1, ld1, P.h, P.h, true, packed + K.w1a_b, st));
-  ARDAE_TRY(launch_pack_weight(W1 + P.h, ld1, P.h, P.h, false, packed + K.w1c_f, st));
-  ARDAE_TRY(launch_pack_weight(W1 + P.h, ld1, P.h, P.h, true, packed + K.w1c_b, st));
+  PACK_PUSH(W1, ld1, P.h, P.h, false, packed + K.w1a_f);
+  PACK_PUSH(W1, ld1, P.h, P.h, true, packed + K.w1a_b);
+  PACK_PUSH(W1 + P.h, ld1, P.h, P.h, false, packed + K.w1c_f);
+  PACK_PUSH(W1 + P.h, ld1, P.h, P.h, true, packed + K.w1c_b);
   ARDAE_TRY(launch_gather_strided(W1 + 2 * P.h, ld1, P.h, packed + K.w1s, st));
   for (int l = 1; l < P.L; ++l) {
-    ARDAE_TRY(launch_pack_weight(params + P.neg[l].w, P.h, P.h, P.h, false, packed + K.neg_f[l], st));
-    ARDAE_TRY(launch_pack_weight(params + P.neg[l].w, P.h, P.h, P.h, true, packed + K.neg_b[l], st));
+    PACK_PUSH(params + P.neg[l].w, P.h, P.h, P.h, false, packed + K.neg_f[l]);
+    PACK_PUSH(params + P.neg[l].w, P.h, P.h, P.h, true, packed + K.neg_b[l]);
   }
   if (P.kind == 1) {
-    ARDAE_TRY(launch_pack_weight(params + P.neg[P.L].w, P.h, P.z, P.h, false, packed + K.fc_f, st));
-    ARDAE_TRY(launch_pack_weight(params + P.neg[P.L].w, P.h, P.h, P.z, true, packed + K.fc_b, st));
+    PACK_PUSH(params + P.neg[P.L].w, P.h, P.z, P.h, false, packed + K.fc_f);
+    PACK_PUSH(params + P.neg[P.L].w, P.h, P.h, P.z, true, packed + K.fc_b);
   }
+  PACK_FLUSH(st);
   return 0;
 }
 

@@ -17,6 +17,10 @@
 namespace ardae {
 namespace {
 
+// collect pack requests; flushed with one launch by PACK_FLUSH
+#define PACK_PUSH(W_, ldw_, nout_, k_, tr_, out_) pack_items__.push_back(PackItem{W_, ldw_, nout_, k_, (tr_) ? 1 : 0, out_})
+#define PACK_FLUSH(st_) ARDAE_TRY(launch_pack_batch(pack_items__.data(), (int)pack_items__.size(), st_))
+
 // ------------------------------------------------------------------------------------------------ data-movement kernels
 // cols[(b*OH+oh)*OW+ow][c*25+kh*5+kw] = x[b][2oh-2+kh][2ow-2+kw][c]  (0 outside H x W); x is NHWC [B,H,W,C]
 __global__ void im2col_s2_kernel(const float* __restrict__ x, int H, int W, int C, int OH, int OW, float* __restrict__ cols, int64_t total) {
@@ -276,26 +280,28 @@ size_t conv_model_packed_floats(const ardae_model_desc& d) { return ConvPacked(C
 size_t conv_model_workspace_floats(const ardae_model_desc& d, int B, int nz, int mode) { return conv_workspace(ConvLayout(d), B, nz, mode); }
 
 int conv_model_pack(const ardae_model_desc& d, const float* params, float* packed, hipStream_t st) {
+  std::vector<PackItem> pack_items__;
   const ConvLayout P(d);
   const ConvPacked K(P);
   for (int i = 0; i < 3; ++i) {
-    ARDAE_TRY(launch_pack_weight(params + P.conv[i].w, P.conv[i].in, P.conv[i].out, P.conv[i].in, false, packed + K.conv_f[i], st));
-    ARDAE_TRY(launch_pack_weight(params + P.conv[i].w, P.conv[i].in, P.conv[i].in, P.conv[i].out, true, packed + K.conv_b[i], st));
+    PACK_PUSH(params + P.conv[i].w, P.conv[i].in, P.conv[i].out, P.conv[i].in, false, packed + K.conv_f[i]);
+    PACK_PUSH(params + P.conv[i].w, P.conv[i].in, P.conv[i].in, P.conv[i].out, true, packed + K.conv_b[i]);
   }
   const int ld4 = 512 + P.nd;
-  ARDAE_TRY(launch_pack_weight(params + P.fc4.w, ld4, 800, 512, false, packed + K.fc4i_f, st));
-  ARDAE_TRY(launch_pack_weight(params + P.fc4.w, ld4, 512, 800, true, packed + K.fc4i_b, st));
-  ARDAE_TRY(launch_pack_weight(params + P.fc4.w + 512, ld4, 800, P.nd, false, packed + K.fc4n_f, st));
-  ARDAE_TRY(launch_pack_weight(params + P.fc5.w, 800, P.zd, 800, false, packed + K.fc5_f, st));
-  ARDAE_TRY(launch_pack_weight(params + P.fc5.w, 800, 800, P.zd, true, packed + K.fc5_b, st));
+  PACK_PUSH(params + P.fc4.w, ld4, 800, 512, false, packed + K.fc4i_f);
+  PACK_PUSH(params + P.fc4.w, ld4, 512, 800, true, packed + K.fc4i_b);
+  PACK_PUSH(params + P.fc4.w + 512, ld4, 800, P.nd, false, packed + K.fc4n_f);
+  PACK_PUSH(params + P.fc5.w, 800, P.zd, 800, false, packed + K.fc5_f);
+  PACK_PUSH(params + P.fc5.w, 800, 800, P.zd, true, packed + K.fc5_b);
   for (int i = 0; i < 2; ++i) {
-    ARDAE_TRY(launch_pack_weight(params + P.dfc[i].w, P.dfc[i].in, P.dfc[i].out, P.dfc[i].in, false, packed + K.dfc_f[i], st));
-    ARDAE_TRY(launch_pack_weight(params + P.dfc[i].w, P.dfc[i].in, P.dfc[i].in, P.dfc[i].out, true, packed + K.dfc_b[i], st));
+    PACK_PUSH(params + P.dfc[i].w, P.dfc[i].in, P.dfc[i].out, P.dfc[i].in, false, packed + K.dfc_f[i]);
+    PACK_PUSH(params + P.dfc[i].w, P.dfc[i].in, P.dfc[i].in, P.dfc[i].out, true, packed + K.dfc_b[i]);
   }
   for (int i = 0; i < 3; ++i) {   // ConvTranspose2d weight [in, out*25]: forward = X . W (transposed pack), backward-data = dC . W^T (natural)
-    ARDAE_TRY(launch_pack_weight(params + P.dcv[i].w, P.dcv[i].in, P.dcv[i].in, P.dcv[i].out, true, packed + K.dcv_f[i], st));
-    ARDAE_TRY(launch_pack_weight(params + P.dcv[i].w, P.dcv[i].in, P.dcv[i].out, P.dcv[i].in, false, packed + K.dcv_b[i], st));
+    PACK_PUSH(params + P.dcv[i].w, P.dcv[i].in, P.dcv[i].in, P.dcv[i].out, true, packed + K.dcv_f[i]);
+    PACK_PUSH(params + P.dcv[i].w, P.dcv[i].in, P.dcv[i].out, P.dcv[i].in, false, packed + K.dcv_b[i]);
   }
+  PACK_FLUSH(st);
   return 0;
 }
 

@@ -29,6 +29,10 @@ int linear_col_panels(int M, int nout);
 // M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]
 int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose, float* out, hipStream_t st);
 int launch_linear(const LinArgs& a, int epi, hipStream_t st);
+// pack many matrices with one launch (the per-step refresh of a network's weight images)
+struct PackItem { const float* W; int ldw, nout, k, transpose; float* out; };
+constexpr int PACK_BATCH_MAX = 48;
+int launch_pack_batch(const PackItem* items, int n, hipStream_t st);
 // warp-specialised persistent variant (linear_ws.hip) for the big N-row layers
 bool linear_ws_eligible(const LinArgs& a, int epi);
 int launch_linear_ws(const LinArgs& a, int epi, hipStream_t st);

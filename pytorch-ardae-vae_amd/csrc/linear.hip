@@ -453,6 +453,35 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int ldw, int nou
   reinterpret_cast<f32x4*>(out)[t] = v;
 }
 
+struct PackBatchDev {
+  int n;
+  PackItem it[PACK_BATCH_MAX];
+};
+
+// all matrices of a network in ONE launch (blockIdx.y = matrix); same image as pack_weight_kernel
+__global__ void pack_batch_kernel(const PackBatchDev b) {
+  const PackItem& P = b.it[blockIdx.y];
+  const int kchunks = (P.k + 7) >> 3;
+  const size_t total4 = (size_t)((P.nout + 31) >> 5) * kchunks * 64;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(t & 63);
+    const size_t blk = t >> 6;
+    const int kc = (int)(blk % kchunks);
+    const int nb = (int)(blk / kchunks);
+    const int n = nb * 32 + (lane & 31);
+    const int kb = kc * 8 + 4 * (lane >> 5);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < P.nout) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kb + j;
+        if (k < P.k) v[j] = P.transpose ? P.W[(size_t)k * P.ldw + n] : P.W[(size_t)n * P.ldw + k];
+      }
+    }
+    reinterpret_cast<f32x4*>(P.out)[t] = v;
+  }
+}
+
 template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB, bool TR = false>
 int launch_geo(const LinArgs& a, hipStream_t st) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
@@ -536,6 +565,25 @@ int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose,
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, st, W, ldw, nout, k,
                      transpose ? 1 : 0, out, kchunks, total4);
   ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pack_batch(const PackItem* items, int n, hipStream_t st) {
+  for (int start = 0; start < n; start += PACK_BATCH_MAX) {
+    PackBatchDev b;
+    b.n = n - start < PACK_BATCH_MAX ? n - start : PACK_BATCH_MAX;
+    size_t max4 = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const PackItem& p = items[start + i];
+      ARDAE_CHECK_ARG(p.W && p.out && p.nout > 0 && p.k > 0 && p.ldw > 0, "pack_batch: bad item %d", start + i);
+      b.it[i] = p;
+      const size_t t4 = packed_floats(p.nout, p.k) / 4;
+      if (t4 > max4) max4 = t4;
+    }
+    const int gx = (int)((max4 + 255) / 256);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(gx < 256 ? gx : 256, b.n), dim3(256), 0, st, b);
+    ARDAE_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -20,6 +20,10 @@
 namespace ardae {
 namespace {
 
+// collect pack requests; flushed with one launch by PACK_FLUSH
+#define PACK_PUSH(W_, ldw_, nout_, k_, tr_, out_) pack_items__.push_back(PackItem{W_, ldw_, nout_, k_, (tr_) ? 1 : 0, out_})
+#define PACK_FLUSH(st_) ARDAE_TRY(launch_pack_batch(pack_items__.data(), (int)pack_items__.size(), st_))
+
 struct Lin {
   size_t w, b;
   int out, in;
@@ -242,26 +246,28 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
+  std::vector<PackItem> pack_items__;
   const ModelLayout P(*d);
   const ModelPacked K(P);
   for (size_t l = 0; l < P.inp.size(); ++l) {
-    ARDAE_TRY(launch_pack_weight(params + P.inp[l].w, P.inp[l].in, P.inp[l].out, P.inp[l].in, false, packed + K.inp_f[l], st));
-    ARDAE_TRY(launch_pack_weight(params + P.inp[l].w, P.inp[l].in, P.inp[l].in, P.inp[l].out, true, packed + K.inp_b[l], st));
+    PACK_PUSH(params + P.inp[l].w, P.inp[l].in, P.inp[l].out, P.inp[l].in, false, packed + K.inp_f[l]);
+    PACK_PUSH(params + P.inp[l].w, P.inp[l].in, P.inp[l].in, P.inp[l].out, true, packed + K.inp_b[l]);
   }
   for (size_t i = 0; i < P.stack.size(); ++i) {
     const Lin& l = P.stack[i];
-    ARDAE_TRY(launch_pack_weight(params + l.w, l.in, l.out, P.h, false, packed + K.sh_f[i], st));
-    ARDAE_TRY(launch_pack_weight(params + l.w, l.in, P.h, l.out, true, packed + K.sh_b[i], st));
-    if (P.stack_noise[i]) ARDAE_TRY(launch_pack_weight(params + l.w + P.h, l.in, l.out, P.nd, false, packed + K.sn_f[i], st));
+    PACK_PUSH(params + l.w, l.in, l.out, P.h, false, packed + K.sh_f[i]);
+    PACK_PUSH(params + l.w, l.in, P.h, l.out, true, packed + K.sh_b[i]);
+    if (P.stack_noise[i]) PACK_PUSH(params + l.w + P.h, l.in, l.out, P.nd, false, packed + K.sn_f[i]);
   }
   for (size_t l = 0; l < P.dec.size(); ++l) {
-    ARDAE_TRY(launch_pack_weight(params + P.dec[l].w, P.dec[l].in, P.dec[l].out, P.dec[l].in, false, packed + K.dec_f[l], st));
-    ARDAE_TRY(launch_pack_weight(params + P.dec[l].w, P.dec[l].in, P.dec[l].in, P.dec[l].out, true, packed + K.dec_b[l], st));
+    PACK_PUSH(params + P.dec[l].w, P.dec[l].in, P.dec[l].out, P.dec[l].in, false, packed + K.dec_f[l]);
+    PACK_PUSH(params + P.dec[l].w, P.dec[l].in, P.dec[l].in, P.dec[l].out, true, packed + K.dec_b[l]);
   }
   for (size_t k = 0; k < P.heads.size(); ++k) {
-    ARDAE_TRY(launch_pack_weight(params + P.heads[k].w, P.heads[k].in, P.heads[k].out, P.heads[k].in, false, packed + K.head_f[k], st));
-    ARDAE_TRY(launch_pack_weight(params + P.heads[k].w, P.heads[k].in, P.heads[k].in, P.heads[k].out, true, packed + K.head_b[k], st));
+    PACK_PUSH(params + P.heads[k].w, P.heads[k].in, P.heads[k].out, P.heads[k].in, false, packed + K.head_f[k]);
+    PACK_PUSH(params + P.heads[k].w, P.heads[k].in, P.heads[k].in, P.heads[k].out, true, packed + K.head_b[k]);
   }
+  PACK_FLUSH(st);
   return 0;
 }
 
