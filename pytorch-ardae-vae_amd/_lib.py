@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libardae_hip.so")
+LIB_PATH = os.environ.get("ARDAE_LIB") or os.path.join(_HERE, "libardae_hip.so")   # ARDAE_LIB: experiment builds
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 

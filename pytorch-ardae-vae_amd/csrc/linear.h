@@ -33,6 +33,9 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st);
 struct PackItem { const float* W; int ldw, nout, k, transpose; float* out; };
 constexpr int PACK_BATCH_MAX = 48;
 int launch_pack_batch(const PackItem* items, int n, hipStream_t st);
+// software-pipelined 64 x 256 kernel (linear_wide.hip): full tiles, K % 32 == 0
+bool linear_wide_eligible(const LinArgs& a, int epi);
+int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);
 // warp-specialised persistent variant (linear_ws.hip) for the big N-row layers
 bool linear_ws_eligible(const LinArgs& a, int epi);
 int launch_linear_ws(const LinArgs& a, int epi, hipStream_t st);

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "linear.h"
+#include "linear_epilogue.h"
 #include "profile.h"
 
 namespace ardae {
@@ -38,112 +39,6 @@ struct Geo {
   static constexpr int LDW = KPANEL + 4;
   static constexpr int LDS_FLOATS = 2 * BM * LDW;   // double-buffered K panels
 };
-
-// Epilogue of one 32x32 accumulator block (16 registers per lane).  All operand loads of the block are issued
-// first, into registers, and only then the math + stores run: outputs may alias inputs (Y == Q in place), so the
-// compiler cannot hoist loads over stores by itself and an element-at-a-time epilogue serialises on HBM latency.
-template <int EPI, int ACT, bool FULL, int R0>
-__device__ __forceinline__ void epilogue_half(const LinArgs& a, const f32x16& acc16, int rbase, int col, bool cok, float bcol,
-                                              float wsig, float& csum, float& loss_part) {
-  // registers R0..R0+7 of the 32x32 block: rows rbase + {0..3} + 8*(R0/4 + {0,1})
-  float acc[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = acc16[R0 + r];
-  int rowv[8];
-  bool ok[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int raw = rbase + ((R0 + r) & 3) + 8 * ((R0 + r) >> 2);
-    ok[r] = FULL ? true : (cok && raw < a.M);
-    rowv[r] = FULL ? raw : min(raw, a.M - 1);
-  }
-  float y[8];
-  if (EPI == EPI_ACT) {
-    float rb[8], rs[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) rb[r] = 0.f, rs[r] = 0.f;
-    if (a.rowbias) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) rb[r] = a.rowbias[(size_t)(rowv[r] / a.rows_per_group) * a.rowbias_ld + col];
-    }
-    if (a.rowscale) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) rs[r] = a.rowscale[rowv[r]];
-    }
-    const float wv = a.Y2 ? a.R[col] : 0.f;   // R is the [Nout] vector w here
-#pragma unroll
-    for (int r = 0; r < 8; ++r) y[r] = act_fwd<ACT>(acc[r] + bcol + rb[r] + rs[r] * wsig);
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (ok[r]) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
-    if (a.Y2) {   // seed of the score pass: e_L = -w (.) act'(pre)
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (ok[r]) a.Y2[(size_t)rowv[r] * a.ldY2 + col] = -wv * act_d1<ACT>(y[r]);
-    }
-  } else if (EPI == EPI_DACT) {
-    float sv[8], qv[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
-    if (a.Q) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) qv[r] = a.Q[(size_t)rowv[r] * a.ldQ + col];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) qv[r] = 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) y[r] = acc[r] * act_d1<ACT>(sv[r]) + qv[r];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (ok[r]) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
-  } else if (EPI == EPI_CHAIN) {
-    float sv[8], rv[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) sv[r] = a.S[(size_t)rowv[r] * a.ldS + col];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) rv[r] = a.R[(size_t)rowv[r] * a.ldR + col];
-    float y2[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      // softplus: s = 1 - exp(-a) and 1 - s = exp(-a) are both formed without cancellation
-      const float em = (ACT == ACT_SOFTPLUS) ? __expf(-sv[r]) : 0.f;
-      y[r] = acc[r] * act_d1<ACT>(sv[r]);
-      y2[r] = acc[r] * rv[r] * em;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-      if (ok[r]) {
-        a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
-        a.Y2[(size_t)rowv[r] * a.ldY2 + col] = y2[r];
-      }
-  } else {  // EPI_DAE_LOSS
-    float sg[8], ev[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) sg[r] = a.sigma[rowv[r]];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) ev[r] = a.eps[(size_t)rowv[r] * a.ldeps + col];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      y[r] = acc[r] + bcol;
-      const float rho = sg[r] * y[r] + ev[r];
-      if (ok[r]) {
-        if (a.Y) a.Y[(size_t)rowv[r] * a.ldY + col] = y[r];
-        if (a.Y2) a.Y2[(size_t)rowv[r] * a.ldY2 + col] = 2.f * sg[r] * rho * a.scale;
-        loss_part += rho * rho;
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) csum += ok[r] ? y[r] : 0.f;
-}
-
-template <int EPI, int ACT, bool FULL>
-__device__ __forceinline__ void epilogue_block(const LinArgs& a, const f32x16& acc, int rbase, int col, bool cok, float bcol,
-                                               float wsig, float& csum, float& loss_part) {
-  epilogue_half<EPI, ACT, FULL, 0>(a, acc, rbase, col, cok, bcol, wsig, csum, loss_part);
-  epilogue_half<EPI, ACT, FULL, 8>(a, acc, rbase, col, cok, bcol, wsig, csum, loss_part);
-}
 
 // Vectorised epilogue for the TRANSPOSED accumulator (TR kernels compute D = W_frag . X_frag^T, i.e. MFMA operand order
 // swapped): lane l holds output row m = l&31 and, per register group g = r>>2, the four CONSECUTIVE columns
@@ -209,7 +104,11 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
   constexpr int BM = G::BM, LDW = G::LDW;
   static_assert(WM * WN == 4, "4 waves per workgroup");
+#ifdef ARDAE_DBG_LDSPAD
+  __shared__ float lds[G::LDS_FLOATS + ARDAE_DBG_LDSPAD];
+#else
   __shared__ float lds[G::LDS_FLOATS];
+#endif
   __shared__ float red[4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -312,7 +211,9 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
     Panel nxt = cur;
     if (has_next) {
       nxt = make_panel(ns, nk0);
+#ifndef ARDAE_DBG_NOSTAGE
       if (nxt.fast) panel_load(nxt);          // in flight during the MFMA loop
+#endif
     }
     if (wave_active) {
       const float* lbuf = lds + bufsel * (BM * LDW);
@@ -324,7 +225,11 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nb = min(nb0 + j, nblk_total - 1);   // clamp: out-of-range blocks are masked at the store
+#ifdef ARDAE_DBG_BL1
+        bptr[j] = cur.wp + (size_t)(nb & 1) * 256 * 8 + lane * 4;
+#else
         bptr[j] = cur.wp + ((size_t)nb * cur.kchunks + kc0) * 256 + lane * 4;
+#endif
       }
       // weight fragments: two register sets, the other one is always in flight (L2 latency behind 16 MFMAs)
       f32x4 be[TN], bo[TN], av[TM];
@@ -373,8 +278,12 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
     }
     if (!has_next) break;
     float* obuf = lds + (bufsel ^ 1) * (BM * LDW);
+#ifndef ARDAE_DBG_NOSTAGE
     if (nxt.fast) panel_store(nxt, obuf); else panel_stage_slow(nxt, obuf);
+#endif
+#ifndef ARDAE_DBG_NOBAR
     __syncthreads();
+#endif
     bufsel ^= 1;
     cur = nxt; cs = ns; ck0 = nk0;
   }
@@ -384,6 +293,19 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
 #endif
   // ------------------------------------------------------------------ epilogue
   float loss_part = 0.f;
+#ifdef ARDAE_DBG_NOEPI
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 12345.678f) a.Y[tid] = s;
+    return;
+  }
+#endif
   if (TR) {
     if (wave_active) {
 #pragma unroll
@@ -604,6 +526,13 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
   }
   if (ws_mode == 2 && linear_ws2_eligible(a, epi)) return launch_linear_ws2(a, epi, st);
   if (ws_mode == 1 && linear_ws_eligible(a, epi) && a.src[0].K <= 256) return launch_linear_ws(a, epi, st);
+  static const bool wide_on = !(getenv("ARDAE_WIDE") && atoi(getenv("ARDAE_WIDE")) == 0);
+  if (wide_on && linear_wide_eligible(a, epi)) {
+    if (epi == EPI_ACT) ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");
+    if (epi == EPI_DACT || epi == EPI_CHAIN) ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT/EPI_CHAIN need S");
+    if (epi == EPI_CHAIN) ARDAE_CHECK_ARG(a.R && a.Y2, "linear: EPI_CHAIN needs S, R and Y2");
+    if (!(epi == EPI_CHAIN && a.act != ACT_SOFTPLUS)) return launch_linear_wide(a, epi, st);
+  }
   switch (epi) {
     case EPI_ACT:
       ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");
