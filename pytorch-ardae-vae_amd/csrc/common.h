@@ -47,23 +47,28 @@ void set_last_error(const char* fmt, ...);
 // ----------------------------------------------------------------------------------------------
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2 };
 
-// Both helpers use the hardware exp2/log2 units (v_exp_f32 / v_log_f32, ~1 ulp) plus a short series where the direct
-// form would cancel, so that RELATIVE accuracy (<= 2e-6) holds down to saturated units with sigmoid ~ 1e-30: their
-// gradients are tiny but RMSprop/Adam normalise them to full-size updates in the first steps, and a unit whose
-// derivative underflowed to exactly 0 would silently stop moving (seen as a 13 % update mismatch on the tiny fixture when
-// the series was dropped).  VALU work is paid for in matrix time on gfx950 (scratch/mfma/coissue.hip: f32 MFMA and VALU
-// of co-resident waves serialise on a SIMD), so these are kept to ~12 instructions each.
+// Both helpers go straight to the hardware exp2 / log2 units (v_exp_f32 / v_log_f32, ~1 ulp; __expf/__logf expand to the
+// denormal-safe sequences, ~3x the instructions, with divergent branches) plus a short series where the direct form would
+// cancel, so that RELATIVE accuracy (a few 1e-6) holds down to saturated units with sigmoid ~ 1e-30: their gradients are
+// tiny but RMSprop/Adam normalise them to full-size updates in the first steps, and a unit whose derivative underflowed to
+// exactly 0 would silently stop moving (seen as a 13 % update mismatch on the tiny fixture when the series was dropped).
+// FP32 MFMA and the vector ALU are one resource on gfx950 (scratch/mfma/samewave.hip), so every instruction here is paid
+// for in matrix time: branch-free, ~11 instructions each.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 __device__ __forceinline__ float softplus_f(float x) {
-  // max(x,0) + log1p(exp(-|x|)) is the overflow-free form of log(1+exp(x)); identity above the threshold
-  const float t = __expf(-fabsf(x));
-  const float l = t < 1e-4f ? t * (1.f - 0.5f * t) : __logf(1.f + t);
-  return x > 20.f ? x : fmaxf(x, 0.f) + l;
+  // max(x,0) + log1p(exp(-|x|)) is the overflow-free form of log(1+exp(x)).  F.softplus' threshold (x > 20 -> x) needs no
+  // select: there exp(-x) < 2.1e-9 is below half an ulp of x, so the sum rounds to x exactly.
+  const float t = fast_exp(-fabsf(x));
+  const float series = t * (1.f - t * (0.5f - t * (1.f / 3.f)));                  // log1p(t), |err| < t^4/4
+  const float direct = __builtin_amdgcn_logf(1.f + t) * 0.693147180559945309f;    // rounding of 1+t: rel. err <= 6e-8 / t
+  return fmaxf(x, 0.f) + (t < 8e-3f ? series : direct);
 }
 
 // softplus'(pre) = sigmoid(pre) = 1 - exp(-a) from the saved output a = softplus(pre)
 __device__ __forceinline__ float softplus_d1_from_out(float a) {
   const float series = a * (1.f - a * (0.5f - a * (1.f / 6.f)));
-  return a < 0.02f ? series : 1.f - __expf(-a);
+  return a < 0.02f ? series : 1.f - fast_exp(-a);
 }
 
 template <int ACT>

@@ -85,7 +85,7 @@ __device__ __forceinline__ void epilogue_tr(const LinArgs& a, const f32x16& acc,
       } else if (EPI == EPI_DACT) {
         y[g][e] = v * act_d1<ACT>(sv[g][e]) + qv[g][e];
       } else {
-        const float em = (ACT == ACT_SOFTPLUS) ? __expf(-sv[g][e]) : 0.f;   // 1 - s without cancellation
+        const float em = (ACT == ACT_SOFTPLUS) ? fast_exp(-sv[g][e]) : 0.f;   // 1 - s without cancellation
         y[g][e] = v * act_d1<ACT>(sv[g][e]);
         y2[g][e] = v * qv[g][e] * em;
       }

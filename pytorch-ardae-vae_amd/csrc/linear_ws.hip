@@ -195,7 +195,7 @@ __global__ __launch_bounds__(WS_THREADS, 3) void linear_ws_kernel(const LinArgs 
             } else if (EPI == EPI_DACT) {
               y[j][q] = v[j][q] * act_d1<ACT>(sv[j][q]) + qv[j][q];
             } else {
-              const float em = (ACT == ACT_SOFTPLUS) ? __expf(-sv[j][q]) : 0.f;
+              const float em = (ACT == ACT_SOFTPLUS) ? fast_exp(-sv[j][q]) : 0.f;
               y[j][q] = v[j][q] * act_d1<ACT>(sv[j][q]);
               y2[j][q] = v[j][q] * qv[j][q] * em;
             }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(WS_THREADS, 3) void linear_ws2_kernel(const LinArgs
             if (EPI == EPI_DACT) {
               y[q] = v[q] * d + qv[jj][q];
             } else {
-              const float em = (ACT == ACT_SOFTPLUS) ? __expf(-sv[jj][q]) : 0.f;
+              const float em = (ACT == ACT_SOFTPLUS) ? fast_exp(-sv[jj][q]) : 0.f;
               y[q] = v[q] * d;
               y2[q] = v[q] * qv[jj][q] * em;
             }
