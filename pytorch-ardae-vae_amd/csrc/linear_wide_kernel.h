@@ -481,9 +481,9 @@ struct ChunkOps {
     if constexpr (S < 16) {
       constexpr int kq = S >> 2, i = (S >> 1) & 1, j = S & 1, bslot = C % (BDEPTH + 1);
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[C & 1][i][kq], B[bslot][j][kq], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0x4);
+      __builtin_amdgcn_sched_barrier(0);
       slot<S>(A, B, xv, l0, l1, rb, x, q);
-      __builtin_amdgcn_sched_barrier(0x4);
+      __builtin_amdgcn_sched_barrier(0);
       steps<S + 1>(acc, A, B, xv, l0, l1, rb, x, q);
     }
   }
@@ -493,7 +493,7 @@ struct ChunkOps {
     constexpr int bslot = C % (BDEPTH + 1);
     wait_frag<SC::vm_frag(P, C)>(A[C & 1][0], A[C & 1][1], B[bslot][0], B[bslot][1]);
     if (C == SC::BAR) __builtin_amdgcn_s_barrier();   // the wait above covered this wave's ds_writes (lgkmcnt(0))
-    __builtin_amdgcn_sched_barrier(0x4);
+    __builtin_amdgcn_sched_barrier(0);
     Ptrs q{nullptr, nullptr, nullptr, nullptr};
     steps<0>(acc, A, B, xv, l0, l1, rb, x, q);
   }
