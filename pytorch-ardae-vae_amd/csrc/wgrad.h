@@ -21,4 +21,8 @@ int wgrad_splits(int M, int O, int I, int nproblems_hint);
 // runs every problem and reduces into p[i].out / out_bias / out_rowscale ( = beta*out + sum )
 int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st);
 
+// software-pipelined 256 x 256 kernel for the big, regular problems (wgrad_wide.hip)
+bool wgrad_wide_eligible(const WgradProblem& p);
+int launch_wgrad_wide(WgradProblem* probs, const int* idx, int n, hipStream_t st);
+
 }  // namespace ardae

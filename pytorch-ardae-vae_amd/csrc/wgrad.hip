@@ -213,10 +213,10 @@ int wgrad_splits(int M, int O, int I, int nproblems_hint) {
 int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
   ARDAE_CHECK_ARG(probs && nprob >= 1 && nprob <= WGRAD_MAX_PROBLEMS, "wgrad: 1..%d problems per batch (got %d)",
                   WGRAD_MAX_PROBLEMS, nprob);
-  WgradBatchDev b;
-  memset(&b, 0, sizeof(b));
-  b.nprob = nprob;
-  int total = 0;
+  // the big regular problems go to the software-pipelined kernel (which may lower their split count), the rest to
+  // wgrad_kernel; one reduction for all
+  WgradProblem local[WGRAD_MAX_PROBLEMS];
+  int wide_idx[WGRAD_MAX_PROBLEMS], nwide = 0, wide_tiles = 0;
   size_t max_elems = 0;
   for (int i = 0; i < nprob; ++i) {
     const WgradProblem& p = probs[i];
@@ -227,26 +227,47 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
     ARDAE_CHECK_ARG(p.splits >= 1 && p.partial && p.out && p.ldout >= p.I, "wgrad[%d]: bad output/scratch", i);
     ARDAE_CHECK_ARG(p.bias_pair < p.npairs, "wgrad[%d]: bias_pair out of range", i);
     ARDAE_CHECK_ARG(p.bias_pair < 0 || p.partial_vec, "wgrad[%d]: bias_pair needs partial_vec", i);
-    b.p[i] = p;
-    b.o_tiles[i] = ceil_div(p.O, BO);
-    b.i_tiles[i] = ceil_div(p.I, BI);
-    b.wg_begin[i] = total;
-    total += b.o_tiles[i] * b.i_tiles[i] * p.splits;
+    local[i] = p;
     const size_t el = (size_t)p.O * p.I + 2 * (size_t)p.O;
     if (el > max_elems) max_elems = el;
-  }
-  b.wg_begin[nprob] = total;
-  if (g_prof_enabled) {
-    double fl = 0, by = 0;
-    for (int i = 0; i < nprob; ++i) {
-      fl += 2.0 * probs[i].npairs * (double)probs[i].M * probs[i].O * probs[i].I;
-      by += 4.0 * (probs[i].npairs * (double)probs[i].M * (probs[i].O + probs[i].I) + (double)probs[i].splits * probs[i].O * probs[i].I);
+    const int tiles = (p.O / 256) * (p.I / 256);
+    if (wgrad_wide_eligible(p) && wide_tiles + tiles <= 32) {
+      wide_idx[nwide++] = i;
+      wide_tiles += tiles;
     }
-    prof_begin(st, "wgrad_kernel", fl, by);
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(256), 0, st, b);
-  prof_end(st);
-  ARDAE_LAUNCH_CHECK();
+  if (nwide > 0) {
+    const int rc = launch_wgrad_wide(local, wide_idx, nwide, st);
+    if (rc < 0) return rc;
+  }
+  WgradBatchDev b;   // the remaining problems for wgrad_kernel
+  memset(&b, 0, sizeof(b));
+  int total = 0, nrest = 0;
+  double fl = 0, by = 0;
+  for (int i = 0, w = 0; i < nprob; ++i) {
+    if (w < nwide && wide_idx[w] == i) { ++w; continue; }
+    const WgradProblem& p = local[i];
+    b.p[nrest] = p;
+    b.o_tiles[nrest] = ceil_div(p.O, BO);
+    b.i_tiles[nrest] = ceil_div(p.I, BI);
+    b.wg_begin[nrest] = total;
+    total += b.o_tiles[nrest] * b.i_tiles[nrest] * p.splits;
+    fl += 2.0 * p.npairs * (double)p.M * p.O * p.I;
+    by += 4.0 * (p.npairs * (double)p.M * (p.O + p.I) + (double)p.splits * p.O * p.I);
+    ++nrest;
+  }
+  b.nprob = nrest;
+  b.wg_begin[nrest] = total;
+  if (nrest > 0) {
+    if (g_prof_enabled) prof_begin(st, "wgrad_kernel", fl, by);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(total), dim3(256), 0, st, b);
+    prof_end(st);
+    ARDAE_LAUNCH_CHECK();
+  }
+  // reduction over every problem, with the split counts actually used
+  memset(&b, 0, sizeof(b));
+  b.nprob = nprob;
+  for (int i = 0; i < nprob; ++i) b.p[i] = local[i];
   const int rb = (int)ceil_div64((int64_t)max_elems, 256);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb < 1024 ? rb : 1024, nprob), dim3(256), 0, st, b);
   ARDAE_LAUNCH_CHECK();
