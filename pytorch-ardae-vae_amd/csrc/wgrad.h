@@ -23,6 +23,7 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st);
 
 // software-pipelined 256 x 256 kernel for the big, regular problems (wgrad_wide.hip)
 bool wgrad_wide_eligible(const WgradProblem& p);
+int wgrad_wide_geometry(const WgradProblem& p);   // 0 none, 1: 256 x 256 tiles, 2: 256 x 32 tiles
 int launch_wgrad_wide(WgradProblem* probs, const int* idx, int n, hipStream_t st);
 
 }  // namespace ardae

@@ -201,6 +201,9 @@ __global__ void wgrad_reduce_kernel(const WgradBatchDev batch) {
 }  // namespace
 
 int wgrad_splits(int M, int O, int I, int nproblems_hint) {
+  // first-layer shapes (I = z_dim): the 256 x 32 geometry of wgrad_wide.hip streams G once, one workgroup per CU, and is
+  // latency-bound per workgroup - give it the whole chip
+  if (O % 256 == 0 && I % 32 == 0 && I <= 64 && M % RC == 0 && M >= 64 * RC) return 256 / ((O / 256) * (I / 32));
   const int tiles = ceil_div(O, BO) * ceil_div(I, BI);
   const int target = 1024;   // ~2 resident workgroups per CU x 256 CUs x 2 waves of work
   int s = target / (tiles * (nproblems_hint > 0 ? nproblems_hint : 1));
@@ -216,7 +219,7 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
   // the big regular problems go to the software-pipelined kernel (which may lower their split count), the rest to
   // wgrad_kernel; one reduction for all
   WgradProblem local[WGRAD_MAX_PROBLEMS];
-  int wide_idx[WGRAD_MAX_PROBLEMS], nwide = 0, wide_tiles = 0;
+  int wide_idx[WGRAD_MAX_PROBLEMS], nwide = 0, wide_tiles[3] = {0, 0, 0};
   size_t max_elems = 0;
   for (int i = 0; i < nprob; ++i) {
     const WgradProblem& p = probs[i];
@@ -230,10 +233,11 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
     local[i] = p;
     const size_t el = (size_t)p.O * p.I + 2 * (size_t)p.O;
     if (el > max_elems) max_elems = el;
-    const int tiles = (p.O / 256) * (p.I / 256);
-    if (wgrad_wide_eligible(p) && wide_tiles + tiles <= 32) {
+    const int geo = wgrad_wide_geometry(p);
+    const int tiles = geo == 1 ? (p.O / 256) * (p.I / 256) : geo == 2 ? (p.O / 256) * (p.I / 32) : 0;
+    if (geo != 0 && wide_tiles[geo] + tiles <= 32) {
       wide_idx[nwide++] = i;
-      wide_tiles += tiles;
+      wide_tiles[geo] += tiles;
     }
   }
   if (nwide > 0) {
