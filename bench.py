@@ -93,7 +93,7 @@ def main():
     from ardae_amd import _lib as L
     import ctypes
 
-    GLOBAL_B, NZ = 512, 256
+    GLOBAL_B, NZ = int(os.environ.get("BENCH_GLOBAL_B", "512")), 256   # BENCH_GLOBAL_B: experiments only
     assert GLOBAL_B % world == 0, "the global batch must divide over the ranks"
     B = GLOBAL_B // world
     torch.manual_seed(0)                                  # identical parameters on every rank
@@ -137,11 +137,14 @@ def main():
     # ---- live per-kernel timing (HIP events on the launch stream), separate from the throughput region
     roofline = None
     if rank == 0:
+        graph_was = eng.use_graph
+        eng.use_graph = False                 # the per-kernel HIP events need individual launches
         lib.ardae_profile_enable(1)
         for _ in range(args.prof_steps):
             one_step()
         rep = L.profile_report()
         lib.ardae_profile_enable(0)
+        eng.use_graph = graph_was
         rep.sort(key=lambda e: -e["total_ms"])
         top = rep[0]
         ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
@@ -157,7 +160,7 @@ def main():
                     "algorithmic_mbytes_per_launch": top["bytes"] / top["calls"] / 1e6,
                     "kernels": [{"name": e["name"], "calls_per_step": e["calls"] / args.prof_steps,
                                  "ms_per_step": e["total_ms"] / args.prof_steps,
-                                 "tflops": e["flops"] / (e["total_ms"] * 1e-3) / 1e12 if e["total_ms"] > 0 else 0.0} for e in rep[:8]]}
+                                 "tflops": e["flops"] / (e["total_ms"] * 1e-3) / 1e12 if e["total_ms"] > 0 else 0.0} for e in rep[:int(os.environ.get("BENCH_TOPK", "8"))]]}
     barrier()
 
     if rank == 0:
@@ -174,6 +177,7 @@ def main():
             "whole_step_tflops": flop * steps_per_s / 1e12,
             "whole_step_frac_of_fp32_mfma_peak": flop * steps_per_s / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
             "losses": stats,
+            "hip_graph": bool(eng._graph is not None),
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:

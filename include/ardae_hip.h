@@ -117,6 +117,16 @@ int ardae_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t
 /* utils/optim.py:49-108 (vendored Adam, eps before the bias correction); vmax non-NULL = amsgrad; step >= 1 */
 int ardae_adam_ref_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
                         double lr, double beta1, double beta2, double eps, int step, void* stream);
+/* Device-resident step state, so that a whole train step (ivae_ardae.py:707-846) can be captured once in a HIP graph and
+ * replayed: kernel arguments are frozen at capture, the 32-byte state block is not.  Layout: u64 rng_offset, i64 adam_step,
+ * f32 lr/(1-beta1^t), f32 sqrt(1-beta2^t); zero-initialise it.  `advance` (first node of the step) adds rng_inc to the
+ * Philox base offset, increments t and refreshes the two Adam coefficients (utils/optim.py:84-104, computed in double);
+ * the _dev variants read the state instead of taking offset / step by value (offset = state.rng_offset + offset_add). */
+#define ARDAE_STEP_STATE_BYTES 32
+int ardae_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, void* stream);
+int ardae_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, void* stream);
+int ardae_adam_ref_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
+                            double beta1, double beta2, double eps, const void* state, void* stream);
 /* torch.optim.RMSprop(lr, momentum) as built at ivae_ardae.py:625-626 (alpha .99, eps 1e-8, not centred) */
 int ardae_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buffer, int64_t n, double lr,
                        double alpha, double eps, double momentum, void* stream);

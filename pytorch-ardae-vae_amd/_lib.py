@@ -91,6 +91,9 @@ EXPORTS = {
     "ardae_philox_uniform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),
     "ardae_bernoulli": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.c_uint64, ctypes.c_void_p]),
+    "ardae_step_state_advance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
+    "ardae_philox_normal_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "ardae_adam_ref_step_dev": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 3 + [ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_adam_ref_step": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_int, ctypes.c_void_p]),
     "ardae_rmsprop_step": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
     "ardae_cdae_param_floats": (ctypes.c_size_t, [ctypes.POINTER(CdaeDesc)]),

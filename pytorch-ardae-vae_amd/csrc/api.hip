@@ -62,6 +62,16 @@ int ardae_adam_ref_step(float* p, const float* g, float* exp_avg, float* exp_avg
                         double lr, double beta1, double beta2, double eps, int step, void* stream) {
   return launch_adam_ref(p, g, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
 }
+int ardae_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, void* stream) {
+  return launch_step_state_advance(state, rng_inc, lr, beta1, beta2, (hipStream_t)stream);
+}
+int ardae_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, void* stream) {
+  return launch_philox_normal_dev(out, n, seed, state, offset_add, (hipStream_t)stream);
+}
+int ardae_adam_ref_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
+                            double beta1, double beta2, double eps, const void* state, void* stream) {
+  return launch_adam_ref_dev(p, g, exp_avg, exp_avg_sq, max_exp_avg_sq, n, beta1, beta2, eps, state, (hipStream_t)stream);
+}
 int ardae_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buffer, int64_t n, double lr,
                        double alpha, double eps, double momentum, void* stream) {
   return launch_rmsprop(p, g, square_avg, momentum_buffer, n, lr, alpha, eps, momentum, (hipStream_t)stream);

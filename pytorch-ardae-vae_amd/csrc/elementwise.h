@@ -22,6 +22,11 @@ int launch_sum_scale(const float* in, int n, float scale, float* out, hipStream_
 int launch_gather_strided(const float* src, int stride, int n, float* dst, hipStream_t st);
 // Philox4x32-10 + Box-Muller standard normals; element i depends only on (seed, offset, i)
 int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st);
+// device-resident step state (graph-replayable step): see ardae_step_state_advance in ardae_hip.h
+int launch_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, hipStream_t st);
+int launch_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, hipStream_t st);
+int launch_adam_ref_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double beta1, double beta2, double eps,
+                        const void* state, hipStream_t st);
 int launch_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st);
 int launch_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t seed, uint64_t offset, hipStream_t st);
 

@@ -1,5 +1,6 @@
 // Bandwidth-bound helper kernels (gfx950).  See elementwise.h for the operator definitions + reference lines.
 #include "elementwise.h"
+#include "linear.h"
 
 namespace ardae {
 namespace {
@@ -30,9 +31,29 @@ __device__ __forceinline__ void philox4(uint64_t seed, uint64_t offset, uint64_t
 }
 __device__ __forceinline__ float u01_open(uint32_t x) { return ((x >> 8) + 1u) * (1.0f / 16777216.0f); }  // (0,1]
 
-__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+// Device-resident step state (ardae_step_state_advance): lets a captured HIP graph replay the step with fresh noise and
+// the right Adam bias correction - kernel arguments are frozen at capture, this block is not.
+struct StepState {
+  uint64_t rng_offset;     // base offset of this step's Philox draws
+  int64_t adam_step;       // t of utils/optim.py:84
+  float adam_step_size;    // lr / (1 - beta1^t)
+  float adam_sqrt_bc2;     // sqrt(1 - beta2^t)
+};
+
+__global__ void step_state_advance_kernel(StepState* s, uint64_t rng_inc, double lr, double beta1, double beta2) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  s->rng_offset += rng_inc;
+  const int64_t t = s->adam_step + 1;
+  s->adam_step = t;
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);   // host formula of launch_adam_ref, in double
+  s->adam_step_size = (float)(lr / bc1);
+  s->adam_sqrt_bc2 = (float)sqrt(bc2);
+}
+
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, const StepState* state) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one counter = 4 normals
   if (q * 4 >= n) return;
+  if (state) offset += state->rng_offset;
   uint32_t r[4];
   philox4(seed, offset, (uint64_t)q, r);
   float v[4];
@@ -186,7 +207,11 @@ __global__ void gather_strided_kernel(const float* __restrict__ src, int stride,
 // ------------------------------------------------------------------------------------------ optimisers
 __global__ void adam_ref_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                 float* __restrict__ vmax, int64_t n, float beta1, float beta2, float eps, float step_size,
-                                float sqrt_bc2) {
+                                float sqrt_bc2, const StepState* state) {
+  if (state) {   // coefficients of the current step from the device-resident state
+    step_size = state->adam_step_size;
+    sqrt_bc2 = state->adam_sqrt_bc2;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i];
     const float mi = m[i] * beta1 + (1.f - beta1) * gi;
@@ -307,6 +332,7 @@ inline int grid_for(int64_t n, int cap = 4096) {
 
 int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int zd,
                           float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(latent && z0 && xi && eps && xbar && sigma && std_b, "latent_perturb: null pointer");
   ARDAE_CHECK_ARG(B > 0 && nz >= 2 && zd >= 1 && zd <= 256, "latent_perturb: need B>0, nz>=2 (unbiased std), 1<=z<=256 (B=%d nz=%d z=%d)", B, nz, zd);
   int zp = 1;
@@ -318,6 +344,7 @@ int launch_latent_perturb(const float* latent, const float* z0, const float* xi,
 }
 
 int launch_center_scale(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float* u, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(latent && z0 && u && B > 0 && nz > 0 && zd > 0, "center_scale: bad arguments");
   const int64_t n = (int64_t)B * nz * zd;
   hipLaunchKernelGGL(center_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latent, z0, n, nz, zd, std_scale, u);
@@ -327,6 +354,7 @@ int launch_center_scale(const float* latent, const float* z0, int B, int nz, int
 
 int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, int cols, float scale, float* out, int ldout,
                        hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(in && out && groups > 0 && rows_per_group > 0 && cols > 0 && ld >= cols && ldout >= cols, "segment_sum: bad arguments");
   hipLaunchKernelGGL(segment_sum_kernel, dim3(groups, ceil_div(cols, 64)), dim3(256), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
   ARDAE_LAUNCH_CHECK();
@@ -334,6 +362,7 @@ int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, 
 }
 
 int launch_sum_scale(const float* in, int n, float scale, float* out, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(in && out && n > 0, "sum_scale: bad arguments");
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, in, n, scale, out);
   ARDAE_LAUNCH_CHECK();
@@ -341,6 +370,7 @@ int launch_sum_scale(const float* in, int n, float scale, float* out, hipStream_
 }
 
 int launch_gather_strided(const float* src, int stride, int n, float* dst, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(src && dst && n > 0 && stride > 0, "gather_strided: bad arguments");
   hipLaunchKernelGGL(gather_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, stride, n, dst);
   ARDAE_LAUNCH_CHECK();
@@ -348,14 +378,35 @@ int launch_gather_strided(const float* src, int stride, int n, float* dst, hipSt
 }
 
 int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(out && n > 0, "philox_normal: bad arguments");
   const int64_t q = (n + 3) / 4;
-  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset);
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset,
+                     (const StepState*)nullptr);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
+  ARDAE_CHECK_ARG(out && n > 0 && state, "philox_normal_dev: bad arguments");
+  const int64_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset_add,
+                     (const StepState*)state);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
+  ARDAE_CHECK_ARG(state, "step_state_advance: null state");
+  hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, st, (StepState*)state, rng_inc, lr, beta1, beta2);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(out && n > 0, "philox_uniform: bad arguments");
   const int64_t q = (n + 3) / 4;
   hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset);
@@ -364,6 +415,7 @@ int launch_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset,
 }
 
 int launch_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t seed, uint64_t offset, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(p && out && rows > 0 && cols > 0, "bernoulli: bad arguments");
   const int64_t q = (rows * cols + 3) / 4;
   hipLaunchKernelGGL(bernoulli_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, p, rows, cols, out, seed, offset);
@@ -373,16 +425,28 @@ int launch_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_
 
 int launch_adam_ref(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
                     double eps, int step, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_ref: bad arguments");
   const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   hipLaunchKernelGGL(adam_ref_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, vmax, n, (float)beta1, (float)beta2,
-                     (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
+                     (float)eps, (float)(lr / bc1), (float)sqrt(bc2), (const StepState*)nullptr);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam_ref_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double beta1, double beta2, double eps,
+                        const void* state, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
+  ARDAE_CHECK_ARG(p && g && m && v && n > 0 && state, "adam_ref_dev: bad arguments");
+  hipLaunchKernelGGL(adam_ref_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, vmax, n, (float)beta1, (float)beta2,
+                     (float)eps, 0.f, 1.f, (const StepState*)state);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, double lr, double alpha, double eps, double momentum,
                    hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(p && g && sq && n > 0 && (momentum <= 0.0 || buf), "rmsprop: bad arguments");
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, sq, buf, n, (float)lr, (float)alpha, (float)eps,
                      (float)momentum);
@@ -391,6 +455,7 @@ int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, d
 }
 
 int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(x && y && n > 0, "affine: bad arguments");
   hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, alpha, beta, y);
   ARDAE_LAUNCH_CHECK();
@@ -400,6 +465,7 @@ int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, 
 int launch_vae_loss(int kind, const float* o0, const float* o1, const float* x, const float* z, int rows, int nz, int D, int zd,
                     float beta, int write_grads, float gscale, const float* dz_extra, float* rec_row, float* pri_row, float* do0,
                     float* do1, float* dzq, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(o0 && x && z && rec_row && pri_row && rows > 0 && nz > 0 && D > 0 && zd > 0, "vae_loss: bad arguments");
   ARDAE_CHECK_ARG(kind == 0 || (kind == 1 && o1), "vae_loss: kind 1 needs the logvar head");
   ARDAE_CHECK_ARG(!write_grads || (do0 && dzq && (kind == 0 || do1)), "vae_loss: gradient outputs missing");
@@ -414,6 +480,7 @@ int launch_vae_loss(int kind, const float* o0, const float* o1, const float* x, 
 }
 
 int launch_vae_loss_finalize(const float* rec_row, const float* pri_row, int rows, float beta, float* losses, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(rec_row && pri_row && losses && rows > 0, "vae_loss_finalize: bad arguments");
   hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_row, pri_row, rows, beta, losses);
   ARDAE_LAUNCH_CHECK();

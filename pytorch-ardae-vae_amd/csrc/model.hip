@@ -176,7 +176,7 @@ void carve(const ModelLayout& P, Bump& ws, int B, int nz, int mode, ModelWs& W) 
 int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
   a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
   a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;
-  return launch_linear(a, epi, st);
+  return linear_or_chain(a, epi, st);
 }
 
 // sampler forward: fills W.e, W.rb, W.t, W.z (and copies z to z_out when given)
@@ -212,9 +212,12 @@ int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, 
       A.src[n].x = noise; A.src[n].ld = P.nd; A.src[n].K = P.nd; A.src[n].wp = packed + K.sn_f[i]; ++n;
     }
     A.nsrc = n;
-    ARDAE_TRY(launch_linear(A, EPI_ACT, st));
+    ARDAE_TRY(linear_or_chain(A, EPI_ACT, st));
   }
-  if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (z_out) {
+    ARDAE_TRY(flush_active_chain());
+    ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
   return 0;
 }
 
@@ -245,6 +248,7 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
   std::vector<PackItem> pack_items__;
   const ModelLayout P(*d);
@@ -286,6 +290,7 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 0));
   ARDAE_CHECK_ARG(z_out, "model_encode: z_out is NULL");
   hipStream_t st = (hipStream_t)stream;
+  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   if (d->kind == 2) return conv_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
@@ -295,11 +300,13 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   const float* nz_ptr = noise;
   if (!noise) {   // encode(x, std=0): the reference multiplies its draw by 0
     float* zero = ws.take((size_t)B * nz * P.nd);
+    ARDAE_TRY(flush_active_chain());
     ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * nz * P.nd * sizeof(float), st));
     nz_ptr = zero;
   }
   ARDAE_CHECK_ARG(ws.ok, "model_encode: internal workspace accounting error");
-  return encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, st);
+  ARDAE_TRY(encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, st));
+  return chain_scope.finish();
 }
 
 int ardae_model_decode(const ardae_model_desc* d, const float* params, const float* packed, const float* z, int R, float* workspace,
@@ -315,6 +322,7 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
   ARDAE_CHECK_ARG(P.kind == 0 || out1, "model_decode: the Gaussian decoder needs out1 (logvar)");
   ARDAE_CHECK_ARG(workspace_floats_ >= P.dec.size() * al64((size_t)R * P.h), "model_decode: workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   Bump ws(workspace, workspace_floats_);
   const int h = P.h;
   const float* cur = z;
@@ -344,6 +352,7 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && z_out && losses, "model_vae_forward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
+  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   if (d->kind == 2) return conv_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
@@ -372,6 +381,7 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
+  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   if (d->kind == 2)
     return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   const ModelLayout P(*d);
@@ -388,7 +398,7 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   {
     LinArgs A{}; A.S = W.dcd[ndec]; A.ldS = h; A.Y = W.ddec[ndec]; A.ldY = h; A.M = R; A.Nout = h; A.act = act; A.nsrc = (int)nh;
     for (size_t k = 0; k < nh; ++k) { A.src[k].x = W.dox[k]; A.src[k].ld = P.D; A.src[k].K = P.D; A.src[k].wp = packed + K.head_b[k]; }
-    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
+    ARDAE_TRY(linear_or_chain(A, EPI_DACT, st));
   }
   for (size_t l = ndec; l >= 2; --l) {
     LinArgs A{}; A.S = W.dcd[l - 1]; A.ldS = h; A.Y = W.ddec[l - 1]; A.ldY = h;

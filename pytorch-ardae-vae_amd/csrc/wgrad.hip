@@ -6,6 +6,7 @@
 // kk=l>>5) supplies A[o=c][k=kk] = G[m0+kk][o] and B[k=kk][i=c] = X[m0+kk][i], i.e. both fragment reads are
 // 32 consecutive floats per half-wave - conflict-free ds_read_b32).
 #include "wgrad.h"
+#include "linear.h"
 #include "profile.h"
 
 namespace ardae {
@@ -214,6 +215,7 @@ int wgrad_splits(int M, int O, int I, int nproblems_hint) {
 }
 
 int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(probs && nprob >= 1 && nprob <= WGRAD_MAX_PROBLEMS, "wgrad: 1..%d problems per batch (got %d)",
                   WGRAD_MAX_PROBLEMS, nprob);
   // the big regular problems go to the software-pipelined kernel (which may lower their split count), the rest to

@@ -29,3 +29,16 @@ for _ in range(it): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / it
 print(f"EPI={epi} M={M} K={K} N={N}: {ms*1e3:.1f} us  {2*M*K*N/ms/1e9:.1f} TFLOP/s")
+if os.environ.get("GRAPH"):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3): run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        for _ in range(it): run()
+    g.replay(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f"graph replay: {e0.elapsed_time(e1) / (5 * it) * 1e3:.1f} us per launch")
