@@ -7,6 +7,7 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export ARDAE_GRAPH=0   # individual launches: the kernel trace and the counters are per kernel either way
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 # separate PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass; no trace domains besides kernel-trace)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --prof-steps 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.log

@@ -18,7 +18,7 @@ import sys
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    name = name.replace("ardae::(anonymous namespace)::", "")
+    name = name.replace("ardae::(anonymous namespace)::", "").replace("ardae::wide::", "").replace("ardae::", "")
     name = re.sub(r"\(.*$", "", name)
     return name[:120]
 
@@ -64,6 +64,12 @@ def main(src, dst_prefix):
         m = re.match(r"(linear_kernel|linear_ws2?_kernel)<(.*)>", k)
         if m:
             out[f"{m.group(1)}<{m.group(2)}>"] = out[k]
+        m = re.match(r"linear_wide_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", k)
+        if m:   # bench.py prints the two flags as 0 / 1
+            a = list(m.groups())
+            out["linear_wide_kernel<%s, %s, %s, %s, %d, %d>" % (a[0], a[1], a[2], a[3], a[4] == "true", a[5] == "true")] = out[k]
+        if k.startswith("wgrad_wide_kernel<"):
+            out["wgrad_wide_kernel<256x256>" if "4, 4, 2" in k else "wgrad_wide_kernel<256x32>"] = out[k]
     with open(os.path.join(os.path.dirname(dst_prefix) or ".", "pmc_summary.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", dst_prefix + "_kernel_stats.csv", "and pmc_summary.json with", len(out), "kernels")
