@@ -37,6 +37,7 @@ constexpr int LIN_CHAIN_MAX = 8;
 struct LinChain {
   explicit LinChain(hipStream_t s) : st(s) {}
   int n = 0, M = 0;
+  bool wide = false;   // a chain of N-row layers for linear_fchain_kernel (else: per-image layers for linear_chain_kernel)
   LinArgs a[LIN_CHAIN_MAX];
   int epi[LIN_CHAIN_MAX];
   hipStream_t st;
@@ -62,6 +63,10 @@ int launch_pack_batch(const PackItem* items, int n, hipStream_t st);
 // software-pipelined 64 x 256 kernel (linear_wide.hip): full tiles, K % 32 == 0
 bool linear_wide_eligible(const LinArgs& a, int epi);
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);
+// fused chain of N-row 256 -> 256 layers in one persistent launch (linear_fchain_kernel.h)
+bool linear_fchain_layer_ok(const LinArgs& a, int epi);
+int linear_fchain_length();
+int launch_linear_fchain(const LinArgs* layers, int nl, int epi, hipStream_t st);
 // warp-specialised persistent variant (linear_ws.hip) for the big N-row layers
 bool linear_ws_eligible(const LinArgs& a, int epi);
 int launch_linear_ws(const LinArgs& a, int epi, hipStream_t st);

@@ -608,6 +608,12 @@ int chain_flush(LinChain& c) {
   const int n = c.n;
   c.n = 0;
   if (n == 0) return 0;
+  if (c.wide) {
+    c.wide = false;
+    if (n == linear_fchain_length()) return launch_linear_fchain(c.a, n, c.epi[0], c.st);
+    for (int i = 0; i < n; ++i) ARDAE_TRY(launch_linear(c.a[i], c.epi[i], c.st));   // not a full chain: layer by layer
+    return 0;
+  }
   if (n == 1) return launch_linear(c.a[0], c.epi[0], c.st);
   LinChainDev d;
   d.n = n;
@@ -634,6 +640,23 @@ int chain_flush(LinChain& c) {
 
 int chain_add(LinChain& c, const LinArgs& a, int epi) {
   ARDAE_TRY(validate_linear(a, epi));
+  if (linear_fchain_layer_ok(a, epi)) {
+    // an N-row layer joins the pending chain only if it provably consumes the previous layer's output row by row
+    if (c.n > 0) {
+      const LinArgs& p = c.a[c.n - 1];
+      const bool joins = c.wide && c.n < linear_fchain_length() && a.M == c.M && epi == c.epi[0] && a.src[0].x == p.Y && a.src[0].ld == p.ldY &&
+                         (epi != EPI_DACT || ((a.Q != nullptr) == (c.a[0].Q != nullptr)));
+      if (!joins) ARDAE_TRY(chain_flush(c));
+    }
+    c.wide = true;
+    c.M = a.M;
+    c.a[c.n] = a;
+    c.epi[c.n] = epi;
+    ++c.n;
+    if (c.n == linear_fchain_length()) return chain_flush(c);
+    return 0;
+  }
+  if (c.wide) ARDAE_TRY(chain_flush(c));
   if (!chain_eligible(a, epi)) {
     ARDAE_TRY(chain_flush(c));
     return launch_linear(a, epi, c.st);

@@ -110,10 +110,13 @@ struct PanelGeo {
 // and the waits derived from it.  NLT / NST = tensors loaded / stored per output element by the epilogue.
 // With a single panel per tile (NP == 1) there is no room to defer: the epilogue stores at once, and the first chunks of
 // the next tile see >= 64 younger stores (the count saturates at the 6-bit maximum).
-template <int NCH, int NP, int NLT, int NST, bool HP>
+template <int NCH, int NP, int NLT, int NST, bool HP, int NXL = PanelGeo<NCH>::NX>
 struct Sched {
-  static constexpr int NX = PanelGeo<NCH>::NX;
-  static constexpr bool DEFER = NP >= 2;
+  static constexpr int NX = NXL;            // activation-panel loads per chunk 0 (0: the activations already sit in LDS)
+  // Deferring keeps the previous tile's results (64*NST registers) alive next to this tile's operands (64*NLT): with
+  // three or more tensors the wave runs out of its 256 architectural VGPRs, and a compiler spill of a register whose load
+  // is still in flight reads garbage (seen as wrong Y2 rows in the first 8 rows of a tile) - those kernels store at once.
+  static constexpr bool DEFER = NP >= 2 && NLT + NST <= 2;
   static constexpr int OPC = NCH / 2;       // chunks of the last panel that carry epilogue-operand loads
   static constexpr int HPC = 8 / OPC;       // half-blocks per such chunk
   static constexpr int XW = NCH - 3;        // chunk that moves the next panel registers -> LDS
@@ -229,7 +232,7 @@ struct WideEpi {
   __device__ __forceinline__ WideEpi(const LinArgs& a_, int lane) : a(a_), colw_loaded(-1) {
     const int l31 = lane & 31, hh = lane >> 5;
     vY = (unsigned)((4 * hh * a.ldY + l31) * 4);
-    vY2 = NST == 2 ? (unsigned)((4 * hh * a.ldY2 + l31) * 4) : 0u;
+    vY2 = NST == 2 ? (unsigned)((4 * hh * (a.Y2 ? a.ldY2 : a.ldY) + l31) * 4) : 0u;   // absent Y2 (fused chains): Y again
     vL0 = (EPI != EPI_ACT) ? (unsigned)((4 * hh * a.ldS + l31) * 4) : 0u;
     vL1 = (EPI == EPI_CHAIN) ? (unsigned)((4 * hh * a.ldR + l31) * 4) : (EPI == EPI_DACT && F1) ? (unsigned)((4 * hh * a.ldQ + l31) * 4) : 0u;
     vRS = (unsigned)(16 * hh);
@@ -246,8 +249,8 @@ struct WideEpi {
     for (int j = 0; j < 2; ++j) {
       const int col = colw + 32 * j + l31;
       bcol[j] = a.bias ? a.bias[col] : 0.f;
-      wsig[j] = F2 ? a.rowscale_w[col] : 0.f;
-      wfc[j] = F1 ? a.R[col] : 0.f;
+      wsig[j] = (F2 && a.rowscale_w) ? a.rowscale_w[col] : 0.f;
+      wfc[j] = (F1 && a.R) ? a.R[col] : 0.f;
     }
   }
 
@@ -267,7 +270,7 @@ struct WideEpi {
     const int r0 = row0 + 32 * I + 16 * H;
     const int c0 = colw + 32 * J;
     if (EPI == EPI_ACT) {   // sigma of the row
-      const float* p = a.rowscale + r0;
+      const float* p = (a.rowscale ? a.rowscale : a.src[0].x) + r0;
       gload1<0>(l0[0], vRS, p); gload1<4>(l0[1], vRS, p); gload1<8>(l0[2], vRS, p); gload1<12>(l0[3], vRS, p);
       gload1<32>(l0[4], vRS, p); gload1<36>(l0[5], vRS, p); gload1<40>(l0[6], vRS, p); gload1<44>(l0[7], vRS, p);
       return;
@@ -300,8 +303,9 @@ struct WideEpi {
       const float v = acc16[8 * H + e];
       float y, y2 = 0.f;
       if (EPI == EPI_ACT) {
-        y = act_fwd<ACT>(F2 ? __builtin_fmaf(l0[e], wsig[J], v + brow) : v + brow);
-        if (F1) y2 = -wfc[J] * act_d1<ACT>(y);
+        // a fused chain instantiates F1/F2 for all its layers; a layer without the operand skips it (uniform select)
+        y = act_fwd<ACT>((F2 && a.rowscale) ? __builtin_fmaf(l0[e], wsig[J], v + brow) : v + brow);
+        if (F1) y2 = a.Y2 ? -wfc[J] * act_d1<ACT>(y) : y;
       } else if (EPI == EPI_DACT) {
         y = v * act_d1<ACT>(l0[e]) + (F1 ? l1[e] : 0.f);
       } else {
@@ -327,11 +331,12 @@ struct WideEpi {
       py += (e == 3) ? (size_t)5 * a.ldY : (size_t)a.ldY;
     }
     if (NST == 2) {
-      float* p2 = a.Y2 + (size_t)r0 * a.ldY2 + c0;
+      const int ld2 = a.Y2 ? a.ldY2 : a.ldY;
+      float* p2 = (a.Y2 ? a.Y2 : a.Y) + (size_t)r0 * ld2 + c0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         gstore1(vY2, y2[e], p2);
-        p2 += (e == 3) ? (size_t)5 * a.ldY2 : (size_t)a.ldY2;
+        p2 += (e == 3) ? (size_t)5 * ld2 : (size_t)ld2;
       }
     }
   }
@@ -377,6 +382,8 @@ struct PanelCtx {
   const EPI_T& epi;
   unsigned raddr, raddr_next, waddr_next, bvoff;
   int tid, row0, colw, prev_row0;   // prev_row0 < 0: no previous tile (nothing to store yet)
+  const LinArgs* prev;              // layer whose results the deferred stores carry (the same layer outside of fused chains)
+  unsigned pvY, pvY2;               // its per-lane store offsets
 };
 
 // One chunk of panel P: wait for its fragments, then 16 MFMAs with the chunk's memory instructions spread evenly behind
@@ -385,14 +392,18 @@ struct PanelCtx {
 // the issue order Sched assumes:
 //   2 fragment reads A(c+1) | 2 weight loads B(c+3) | c == 0: NX panel loads | NX panel LDS writes (c == XW)
 //   | 8*NST deferred stores | last panel: 2 row-bias loads, HPC*8*NLT epilogue-operand loads
-template <int C, int P, int NCH, int NP, bool HP, class EPI_T>
+// XLDS: the layer's whole activation tile (64 rows x K, row stride FC_TLD floats) already sits in LDS (fused chains:
+// written there by the previous layer's epilogue) - no panel loads, no ring, no barrier inside the K loop.
+constexpr int FC_TLD = 260;
+template <int C, int P, int NCH, int NP, bool HP, class EPI_T, bool XLDS = false>
 struct ChunkOps {
-  using SC = Sched<NCH, NP, EPI_T::NLT, EPI_T::NST, HP>;
+  using SC = Sched<NCH, NP, EPI_T::NLT, EPI_T::NST, HP, XLDS ? 0 : PanelGeo<NCH>::NX>;
   static constexpr int NX = PanelGeo<NCH>::NX;
   static constexpr int NLT = EPI_T::NLT, NST = EPI_T::NST;
   static constexpr bool LAST = P == NP - 1;
   static constexpr int SHB = SC::store_hb(P, C);
-  static constexpr int n_a = 2, n_b = 2, n_x = C == 0 ? NX : 0, n_w = C == SC::XW ? NX : 0, n_st = SHB >= 0 ? 8 * NST : 0,
+  static constexpr int n_a = (XLDS && LAST && C == NCH - 1) ? 0 : 2;   // no next chunk inside this layer's tile
+  static constexpr int n_b = 2, n_x = (C == 0 && !XLDS) ? NX : 0, n_w = (C == SC::XW && !XLDS) ? NX : 0, n_st = SHB >= 0 ? 8 * NST : 0,
                        n_rb = (LAST && C == 0) ? 2 : 0, n_op = (LAST && C < SC::OPC) ? SC::HPC * 8 * NLT : 0;
   static constexpr int o_a = 0, o_b = o_a + n_a, o_x = o_b + n_b, o_w = o_x + n_x, o_st = o_w + n_w, o_rb = o_st + n_st,
                        o_op = o_rb + n_rb, total = o_op + n_op;
@@ -413,7 +424,8 @@ struct ChunkOps {
     const LinArgs& a = x.epi.a;
     if constexpr (K < o_b) {   // fragment read of the next chunk (chunk 0 of the next panel after the last one)
       constexpr int i = K - o_a;
-      if constexpr (C + 1 < NCH) lds_read4<(C + 1) * 32 + i * 32 * WLDW * 4>(A[(C + 1) & 1][i], x.raddr);
+      if constexpr (XLDS) lds_read4<(P * NCH + C + 1) * 32 + i * 32 * FC_TLD * 4>(A[(C + 1) & 1][i], x.raddr);
+      else if constexpr (C + 1 < NCH) lds_read4<(C + 1) * 32 + i * 32 * WLDW * 4>(A[(C + 1) & 1][i], x.raddr);
       else lds_read4<i * 32 * WLDW * 4>(A[0][i], x.raddr_next);
     } else if constexpr (K < o_x) {
       constexpr int j = K - o_b;
@@ -431,14 +443,16 @@ struct ChunkOps {
     } else if constexpr (K < o_rb) {
       constexpr int k = K - o_st, tns = k / 8, e = k % 8;
       constexpr int J = SHB >> 2, I = (SHB >> 1) & 1, H = SHB & 1;
+      const LinArgs& pa = *x.prev;
       if constexpr (tns == 0) {
-        if constexpr (e == 0) q.py = a.Y + (size_t)(x.prev_row0 + 32 * I + 16 * H) * a.ldY + x.colw + 32 * J;
-        gstore1(x.epi.vY, l0[8 * SHB + e], q.py);
-        q.py += (e == 3) ? (size_t)5 * a.ldY : (size_t)a.ldY;
+        if constexpr (e == 0) q.py = pa.Y + (size_t)(x.prev_row0 + 32 * I + 16 * H) * pa.ldY + x.colw + 32 * J;
+        gstore1(x.pvY, l0[8 * SHB + e], q.py);
+        q.py += (e == 3) ? (size_t)5 * pa.ldY : (size_t)pa.ldY;
       } else {
-        if constexpr (e == 0) q.py2 = a.Y2 + (size_t)(x.prev_row0 + 32 * I + 16 * H) * a.ldY2 + x.colw + 32 * J;
-        gstore1(x.epi.vY2, l1[8 * SHB + e], q.py2);
-        q.py2 += (e == 3) ? (size_t)5 * a.ldY2 : (size_t)a.ldY2;
+        const int ld2 = pa.Y2 ? pa.ldY2 : pa.ldY;
+        if constexpr (e == 0) q.py2 = (pa.Y2 ? pa.Y2 : pa.Y) + (size_t)(x.prev_row0 + 32 * I + 16 * H) * ld2 + x.colw + 32 * J;
+        gstore1(x.pvY2, l1[8 * SHB + e], q.py2);
+        q.py2 += (e == 3) ? (size_t)5 * ld2 : (size_t)ld2;
       }
     } else if constexpr (K < o_op) {
       constexpr int k = K - o_rb;
@@ -450,7 +464,7 @@ struct ChunkOps {
       constexpr int J = HB >> 2, I = (HB >> 1) & 1, H = HB & 1;
       if constexpr (EPI_T::SIGMA_OPERAND) {   // EPI_ACT with a per-row scale: sigma of the row
         constexpr int off = ((e & 3) + 8 * (e >> 2)) * 4;
-        gload1<off>(l0[8 * HB + e], x.epi.vRS, a.rowscale + x.row0 + 32 * I + 16 * H);
+        gload1<off>(l0[8 * HB + e], x.epi.vRS, (a.rowscale ? a.rowscale : a.src[0].x) + x.row0 + 32 * I + 16 * H);
       } else if constexpr (tns == 0) {
         if constexpr (e == 0) q.p0 = a.S + (size_t)(x.row0 + 32 * I + 16 * H) * a.ldS + x.colw + 32 * J;
         gload1<0>(l0[8 * HB + e], x.epi.vL0, q.p0);
@@ -492,25 +506,25 @@ struct ChunkOps {
                                              float* l1, float (&rb)[2], const PanelCtx<NCH, EPI_T>& x) {
     constexpr int bslot = C % (BDEPTH + 1);
     wait_frag<SC::vm_frag(P, C)>(A[C & 1][0], A[C & 1][1], B[bslot][0], B[bslot][1]);
-    if (C == SC::BAR) __builtin_amdgcn_s_barrier();   // the wait above covered this wave's ds_writes (lgkmcnt(0))
+    if (C == SC::BAR && !XLDS) __builtin_amdgcn_s_barrier();   // the wait above covered this wave's ds_writes (lgkmcnt(0))
     __builtin_amdgcn_sched_barrier(0);
     Ptrs q{nullptr, nullptr, nullptr, nullptr};
     steps<0>(acc, A, B, xv, l0, l1, rb, x, q);
   }
 };
 
-template <int P, int NCH, int NP, bool HP, class EPI_T>
+template <int P, int NCH, int NP, bool HP, class EPI_T, bool XLDS = false>
 __device__ __forceinline__ void panel(f32x16 (&acc)[2][2], f32x4 (&A)[2][2], f32x4 (&B)[BDEPTH + 1][2], f32x4 (&xv)[PanelGeo<NCH>::NX],
                                       float* l0, float* l1, float (&rb)[2], const PanelCtx<NCH, EPI_T>& x) {
-  ChunkOps<0, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
-  ChunkOps<1, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
-  ChunkOps<2, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
-  ChunkOps<3, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
+  ChunkOps<0, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
+  ChunkOps<1, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
+  ChunkOps<2, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
+  ChunkOps<3, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
   if constexpr (NCH == 8) {
-    ChunkOps<4, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
-    ChunkOps<5, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
-    ChunkOps<6, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
-    ChunkOps<7, P, NCH, NP, HP, EPI_T>::run(acc, A, B, xv, l0, l1, rb, x);
+    ChunkOps<4, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
+    ChunkOps<5, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
+    ChunkOps<6, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
+    ChunkOps<7, P, NCH, NP, HP, EPI_T, XLDS>::run(acc, A, B, xv, l0, l1, rb, x);
   }
 }
 
@@ -529,7 +543,8 @@ __device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][2], f32x4 (&A)[2][2
     s.bnxt[1] = panel_b(tn, pn, 1);
     s.xnxt = panel_x(tn, pn, s.ldnxt);
     const int bnext = buf + 1 == NBUF ? 0 : buf + 1;
-    const PanelCtx<NCH, EPI_T> x{s, epi, rlane + buf * WBUF_BYTES, rlane + bnext * WBUF_BYTES, wlane + bnext * WBUF_BYTES, bvoff, tid, row0, colw, prev_row0};
+    const PanelCtx<NCH, EPI_T> x{s, epi, rlane + buf * WBUF_BYTES, rlane + bnext * WBUF_BYTES, wlane + bnext * WBUF_BYTES, bvoff, tid, row0, colw, prev_row0,
+                                 &epi.a, epi.vY, epi.vY2};
     panel<P, NCH, NP, HP>(acc, A, B, xv, l0, l1, rb, x);
     s.bcur[0] = s.bnxt[0];
     s.bcur[1] = s.bnxt[1];

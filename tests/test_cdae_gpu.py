@@ -173,6 +173,14 @@ def test_cdae_loss_grads_vs_oracle(kind, B, S, z, h, L):
     assert_grads_close(gs, ref_g, g64, [n for n, _ in O.cdae_param_spec(cc)])
 
 
+@pytest.mark.parametrize("kind", ["grad", "res"])
+def test_cdae_loss_grads_vs_oracle_nrow_kernels(kind):
+    """Config #2 widths (h=256, L=3, z=32) with 8192 rows (B=32, nz=256): the smallest size that runs the production
+    N-row kernels - the software-pipelined wide linear kernel, the fused layer chains and the 256x256 / 256x32
+    weight-gradient kernels - instead of the generic ones.  Same oracle comparison as above."""
+    test_cdae_loss_grads_vs_oracle(kind, 32, 256, 32, 256, 3)
+
+
 def test_cdae_cfg2_golden_summaries(golden_dir):
     """Full-width config #2 network (h=256, L=3, z=32) at B=8, nz=16: parameters regenerated from the seed."""
     fx = load(golden_dir, "cfg2_b8_nz16")

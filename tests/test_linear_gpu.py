@@ -101,9 +101,17 @@ def test_linear_transposed_pack_and_two_sources():
     assert relerr(Y, X1.double() @ Wt.double()) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,Nout", [(8192, 256, 256), (24576, 256, 256), (65536, 256, 256), (16384, 32, 256)])
+@pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
+def test_linear_wide_kernel_epilogues(M, K, Nout, epi):
+    """The software-pipelined N-row kernel (linear_wide_kernel: >= 128 tiles of 64 rows, K in {256, 32}): one tile per
+    workgroup (8192 rows), one or two (24576: deferred stores carried into the next tile), four (65536)."""
+    test_linear_warp_specialised_epilogues(M, K, Nout, epi, rpg=64)
+
+
 @pytest.mark.parametrize("M,K,Nout", [(4096, 256, 256), (12288, 32, 256), (4096, 256, 128)])
 @pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
-def test_linear_warp_specialised_epilogues(M, K, Nout, epi):
+def test_linear_warp_specialised_epilogues(M, K, Nout, epi, rpg=16):
     """Same operators on the persistent warp-specialised kernel (M >= 4096, K % 32 == 0)."""
     g = torch.Generator().manual_seed(M + K + Nout)
     X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5
@@ -126,9 +134,9 @@ def test_linear_warp_specialised_epilogues(M, K, Nout, epi):
         assert relerr(Y2, v * R.double() * (1 - s1)) < 2e-5
     else:
         w = torch.randn(Nout, generator=g); b = torch.randn(Nout, generator=g)
-        rb = torch.randn(M // 16, Nout, generator=g); sig = torch.randn(M, generator=g); wsig = torch.randn(Nout, generator=g)
-        pre = v + b.double() + rb.double().repeat_interleave(16, 0) + sig.double()[:, None] * wsig.double()
-        run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), wpk)], act=2, bias=b.cuda(), rowbias=rb.cuda(), rows_per_group=16,
+        rb = torch.randn(M // rpg, Nout, generator=g); sig = torch.randn(M, generator=g); wsig = torch.randn(Nout, generator=g)
+        pre = v + b.double() + rb.double().repeat_interleave(rpg, 0) + sig.double()[:, None] * wsig.double()
+        run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), wpk)], act=2, bias=b.cuda(), rowbias=rb.cuda(), rows_per_group=rpg,
                    rowscale=sig.cuda(), rowscale_w=wsig.cuda(), R=w.cuda(), Y=Y, Y2=Y2)
         assert relerr(Y, torch.nn.functional.softplus(pre)) < 2e-5
         assert relerr(Y2, -w.double() * torch.sigmoid(pre)) < 2e-5
