@@ -155,11 +155,15 @@ __global__ __launch_bounds__(256, 1) void linear_fchain_kernel(const FcArgs c) {
       const float* x = c.a[0].src[0].x + (size_t)row0 * ld;
       float* in = lds + k.buf * (WBM * FC_TLD);
       const int r = tid >> 6, c4 = tid & 63;
-      f32x4 v[16];
+      // four rounds of four float4 per thread: the previous tile's results may still occupy 64 registers (deferred stores)
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v[4];
 #pragma unroll
-      for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const f32x4*>(x + (size_t)(4 * p + r) * ld + c4 * 4);
+        for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const f32x4*>(x + (size_t)(16 * q + 4 * p + r) * ld + c4 * 4);
 #pragma unroll
-      for (int p = 0; p < 16; ++p) *reinterpret_cast<f32x4*>(in + (4 * p + r) * FC_TLD + c4 * 4) = v[p];
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(in + (16 * q + 4 * p + r) * FC_TLD + c4 * 4) = v[p];
+      }
       __syncthreads();
     }
     fc_layers<0, NL, EPI_T>(c, A, B, xv, l0, l1, rb, s, k, lds, rlane, bvoff, tid, lane, wave, row0, colw, tile, tile == (int)blockIdx.x);

@@ -109,6 +109,40 @@ def test_linear_wide_kernel_epilogues(M, K, Nout, epi):
     test_linear_warp_specialised_epilogues(M, K, Nout, epi, rpg=64)
 
 
+@pytest.mark.parametrize("epi", ["act", "dact_q", "chain"])
+def test_linear_wide_kernel_full_size_matches_generic_kernel(epi):
+    """BASELINE config #2 size (131072 rows = 512 images x 256 samples, 8 tiles per workgroup): the software-pipelined
+    kernel against the generic kernel on the same data.  The generic path is forced by a 4-byte-misaligned copy of X (the
+    wide kernel needs 16-byte aligned rows); both are fp32 fmaf chains over k in the same order, so they agree to rounding
+    of the epilogue only."""
+    M, K, Nout = 131072, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(7)
+    X = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(Nout, K, device="cuda", generator=g) / K ** 0.5
+    S = torch.nn.functional.softplus(torch.randn(M, Nout, device="cuda", generator=g) * 3)
+    Q = torch.randn(M, Nout, device="cuda", generator=g); R = torch.randn(M, Nout, device="cuda", generator=g)
+    b = torch.randn(Nout, device="cuda", generator=g)
+    Xu = torch.empty(M * K + 1, device="cuda")[1:].view(M, K)   # same values, rows start 4 bytes off a 16-byte boundary
+    Xu.copy_(X)
+    wpk = pack(W)
+    outs = []
+    for x in (X, Xu):
+        Y = torch.full((M, Nout), float("nan"), device="cuda"); Y2 = torch.full((M, Nout), float("nan"), device="cuda")
+        if epi == "act":
+            run_linear(L.EPI_ACT, M, Nout, [(x, wpk)], act=2, bias=b, Y=Y)
+        elif epi == "dact_q":
+            Y.copy_(Q)
+            run_linear(L.EPI_DACT, M, Nout, [(x, wpk)], act=2, S=S, Q=Y, Y=Y)       # in place
+        else:
+            run_linear(L.EPI_CHAIN, M, Nout, [(x, wpk)], act=2, S=S, R=R, Y=Y, Y2=Y2)
+        outs.append((Y, Y2))
+    (Ya, Y2a), (Yb, Y2b) = outs
+    assert not torch.isnan(Ya).any()
+    assert float((Ya - Yb).abs().max() / Yb.abs().max()) < 2e-6
+    if epi == "chain":
+        assert float((Y2a - Y2b).abs().max() / Y2b.abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize("M,K,Nout", [(4096, 256, 256), (12288, 32, 256), (4096, 256, 128)])
 @pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
 def test_linear_warp_specialised_epilogues(M, K, Nout, epi, rpg=16):
