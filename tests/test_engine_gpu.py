@@ -122,6 +122,41 @@ def test_engine_trajectory_golden(golden_dir, name):
             break   # summaries-only fixtures: parameters cannot be re-synchronised, so only the first step is comparable
 
 
+@pytest.mark.parametrize("kind", ["grad", "res"])
+def test_engine_step_production_kernels_vs_oracle(kind):
+    """Config #2 network (784 / 100 / h 256 / z 32, cDAE h 256 L 3) on 128 images x 256 samples = 32768 rows: the size from
+    which every N-row launch runs on the production kernels (software-pipelined linear, 256x256 / 256x32 weight
+    gradients) instead of the generic ones the small fixtures exercise.  One full step (cDAE update + VAE update) against
+    the oracle run live on the CPU with the same parameters, images and noise."""
+    mc = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
+    cc = O.CdaeCfg(kind, 32, 32, 256, 3)
+    tc = O.TrainCfg(nz_cdae=256)
+    B = 128
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc))
+    pc = O.init_params(O.cdae_param_spec(cc), 1)
+    gen = torch.Generator().manual_seed(11)
+    x1 = torch.bernoulli(torch.full((B, 784), 0.2), generator=gen)
+    x2 = torch.bernoulli(torch.full((B, 784), 0.2), generator=gen)
+    noise = O.draw_step_noise(mc, tc, B, gen)
+    model, cdae = build(mc, cc)
+    model.load_state_dict(pm); cdae.load_state_dict(pc)
+    model, cdae = model.to("cuda"), cdae.to("cuda")
+    before_c, before_m = cdae.flat_params().clone().cpu(), model.flat_params().clone().cpu()
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=256), batch_size=B)
+    eng.step(x1.cuda(), x2.cuda(), noise={k: v.cuda().contiguous() for k, v in noise.items()})
+    got = eng.stats()
+    rm, rc = {k: v.clone() for k, v in pm.items()}, {k: v.clone() for k, v in pc.items()}
+    ref = O.train_step(mc, cc, tc, rm, rc, {}, {}, x1, x2, noise)
+    for k in ("cdae_loss", "model_loss"):
+        assert rel(got[k], ref[k]) < 1e-4, k
+    for k in ("recon", "prior"):
+        assert rel(got[k], ref[k]) < 2e-5, k
+    ref_c = torch.cat([rc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)])
+    ref_m = torch.cat([rm[n].reshape(-1) for n, _ in O.model_param_spec(mc)])
+    assert_update_close(cdae.flat_params().cpu(), before_c, ref_c, "cdae update")
+    assert_update_close(model.flat_params().cpu(), before_m, ref_m, "model update")
+
+
 @pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res"])
 def test_vae_phase_grads_golden(golden_dir, name):
     mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, name)
