@@ -31,6 +31,13 @@ constexpr int WIDE_KPANEL = ARDAE_WIDE_KPANEL;
 #define ARDAE_WIDE_MINB 3
 #endif
 constexpr int WIDE_MINB = ARDAE_WIDE_MINB;
+// small-M geometry (per-image layers, a few hundred rows): these launches are pure latency - stage the whole K (up to
+// 256) in one panel, so a 256-wide layer pays ONE exposed HBM/L2 round trip instead of four (22 -> ~10 us per launch)
+#ifndef ARDAE_SMALLM_KPANEL
+#define ARDAE_SMALLM_KPANEL 256
+#endif
+constexpr int SMALLM_KPANEL = ARDAE_SMALLM_KPANEL;
+constexpr int SMALLM_MINB = SMALLM_KPANEL > 64 ? 2 : 4;
 
 template <int TM, int TN, int WM, int WN, int KPANEL>
 struct Geo {
@@ -196,6 +203,23 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
 #endif
   int cs = 0, ck0 = 0;
   Panel cur = make_panel(0, 0);
+  // Small-M geometry with 256-wide panels (per-image layers): the launch is latency, not throughput - put ALL 32 weight
+  // fragments of a full panel in flight at once (128 registers), for the first panel even before the activations are
+  // staged, instead of one L2 round trip per 8-deep chunk.
+  constexpr bool ALLB = TM == 1 && TN == 1 && KPANEL == 256 && !TR;
+  f32x4 ball[ALLB ? 32 : 1];
+  bool ball_valid = false;
+  auto load_all_b = [&](const Panel& p) {
+    const int nb = min(nb0, nblk_total - 1);
+    const float* bp = p.wp + ((size_t)nb * p.kchunks + (p.k0 >> 3)) * 256 + lane * 4;
+#pragma unroll
+    for (int c = 0; c < (ALLB ? 32 : 1); ++c) ball[c] = *reinterpret_cast<const f32x4*>(bp + (size_t)c * 256);
+  };
+  if (ALLB && wave_active && (cur.kw8 >> 3) == 32) {
+    load_all_b(cur);
+    ball_valid = true;
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (cur.fast) { panel_load(cur); panel_store(cur, lds); } else panel_stage_slow(cur, lds);
   __syncthreads();
 #ifdef ARDAE_STAMPS
@@ -230,9 +254,27 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
       }
       // weight fragments: two register sets, the other one is always in flight (L2 latency behind 16 MFMAs)
       f32x4 be[TN], bo[TN], av[TM];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) be[j] = *reinterpret_cast<const f32x4*>(bptr[j]);
       int kc = 0;
+      if (ALLB && nch == 32) {
+        if (!ball_valid) {
+          load_all_b(cur);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ball_valid = false;
+        f32x4 a2[2];
+        a2[0] = *reinterpret_cast<const f32x4*>(arow[0]);
+#pragma unroll
+        for (int c = 0; c < (ALLB ? 32 : 1); ++c) {
+          if (c + 1 < 32) a2[(c + 1) & 1] = *reinterpret_cast<const f32x4*>(arow[0] + (c + 1) * 8);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[c & 1][q], ball[c][q], acc[0][0], 0, 0, 0);
+        }
+        kc = nch;   // the generic loops below find nothing left
+      }
+      if (kc < nch) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) be[j] = *reinterpret_cast<const f32x4*>(bptr[j]);
+      }
       for (; kc + 1 < nch; kc += 2) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bo[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)(kc + 1) * 256);
@@ -379,13 +421,13 @@ template <int EPI, int ACT>
 __device__ __forceinline__ void chain_layer(const LinArgs& a, int bx, float* lds, float* red) {
   const int nby = (a.Nout + 127) >> 7;
   for (int by = 0; by < nby; ++by) {
-    linear_tile<1, 1, 1, 4, 64, EPI, ACT, false>(a, bx, by, nby, lds, red);
+    linear_tile<1, 1, 1, 4, SMALLM_KPANEL, EPI, ACT, false>(a, bx, by, nby, lds, red);
     __syncthreads();   // the next tile restages the LDS panels
   }
 }
 
-__global__ __launch_bounds__(256, 4) void linear_chain_kernel(const LinChainDev c) {
-  __shared__ float lds[Geo<1, 1, 1, 4, 64>::LDS_FLOATS];
+__global__ __launch_bounds__(256, SMALLM_MINB) void linear_chain_kernel(const LinChainDev c) {
+  __shared__ float lds[Geo<1, 1, 1, 4, SMALLM_KPANEL>::LDS_FLOATS];
   __shared__ float red[4];
   const int bx = blockIdx.x;
   for (int li = 0; li < c.n; ++li) {
@@ -512,7 +554,7 @@ int launch_epi(const LinArgs& a, hipStream_t st) {
       ARDAE_CHECK_ARG(a.colsum == nullptr, "linear: colsum is not available in the narrow (Nout<=32) geometry");
       return launch_geo<1, 1, 4, 1, 64, EPI, ACT, 2>(a, st);
     case 1:
-      return launch_geo<1, 1, 1, 4, 64, EPI, ACT, 4>(a, st);
+      return launch_geo<1, 1, 1, 4, SMALLM_KPANEL, EPI, ACT, SMALLM_MINB>(a, st);
     default:
       if (EPI != EPI_DAE_LOSS && tr_eligible(a, EPI)) return launch_geo<2, 2, 1, 4, WIDE_KPANEL, EPI, ACT, WIDE_MINB, true>(a, st);
       return launch_geo<2, 2, 1, 4, WIDE_KPANEL, EPI, ACT, WIDE_MINB>(a, st);
