@@ -87,7 +87,7 @@ class ArdaeEngine:
         self.use_graph = bool(graph) and os.environ.get("ARDAE_GRAPH", "1") != "0" and \
             (self.world == 1 or os.environ.get("ARDAE_GRAPH_DP") == "1")
         self._graph, self._graph_key, self._xc, self._xv = None, None, None, None
-        self._in_step, self._draws = False, 0
+        self._in_step, self._draws, self._warmed = False, 0, False
         self.repack()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -206,9 +206,10 @@ class ArdaeEngine:
             key = (b, tuple(self._xc.shape), tuple(self._xv.shape))
             if self._graph is not None and self._graph_key == key:
                 self._graph.replay()
-            elif self.step_count == 0:
-                # first iteration eagerly: every kernel gets loaded outside of a capture
+            elif not self._warmed:
+                # first iteration of this engine eagerly: every kernel gets loaded outside of a capture
                 self._step_body([self._xc], self._xv, None, b)
+                self._warmed = True
             else:
                 g = torch.cuda.CUDAGraph()
                 try:
@@ -228,6 +229,76 @@ class ArdaeEngine:
         xs = x_cdae if many else [x_cdae] * self.cfg.num_cdae_updates
         self._step_body(xs, x_vae, noise, beta)
         self.step_count += 1
+
+    # ------------------------------------------------------------------------------------------------------------
+    # Checkpoints in the reference's format (ivae_ardae.py:931-950,1120-1139; utils/msc.py:67-93): one dict per network with
+    # 'state_dict' and 'optimizer' (torch.optim.Optimizer.state_dict() layout: per-parameter 'step' / 'exp_avg' / 'exp_avg_sq',
+    # resp. 'step' / 'square_avg' / 'momentum_buffer', and 'param_groups'), so that files written by the reference loop, by the
+    # drop-in modules + net.Adam / net.RMSprop, and by the fused engine are interchangeable.  The caller adds its own
+    # bookkeeping keys ('epoch', 'batch_idx', 'best_val_loss', ...) exactly as the reference does.
+    def _per_param(self, module, flat, n_used):
+        out, off = [], 0
+        for name, p in module.named_parameters():
+            k = p.numel()
+            out.append(flat[off:off + k].view_as(p) if off + k <= n_used else None)
+            off += k
+        return out
+
+    def model_checkpoint(self):
+        cfg = self.cfg
+        m, v = self._per_param(self.model, self.m_m, self.m_m.numel()), self._per_param(self.model, self.v_m, self.v_m.numel())
+        state = {i: {"step": self.step_count, "exp_avg": m[i].clone(), "exp_avg_sq": v[i].clone()} for i in range(len(m))} if self.step_count else {}
+        return {"state_dict": {k: t.clone() for k, t in self.model.state_dict().items()},
+                "optimizer": {"state": state,
+                              "param_groups": [{"lr": cfg.m_lr, "betas": (cfg.m_beta1, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                                                "params": list(range(len(m)))}]},
+                "engine": {"step_count": self.step_count, "rng_seed": rng.get_state()["seed"], "step_state": self.state.cpu().clone()}}
+
+    def cdae_checkpoint(self):
+        cfg = self.cfg
+        sq, buf = self._per_param(self.cdae, self.sq_c, self.n_c), self._per_param(self.cdae, self.buf_c, self.n_c)
+        state = {}
+        if self.step_count:
+            for i in range(len(sq)):
+                if sq[i] is not None:   # neglogprob.fc.bias gets no gradient in the reference: no state (graddae/mlp.py:437)
+                    state[i] = {"step": self.step_count * cfg.num_cdae_updates, "square_avg": sq[i].clone(), "momentum_buffer": buf[i].clone()}
+        return {"state_dict": {k: t.clone() for k, t in self.cdae.state_dict().items()},
+                "optimizer": {"state": state,
+                              "param_groups": [{"lr": cfg.d_lr, "momentum": cfg.d_momentum, "alpha": 0.99, "eps": 1e-8, "centered": False,
+                                                "weight_decay": 0, "params": list(range(len(sq)))}]}}
+
+    def load_checkpoints(self, model_ckpt, cdae_ckpt):
+        """Inverse of model_checkpoint() / cdae_checkpoint(); also accepts files written by the reference loop."""
+        self.model.load_state_dict(model_ckpt["state_dict"])
+        self.cdae.load_state_dict(cdae_ckpt["state_dict"])
+        mst, cst = model_ckpt["optimizer"]["state"], cdae_ckpt["optimizer"]["state"]
+        steps = {int(s["step"]) for s in mst.values()}
+        if len(steps) > 1:
+            raise ValueError("the fused engine keeps one Adam step count for all parameters")
+        self.m_m.zero_(); self.v_m.zero_(); self.sq_c.zero_(); self.buf_c.zero_()
+        with torch.no_grad():
+            for i, t in enumerate(self._per_param(self.model, self.m_m, self.m_m.numel())):
+                if i in mst:
+                    t.copy_(mst[i]["exp_avg"])
+            for i, t in enumerate(self._per_param(self.model, self.v_m, self.v_m.numel())):
+                if i in mst:
+                    t.copy_(mst[i]["exp_avg_sq"])
+            for i, t in enumerate(self._per_param(self.cdae, self.sq_c, self.n_c)):
+                if t is not None and i in cst:
+                    t.copy_(cst[i]["square_avg"])
+            for i, t in enumerate(self._per_param(self.cdae, self.buf_c, self.n_c)):
+                if t is not None and i in cst and cst[i].get("momentum_buffer") is not None:
+                    t.copy_(cst[i]["momentum_buffer"])
+        self.step_count = steps.pop() if steps else 0
+        eng = model_ckpt.get("engine")
+        if eng is not None:     # written by this engine: continue the same noise stream
+            rng.manual_seed(eng["rng_seed"], rng.get_state()["offset"])
+            self.state.copy_(eng["step_state"].to(self.dev))
+        else:                   # written by the reference / the module path: only Adam's t matters
+            self.state.zero_()
+        self.state[1] = self.step_count
+        self._graph = None      # parameters were rewritten outside of the captured step
+        self.repack()
 
     def stats(self):
         """Host copy of the logged scalars of ivae_ardae.py:756-758,774,837-841 (this is the only synchronising call)."""

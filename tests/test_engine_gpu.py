@@ -325,3 +325,49 @@ def test_iwae_logprob_golden(golden_dir):
         model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=8)      # needs sample_size >= 2 z_dim (ivae/mnist.py:382)
     _, mean, z = model.generate(5)
     assert mean.shape == (5, 24) and z.shape == (5, 8) and bool((mean >= 0).all() and (mean <= 1).all())
+
+
+def test_engine_checkpoint_roundtrip_reference_format(tmp_path):
+    """the fused engine writes / reads the reference's checkpoint dicts ('state_dict' + 'optimizer' in
+    torch.optim layout, ivae_ardae.py:931-950).  A resumed engine continues bit-identically (parameters, optimiser state,
+    noise stream); the optimiser dicts load into the drop-in optimisers; the files survive torch.load(weights_only=True)."""
+    mc = O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus")
+    cc = O.CdaeCfg("grad", 8, 8, 64, 3)
+    B = 8
+
+    def fresh(seed_params):
+        model, cdae = build(mc, cc)
+        if seed_params:
+            model.load_state_dict(O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc)))
+            cdae.load_state_dict(O.init_params(O.cdae_param_spec(cc), 1))
+        model, cdae = model.to("cuda"), cdae.to("cuda")
+        return model, cdae, net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=16), batch_size=B)
+
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.bernoulli(torch.full((B, 24), 0.3), generator=g).cuda() for _ in range(6)]
+    net.manual_seed(123)
+    model, cdae, eng = fresh(True)
+    eng.step(xs[0], xs[1]); eng.step(xs[2], xs[3])
+    mck, cck = eng.model_checkpoint(), eng.cdae_checkpoint()
+    # same top-level keys as the reference's files (plus the engine's RNG bookkeeping), tensor-only payload
+    torch.save(mck, tmp_path / "model.pth.tar"); torch.save(cck, tmp_path / "cdae.pth.tar")
+    mck2 = torch.load(tmp_path / "model.pth.tar", weights_only=True); cck2 = torch.load(tmp_path / "cdae.pth.tar", weights_only=True)
+    assert list(mck2["state_dict"]) == [n for n, _ in O.model_param_spec(mc)]
+    assert set(cck2["optimizer"]["state"]) == set(range(len(O.cdae_param_spec(cc)) - 1))      # no state for neglogprob.fc.bias
+    eng.step(xs[4], xs[5])
+    want_m, want_c = model.flat_params().clone(), cdae.flat_params().clone()
+
+    model_b, cdae_b, eng_b = fresh(False)
+    eng_b.load_checkpoints(mck2, cck2)
+    assert eng_b.step_count == 2
+    eng_b.step(xs[4], xs[5])
+    assert torch.equal(model_b.flat_params(), want_m) and torch.equal(cdae_b.flat_params(), want_c)
+
+    # interchangeable with the drop-in optimisers (and hence with the reference's utils.Adam / torch RMSprop layouts)
+    model_c, cdae_c = build(mc, cc)
+    model_c, cdae_c = model_c.to("cuda"), cdae_c.to("cuda")
+    m_opt = net.Adam(model_c.parameters(), lr=1e-4, betas=(0.5, 0.999)); c_opt = net.RMSprop(cdae_c.parameters(), lr=1e-4, momentum=0.5)
+    m_opt.load_state_dict(mck2["optimizer"]); c_opt.load_state_dict(cck2["optimizer"])
+    st = m_opt.state_dict()["state"]
+    assert int(st[0]["step"]) == 2 and torch.equal(st[0]["exp_avg"].cpu(), mck2["optimizer"]["state"][0]["exp_avg"].cpu())
+    assert m_opt.state_dict()["param_groups"][0]["betas"] == (0.5, 0.999) or list(m_opt.state_dict()["param_groups"][0]["betas"]) == [0.5, 0.999]
