@@ -8,6 +8,7 @@ The compute is libardae_hip.so (hand-written HIP for gfx950, C ABI in include/ar
 """
 from . import _lib  # noqa: F401
 from . import rng  # noqa: F401
+from . import data  # noqa: F401
 from .rng import manual_seed  # noqa: F401
 from .modules import (MNISTIPVAE, ToyIPVAE, ConvIPVAE, MLPGradCARDAE, MLPResCARDAE, ImplicitPosteriorVAE, ConditionalARDAE,  # noqa: F401
                       normal_energy_func)

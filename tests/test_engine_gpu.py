@@ -371,3 +371,27 @@ def test_engine_checkpoint_roundtrip_reference_format(tmp_path):
     st = m_opt.state_dict()["state"]
     assert int(st[0]["step"]) == 2 and torch.equal(st[0]["exp_avg"].cpu(), mck2["optimizer"]["state"][0]["exp_avg"].cpu())
     assert m_opt.state_dict()["param_groups"][0]["betas"] == (0.5, 0.999) or list(m_opt.state_dict()["param_groups"][0]["betas"]) == [0.5, 0.999]
+
+
+def test_on_device_data_helpers():
+    """dynamic binarisation (datasets/mnist.py:36-40) and the 25-Gaussians set (datasets/toy.py:193-227) drawn on
+    the device from the library's Philox stream."""
+    net.manual_seed(5)
+    x, label = net.data.gaussians25(25 * 4000)
+    assert x.shape == (100000, 2) and label.shape == (100000,) and x.is_cuda
+    lin = torch.linspace(-4, 4, 5)
+    for comp in (0, 1, 7, 24):
+        pts = x[label == comp].cpu()
+        assert pts.shape[0] == 4000
+        want = torch.tensor([lin[comp % 5], lin[comp // 5]])               # x varies fastest, as np.meshgrid(x, y) does
+        assert (pts.mean(0) - want).abs().max() < 0.03                      # 6 sigma of the sample mean
+        assert (pts.var(0) - 0.1).abs().max() < 0.012
+    with pytest.raises(ValueError):
+        net.data.gaussians25(1001)
+    probs = torch.rand(64, 784, device="cuda")
+    xb = net.data.dynamic_binarize(probs)
+    assert set(torch.unique(xb).tolist()) <= {0.0, 1.0}
+    assert abs(float(xb.mean()) - float(probs.mean())) < 0.01
+    strong = net.data.dynamic_binarize((probs > 0.5).float())               # probabilities 0 / 1 are reproduced exactly
+    assert torch.equal(strong, (probs > 0.5).float())
+    assert not torch.equal(net.data.dynamic_binarize(probs), xb)            # a fresh draw every call
