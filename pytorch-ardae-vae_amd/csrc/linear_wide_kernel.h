@@ -117,8 +117,26 @@ struct Sched {
   // three or more tensors the wave runs out of its 256 architectural VGPRs, and a compiler spill of a register whose load
   // is still in flight reads garbage (seen as wrong Y2 rows in the first 8 rows of a tile) - those kernels store at once.
   static constexpr bool DEFER = NP >= 2 && NLT + NST <= 2;
-  static constexpr int OPC = NCH / 2;       // chunks of the last panel that carry epilogue-operand loads
-  static constexpr int HPC = 8 / OPC;       // half-blocks per such chunk
+  static constexpr int OPC = NCH / 2;       // the operand loads end with chunk OPC-1 of the last panel (NCH/2 chunks to land)
+  // Operand loads (64*NLT per tile, in half-block order): with one tensor they fit one per MFMA in chunks 0..OPC-1 of the
+  // last panel; with two tensors and at least two panels they start a panel earlier (no stores ride in those kernels), so
+  // that an MFMA never has more than one of them behind it (two per MFMA stalled the K loop by ~6 k cycles per tile).
+  static constexpr int NOPS = 64 * NLT;
+  static constexpr bool OP_EARLY = NLT == 2 && NP >= 2;
+  static constexpr int OP_G0 = OP_EARLY ? (NP - 2) * NCH : (NP - 1) * NCH;          // first global chunk carrying operand loads
+  static constexpr int OP_NCHK = (NP - 1) * NCH + OPC - OP_G0;                       // number of chunks carrying them
+  static constexpr int OP_PER = NOPS == 0 ? 0 : (NOPS + OP_NCHK - 1) / OP_NCHK;      // operand loads per chunk
+  // [begin, end) of the operand-load indices issued in chunk k of panel p
+  static constexpr int op_begin(int p, int k) {
+    const int g = p * NCH + k - OP_G0;
+    if (NOPS == 0 || g < 0 || g >= OP_NCHK) return 0;
+    return g * OP_PER < NOPS ? g * OP_PER : NOPS;
+  }
+  static constexpr int op_end(int p, int k) {
+    const int g = p * NCH + k - OP_G0;
+    if (NOPS == 0 || g < 0 || g >= OP_NCHK) return 0;
+    return (g + 1) * OP_PER < NOPS ? (g + 1) * OP_PER : NOPS;
+  }
   static constexpr int XW = NCH - 3;        // chunk that moves the next panel registers -> LDS
   static constexpr int BAR = NCH - 2;       // chunk that holds the barrier
   static constexpr int STRIDE = DEFER ? (NP - 1) * NCH / 8 : 1;   // chunks between deferred half-block stores
@@ -130,7 +148,7 @@ struct Sched {
   }
   static constexpr int extras(int p, int k) {
     const bool last = p == NP - 1;
-    return (k == 0 ? NX : 0) + (store_hb(p, k) >= 0 ? 8 * NST : 0) + (last && k == 0 ? 2 : 0) + ((last && k < OPC) ? HPC * 8 * NLT : 0);
+    return (k == 0 ? NX : 0) + (store_hb(p, k) >= 0 ? 8 * NST : 0) + (last && k == 0 ? 2 : 0) + (op_end(p, k) - op_begin(p, k));
   }
   // operations younger than B(c) when chunk c of panel p waits for it.  B(c) was issued first thing in chunk c - BDEPTH;
   // chunks before 0 belong to the previous panel (the previous tile's last one for p == 0)
@@ -404,7 +422,7 @@ struct ChunkOps {
   static constexpr int SHB = SC::store_hb(P, C);
   static constexpr int n_a = (XLDS && LAST && C == NCH - 1) ? 0 : 2;   // no next chunk inside this layer's tile
   static constexpr int n_b = 2, n_x = (C == 0 && !XLDS) ? NX : 0, n_w = (C == SC::XW && !XLDS) ? NX : 0, n_st = SHB >= 0 ? 8 * NST : 0,
-                       n_rb = (LAST && C == 0) ? 2 : 0, n_op = (LAST && C < SC::OPC) ? SC::HPC * 8 * NLT : 0;
+                       n_rb = (LAST && C == 0) ? 2 : 0, n_op = SC::op_end(P, C) - SC::op_begin(P, C);
   static constexpr int o_a = 0, o_b = o_a + n_a, o_x = o_b + n_b, o_w = o_x + n_x, o_st = o_w + n_w, o_rb = o_st + n_st,
                        o_op = o_rb + n_rb, total = o_op + n_op;
   static constexpr int PER = (total + 15) / 16;   // instructions behind each MFMA
@@ -460,19 +478,22 @@ struct ChunkOps {
       else x.epi.template issue_rowbias_one<1>(rb[1], x.row0, x.colw);
     } else {
       constexpr int k = K - o_op;
-      constexpr int HB = C * SC::HPC + k / (8 * NLT), tns = (k / 8) % NLT, e = k % 8;
+      constexpr int idx = SC::op_begin(P, C) + k;                         // index in the tile's operand-load sequence
+      constexpr int HB = idx / (8 * NLT), tns = (idx / 8) % NLT, e = idx % 8;
       constexpr int J = HB >> 2, I = (HB >> 1) & 1, H = HB & 1;
+      constexpr bool fresh = e == 0 || k == 0;                            // first load of its stream in this chunk: full address
+      constexpr int roff = 32 * I + 16 * H + (e & 3) + 8 * (e >> 2);      // row of element e inside the tile (without the lane part)
       if constexpr (EPI_T::SIGMA_OPERAND) {   // EPI_ACT with a per-row scale: sigma of the row
         constexpr int off = ((e & 3) + 8 * (e >> 2)) * 4;
         gload1<off>(l0[8 * HB + e], x.epi.vRS, (a.rowscale ? a.rowscale : a.src[0].x) + x.row0 + 32 * I + 16 * H);
       } else if constexpr (tns == 0) {
-        if constexpr (e == 0) q.p0 = a.S + (size_t)(x.row0 + 32 * I + 16 * H) * a.ldS + x.colw + 32 * J;
+        if constexpr (fresh) q.p0 = a.S + (size_t)(x.row0 + roff) * a.ldS + x.colw + 32 * J;
         gload1<0>(l0[8 * HB + e], x.epi.vL0, q.p0);
         q.p0 += (e == 3) ? (size_t)5 * a.ldS : (size_t)a.ldS;
       } else {
         const float* T = EPI_T::CHAIN ? a.R : a.Q;
         const int ld1 = EPI_T::CHAIN ? a.ldR : a.ldQ;
-        if constexpr (e == 0) q.p1 = T + (size_t)(x.row0 + 32 * I + 16 * H) * ld1 + x.colw + 32 * J;
+        if constexpr (fresh) q.p1 = T + (size_t)(x.row0 + roff) * ld1 + x.colw + 32 * J;
         gload1<0>(l1[8 * HB + e], x.epi.vL1, q.p1);
         q.p1 += (e == 3) ? (size_t)5 * ld1 : (size_t)ld1;
       }
