@@ -69,6 +69,7 @@ class ArdaeEngine:
         self.ws_vae = f(lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzm, 1))
         self.ws_small = f(max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, nzm, 0),
                               lib.ardae_model_workspace_floats(ctypes.byref(md), B, 1, 0)))
+        self.ws_small_v = f(lib.ardae_model_workspace_floats(ctypes.byref(md), B, 1, 0))   # VAE-side encode(std=0): may run beside the cDAE phase
         self.z0, self.latent = f(B, z), f(N, z)
         self.noise_s, self.xi, self.eps = f(N, nd), f(N), f(N, z)
         self.xbar, self.sigma, self.std_b = f(N, z), f(N), f(B)
@@ -88,6 +89,10 @@ class ArdaeEngine:
             (self.world == 1 or os.environ.get("ARDAE_GRAPH_DP") == "1")
         self._graph, self._graph_key, self._xc, self._xv = None, None, None, None
         self._in_step, self._draws, self._warmed = False, 0, False
+        # The first half of the VAE update (sampler + decoder + ELBO pieces on the VAE batch, ~25 per-image launches) needs
+        # nothing from the cDAE update: step() runs it on a side stream next to the cDAE phase's N-row kernels.
+        self.overlap = os.environ.get("ARDAE_OVERLAP", "1") != "0"
+        self._side = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self.repack()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -111,13 +116,17 @@ class ArdaeEngine:
     def _allreduce_mean(self, t):
         dist.allreduce_mean_(t, self.pg)
 
-    def _normal(self, out):
+    def _normal(self, out, draw=None):
         """One standard-normal draw.  Inside `step()` the offset comes from the device step state (graph-replayable);
-        phase calls made directly use the host-side stream of `rng`."""
+        phase calls made directly use the host-side stream of `rng`.  `draw`: fixed index of the draw inside the step
+        (so that the numbers do not depend on the order in which concurrent parts of the step are launched)."""
         if not self._in_step:
             return rng.normal(None, self.dev, out=out)
-        k = self._draws
-        self._draws += 1
+        if draw is None:
+            k = self._draws
+            self._draws += 1
+        else:
+            k = draw
         if k >= self.RNG_STRIDE:
             raise RuntimeError("more Philox draws in one step than RNG_STRIDE reserves")
         L.check(self.lib.ardae_philox_normal_dev(L.ptr(out), out.numel(), ctypes.c_uint64(rng.get_state()["seed"]), ctypes.c_void_p(self.state.data_ptr()),
@@ -145,17 +154,24 @@ class ArdaeEngine:
                                            cfg.d_lr, 0.99, 1e-8, cfg.d_momentum, st), "ardae_rmsprop_step")
             self._pack_cdae()
 
-    def vae_phase(self, x, noise=None, beta=None, apply_update=True):
-        """ivae_ardae.py:781-846.  noise: optional dict(vae [B*nz_model, nd])."""
+    def vae_forward_part(self, x, noise=None, beta=None, draw=None):
+        """ivae_ardae.py:781-827: everything of the VAE update that does not involve the cDAE (forward, ELBO pieces, z0, u)."""
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         beta = cfg.beta if beta is None else beta
         B, nz, md = self.B, cfg.nz_model, self.model._desc
-        nv = noise["vae"] if noise else self._normal(self.noise_v)
+        nv = noise["vae"] if noise else self._normal(self.noise_v, draw)
         L.check(lib.ardae_model_vae_forward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
                                             float(beta), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.zv), L.ptr(self.losses_m), st),
                 "ardae_model_vae_forward")
-        self._encode(x, None, 1, self.z0v, self.ws_small)
+        self._encode(x, None, 1, self.z0v, self.ws_small_v)
         L.check(lib.ardae_center_scale(L.ptr(self.zv), L.ptr(self.z0v), B, nz, self.model.z_dim, cfg.std_scale, L.ptr(self.u), st))
+        return nv
+
+    def vae_backward_part(self, x, nv, beta=None, apply_update=True):
+        """ivae_ardae.py:829-846: entropy gradient through the (updated) cDAE, backward, Adam."""
+        cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
+        beta = cfg.beta if beta is None else beta
+        B, nz, md = self.B, cfg.nz_model, self.model._desc
         L.check(lib.ardae_cdae_score(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.u),
                                      L.ptr(self.sigma0), L.ptr(self.z0v), B, nz, L.ptr(self.ws_small), self.ws_small.numel(),
                                      L.ptr(self.g), st), "ardae_cdae_score")
@@ -178,6 +194,11 @@ class ArdaeEngine:
                         "ardae_adam_ref_step")
             self._pack_model()
 
+    def vae_phase(self, x, noise=None, beta=None, apply_update=True):
+        """ivae_ardae.py:781-846.  noise: optional dict(vae [B*nz_model, nd])."""
+        nv = self.vae_forward_part(x, noise, beta)
+        self.vae_backward_part(x, nv, beta, apply_update)
+
     def _step_body(self, xs, x_vae, noise, beta):
         """The launches of one iteration, in stream order (this is what the graph captures)."""
         cfg = self.cfg
@@ -185,9 +206,20 @@ class ArdaeEngine:
         try:
             L.check(self.lib.ardae_step_state_advance(ctypes.c_void_p(self.state.data_ptr()), ctypes.c_uint64(self.RNG_STRIDE), cfg.m_lr, cfg.m_beta1, 0.999,
                                                       L.stream_ptr()), "ardae_step_state_advance")
-            for xc in xs:
-                self.cdae_phase(xc, noise)
-            self.vae_phase(x_vae, noise, beta)
+            vae_draw = self.RNG_STRIDE - 1            # the VAE sampler's noise keeps its own offset whatever the launch order
+            if self.overlap:
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    nv = self.vae_forward_part(x_vae, noise, beta, draw=vae_draw)
+                for xc in xs:
+                    self.cdae_phase(xc, noise)
+                main.wait_stream(self._side)
+            else:
+                for xc in xs:
+                    self.cdae_phase(xc, noise)
+                nv = self.vae_forward_part(x_vae, noise, beta, draw=vae_draw)
+            self.vae_backward_part(x_vae, nv, beta)
         finally:
             self._in_step = False
 
