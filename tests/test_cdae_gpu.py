@@ -181,6 +181,22 @@ def test_cdae_loss_grads_vs_oracle_nrow_kernels(kind):
     test_cdae_loss_grads_vs_oracle(kind, 32, 256, 32, 256, 3)
 
 
+@pytest.mark.parametrize("knob", ["ARDAE_FCHAIN", "ARDAE_CHAIN", "ARDAE_WIDE=0", "ARDAE_WGRAD_WIDE=0"])
+def test_cdae_nrow_kernels_opt_in_variants(knob):
+    """The opt-in / fallback code paths (fused N-row layer chains, per-image layer chains, generic linear and weight-gradient
+    kernels) must give the same answers as the defaults: the library reads its knobs once per process, so the 8192-row
+    oracle comparison is re-run in a child process with the knob set."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    k, _, v = knob.partition("=")
+    env[k] = v or "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "nrow_kernels and grad and not opt_in"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout, r.stdout[-500:]      # both cDAE kinds ran (mlp-grad, mlp-res) and nothing else
+
+
 def test_cdae_cfg2_golden_summaries(golden_dir):
     """Full-width config #2 network (h=256, L=3, z=32) at B=8, nz=16: parameters regenerated from the seed."""
     fx = load(golden_dir, "cfg2_b8_nz16")
