@@ -60,6 +60,9 @@ int linear_or_chain(const LinArgs& a, int epi, hipStream_t st);   // chain_add o
 struct PackItem { const float* W; int ldw, nout, k, transpose; float* out; };
 constexpr int PACK_BATCH_MAX = 48;
 int launch_pack_batch(const PackItem* items, int n, hipStream_t st);
+// split-K 32 x 32 kernel for the per-image (B-row) problems (linear_small.hip): latency, not throughput
+bool linear_small_eligible(const LinArgs& a, int epi);
+int launch_linear_small(const LinArgs& a, int epi, hipStream_t st);
 // software-pipelined 64 x 256 kernel (linear_wide.hip): full tiles, K % 32 == 0
 bool linear_wide_eligible(const LinArgs& a, int epi);
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);

@@ -753,6 +753,10 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
   }
   if (ws_mode == 2 && linear_ws2_eligible(a, epi)) return launch_linear_ws2(a, epi, st);
   if (ws_mode == 1 && linear_ws_eligible(a, epi) && a.src[0].K <= 256) return launch_linear_ws(a, epi, st);
+  if (linear_small_eligible(a, epi)) {
+    ARDAE_TRY(validate_linear(a, epi));
+    return launch_linear_small(a, epi, st);
+  }
   static const bool wide_on = !(getenv("ARDAE_WIDE") && atoi(getenv("ARDAE_WIDE")) == 0);
   if (wide_on && linear_wide_eligible(a, epi)) {
     if (epi == EPI_ACT) ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");
