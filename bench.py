@@ -81,13 +81,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs (tests/test_dp_gpu.py): BENCH_ONE_GPU=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo moves the
+    # gradient buffers through the host, because RCCL refuses two ranks on one device.  The driver's runs use neither.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = 0 if (world == 1 or os.environ.get("BENCH_ONE_GPU") == "1") else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if backend == "nccl":
+            torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            torch.distributed.init_process_group(backend=backend)
+    dev = torch.device("cuda", dev_index)
 
     import ardae_amd as net
     from ardae_amd import _lib as L
@@ -136,15 +141,19 @@ def main():
 
     # ---- live per-kernel timing (HIP events on the launch stream), separate from the throughput region
     roofline = None
-    if rank == 0:
+    rep = None
+    if args.prof_steps > 0:
+        # every rank runs the instrumented steps (they contain the gradient all-reduces); rank 0 reports its own kernels
         graph_was = eng.use_graph
         eng.use_graph = False                 # the per-kernel HIP events need individual launches
         lib.ardae_profile_enable(1)
         for _ in range(args.prof_steps):
             one_step()
+        torch.cuda.synchronize()
         rep = L.profile_report()
         lib.ardae_profile_enable(0)
         eng.use_graph = graph_was
+    if rank == 0 and rep:
         rep.sort(key=lambda e: -e["total_ms"])
         top = rep[0]
         ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
@@ -180,7 +189,7 @@ def main():
             "hip_graph": bool(eng._graph is not None),
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (contract)
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -174,7 +174,7 @@ typedef struct ardae_model_desc {
 } ardae_model_desc;
 size_t ardae_model_param_floats(const ardae_model_desc* d);
 size_t ardae_model_packed_floats(const ardae_model_desc* d);
-/* mode 0: encode only; mode 1: vae_forward + vae_backward; mode 2: decode only (B = rows, nz = 1) */
+/* mode 0: encode only; mode 1: vae_forward + vae_backward; mode 2: decode only (B = rows, nz = 1); mode 3: encode_pair */
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode);
 int ardae_model_pack(const ardae_model_desc* d, const float* params, float* packed, void* stream);
 /* Encoder.forward (ivae/mnist.py:102-121): z[B*nz, z] = f(x[B, input_dim], noise[B*nz, noise_dim]); noise NULL = zeros,
@@ -182,6 +182,12 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
 int ardae_model_encode(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
                        const float* noise, int B, int nz, float* workspace, size_t workspace_floats, float* z_out,
                        void* stream);
+/* The two sampler calls that open a cDAE update (ivae_ardae.py:735,749) on the same images in one pass: z0 = encode(x, std=0)
+ * [B, z] and z = forward_hidden(x, nz) [B*nz, z] share the per-image trunk (inp_encode and the image half of the first
+ * concat layer), which is computed once.  Workspace: ardae_model_workspace_floats(d, B, nz, 3). */
+int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                            const float* noise, int B, int nz, float* workspace, size_t workspace_floats, float* z0_out,
+                            float* z_out, void* stream);
 /* ImplicitPosteriorVAE.forward (ivae/mnist.py:267-301): z_out [B*nz, z]; losses[3] = {loss, recon.mean, prior.mean}
  * (device); activations stay in `workspace` for the backward call */
 int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,

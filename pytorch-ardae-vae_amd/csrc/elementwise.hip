@@ -164,26 +164,35 @@ __global__ void center_scale_kernel(const float* __restrict__ latent, const floa
   u[e] = std_scale * (latent[e] - z0[(row / nz) * zd + d]);
 }
 
-// grid (groups, ceil(cols/64)); 256 threads = 4 row lanes x 64 consecutive columns (256-B coalesced rows)
-__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ in, int ld, int rows_per_group, int cols,
-                                                          float scale, float* __restrict__ out, int ldout) {
-  __shared__ float red[256];
+// grid (groups, ceil(cols/64)); NT threads = NT/64 row lanes x 64 consecutive columns (256-B coalesced rows), eight rows
+// in flight per thread.  NT = 256 for many groups (the chip is full anyway); NT = 1024 for the few-groups / many-rows case
+// (the per-tile column sums of an N-row launch: one group of 2048 rows took 53 us on four 256-thread workgroups).
+template <int NT>
+__global__ __launch_bounds__(NT) void segment_sum_kernel(const float* __restrict__ in, int ld, int rows_per_group, int cols,
+                                                         float scale, float* __restrict__ out, int ldout) {
+  constexpr int RL = NT / 64;
+  __shared__ float red[NT];
   const int g = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
   if (c < cols) {
     const float* p = in + (size_t)g * rows_per_group * ld + c;
     int r = rl;
-    for (; r + 12 < rows_per_group; r += 16) {
-      s0 += p[(size_t)r * ld];
-      s1 += p[(size_t)(r + 4) * ld];
-      s2 += p[(size_t)(r + 8) * ld];
-      s3 += p[(size_t)(r + 12) * ld];
+    for (; r + 7 * RL < rows_per_group; r += 8 * RL) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += p[(size_t)(r + j * RL) * ld];
     }
-    for (; r < rows_per_group; r += 4) s0 += p[(size_t)r * ld];
+    for (; r < rows_per_group; r += RL) s[0] += p[(size_t)r * ld];
   }
-  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  if (rl == 0 && c < cols) out[(size_t)g * ldout + c] = scale * ((red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]));
+  if (rl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < RL; ++j) t += red[threadIdx.x + 64 * j];
+    out[(size_t)g * ldout + c] = scale * t;
+  }
 }
 
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ in, int n, float scale, float* __restrict__ out) {
@@ -356,7 +365,10 @@ int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, 
                        hipStream_t st) {
   ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(in && out && groups > 0 && rows_per_group > 0 && cols > 0 && ld >= cols && ldout >= cols, "segment_sum: bad arguments");
-  hipLaunchKernelGGL(segment_sum_kernel, dim3(groups, ceil_div(cols, 64)), dim3(256), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
+  if ((int64_t)groups * ceil_div(cols, 64) < 256 && rows_per_group >= 128)
+    hipLaunchKernelGGL(segment_sum_kernel<1024>, dim3(groups, ceil_div(cols, 64)), dim3(1024), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
+  else
+    hipLaunchKernelGGL(segment_sum_kernel<256>, dim3(groups, ceil_div(cols, 64)), dim3(256), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

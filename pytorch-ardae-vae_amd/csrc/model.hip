@@ -179,10 +179,10 @@ int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, cons
   return linear_or_chain(a, epi, st);
 }
 
-// sampler forward: fills W.e, W.rb, W.t, W.z (and copies z to z_out when given)
-int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* x,
-               const float* noise, int B, int nz, ModelWs& W, float* z_out, hipStream_t st) {
-  const int R = B * nz, h = P.h, act = P.act;
+// sampler trunk (once per image): inp_encode on B rows, then rb = inp . S_1[:, :h]^T + b_S1.  Fills W.e, W.rb.
+int encode_trunk(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* x, int B,
+                 ModelWs& W, hipStream_t st) {
+  const int h = P.h, act = P.act;
   const float* x_in = x;
   if (P.kind == 0) {
     ARDAE_TRY(launch_affine(x, (int64_t)B * P.D, 2.f, -1.f, W.x2, st));
@@ -192,21 +192,25 @@ int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, 
     LinArgs A{}; A.bias = params + P.inp[l - 1].b; A.Y = W.e[l]; A.ldY = h;
     ARDAE_TRY(lin1(EPI_ACT, act, B, h, l == 1 ? x_in : W.e[l - 1], l == 1 ? P.D : h, P.inp[l - 1].in, packed + K.inp_f[l - 1], A, st));
   }
-  {  // rb = inp . S_1[:, :h]^T + b_S1   (once per image)
-    LinArgs A{}; A.bias = params + P.stack[0].b; A.Y = W.rb; A.ldY = h;
-    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.stack[0].out, W.e[P.inp.size()], h, h, packed + K.sh_f[0], A, st));
-  }
+  LinArgs A{}; A.bias = params + P.stack[0].b; A.Y = W.rb; A.ldY = h;
+  return lin1(EPI_ACT, ACT_NONE, B, P.stack[0].out, W.e[P.inp.size()], h, h, packed + K.sh_f[0], A, st);
+}
+
+// sampler stack on R = B*nz rows: layer 0 takes the per-image rb plus its noise part, the last layer writes zdst [R, zd]
+int encode_stack(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* noise,
+                 int B, int nz, const float* rb, const std::vector<float*>& t, float* zdst, hipStream_t st) {
+  const int R = B * nz, h = P.h, act = P.act;
   const size_t ns = P.stack.size();
   for (size_t i = 0; i < ns; ++i) {
     const bool last = i + 1 == ns;
     const int out = P.stack[i].out;
-    LinArgs A{}; A.Y = last ? W.z : W.t[i + 1]; A.ldY = out; A.M = R; A.Nout = out; A.act = last ? ACT_NONE : act;
+    LinArgs A{}; A.Y = last ? zdst : t[i + 1]; A.ldY = out; A.M = R; A.Nout = out; A.act = last ? ACT_NONE : act;
     int n = 0;
     if (i == 0) {
-      A.rowbias = W.rb; A.rowbias_ld = h; A.rows_per_group = nz;
+      A.rowbias = rb; A.rowbias_ld = h; A.rows_per_group = nz;
     } else {
       A.bias = params + P.stack[i].b;
-      A.src[n].x = W.t[i]; A.src[n].ld = h; A.src[n].K = h; A.src[n].wp = packed + K.sh_f[i]; ++n;
+      A.src[n].x = t[i]; A.src[n].ld = h; A.src[n].K = h; A.src[n].wp = packed + K.sh_f[i]; ++n;
     }
     if (P.stack_noise[i]) {
       A.src[n].x = noise; A.src[n].ld = P.nd; A.src[n].K = P.nd; A.src[n].wp = packed + K.sn_f[i]; ++n;
@@ -214,11 +218,24 @@ int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, 
     A.nsrc = n;
     ARDAE_TRY(linear_or_chain(A, EPI_ACT, st));
   }
+  return 0;
+}
+
+// sampler forward: fills W.e, W.rb, W.t, W.z (and copies z to z_out when given)
+int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* x,
+               const float* noise, int B, int nz, ModelWs& W, float* z_out, hipStream_t st) {
+  ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
+  ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, W.z, st));
   if (z_out) {
     ARDAE_TRY(flush_active_chain());
-    ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   return 0;
+}
+
+// extra floats of the encode_pair workspace: the zero-noise stack's hidden rows and its zero noise block (B rows each)
+size_t encode_pair_extra(const ModelLayout& P, int B) {
+  return (P.stack.size() - 1) * al64((size_t)B * P.h) + al64((size_t)B * P.nd);
 }
 
 }  // namespace
@@ -238,9 +255,10 @@ size_t ardae_model_packed_floats(const ardae_model_desc* d) {
 }
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
   if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
-  if (d->kind == 2) return conv_model_workspace_floats(*d, B, nz, mode);
+  if (d->kind == 2) return conv_model_workspace_floats(*d, B, nz, mode == 3 ? 0 : mode);
   const ModelLayout P(*d);
   if (mode == 2) return P.dec.size() * al64((size_t)B * nz * P.h);
+  if (mode == 3) return workspace_floats(P, B, nz, 0) + encode_pair_extra(P, B);   // ardae_model_encode_pair
   return workspace_floats(P, B, nz, mode) + (size_t)al64((size_t)B * nz * P.nd);   // + a zero-noise buffer for encode(std=0)
 }
 
@@ -306,6 +324,34 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   }
   ARDAE_CHECK_ARG(ws.ok, "model_encode: internal workspace accounting error");
   ARDAE_TRY(encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, st));
+  return chain_scope.finish();
+}
+
+int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
+                            int B, int nz, float* workspace, size_t workspace_floats_, float* z0_out, float* z_out, void* stream) {
+  ARDAE_TRY(desc_ok(d));
+  ARDAE_CHECK_ARG(params && packed && x && noise && workspace && z0_out && z_out, "model_encode_pair: null pointer argument");
+  ARDAE_CHECK_ARG(B > 0 && nz > 0 && (int64_t)B * nz < (int64_t)1 << 30, "model_encode_pair: bad batch (B=%d nz=%d)", B, nz);
+  ARDAE_CHECK_ARG(workspace_floats_ >= ardae_model_workspace_floats(d, B, nz, 3), "model_encode_pair: workspace too small");
+  if (d->kind == 2) {   // conv sampler: two passes over the same workspace
+    ARDAE_TRY(ardae_model_encode(d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, stream));
+    return ardae_model_encode(d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, stream);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ChainScope chain_scope(st);
+  const ModelLayout P(*d);
+  const ModelPacked K(P);
+  Bump ws(workspace, workspace_floats_);
+  ModelWs W;
+  carve(P, ws, B, nz, 0, W);
+  std::vector<float*> t0(P.stack.size(), nullptr);
+  for (size_t i = 1; i < P.stack.size(); ++i) t0[i] = ws.take((size_t)B * P.h);
+  float* zero = ws.take((size_t)B * P.nd);
+  ARDAE_CHECK_ARG(ws.ok, "model_encode_pair: internal workspace accounting error");
+  ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * P.nd * sizeof(float), st));
+  ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
+  ARDAE_TRY(encode_stack(P, K, params, packed, zero, B, 1, W.rb, t0, z0_out, st));      // encode(x, std=0): the draw is multiplied by 0
+  ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, st));   // forward_hidden(x, nz)
   return chain_scope.finish();
 }
 

@@ -64,7 +64,7 @@ class ArdaeEngine:
         f = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
         lib = self.lib
         ws_floats = max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, nzc, 1),
-                        lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzc, 0))
+                        lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzc, 3))
         self.ws = f(ws_floats)
         self.ws_vae = f(lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzm, 1))
         self.ws_small = f(max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, nzm, 0),
@@ -134,15 +134,22 @@ class ArdaeEngine:
         return out
 
     # ------------------------------------------------------------------------------------------------------------
-    def cdae_phase(self, x, noise=None, apply_update=True):
-        """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z])."""
+    def cdae_phase(self, x, noise=None, apply_update=True, drawn=None):
+        """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z]).
+        drawn: event after which the engine's own three draws (sampler, sigma, eps) are in their buffers - step() issues them
+        on the side stream, next to the per-image trunk this method starts with."""
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         B, nz, z = self.B, cfg.nz_cdae, self.model.z_dim
-        self._encode(x, None, 1, self.z0, self.ws_small)                       # context == latent_mean (lt0)
-        ns = noise["sampler"] if noise else self._normal(self.noise_s)
-        self._encode(x, ns, nz, self.latent, self.ws)                          # forward_hidden
-        xi = noise["sigma"].reshape(-1) if noise else self._normal(self.xi)
-        eps = noise["eps"] if noise else self._normal(self.eps)
+        if noise:
+            ns, xi, eps = noise["sampler"], noise["sigma"].reshape(-1), noise["eps"]
+        elif drawn is not None:
+            ns, xi, eps = self.noise_s, self.xi, self.eps
+            torch.cuda.current_stream().wait_event(drawn)
+        else:
+            ns, xi, eps = self._normal(self.noise_s), self._normal(self.xi), self._normal(self.eps)
+        # context == latent_mean == encode(x, std=0) (lt0) and forward_hidden(x, nz) share the per-image trunk: one pass
+        L.check(lib.ardae_model_encode_pair(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(ns), B, nz,
+                                            L.ptr(self.ws), self.ws.numel(), L.ptr(self.z0), L.ptr(self.latent), st), "ardae_model_encode_pair")
         L.check(lib.ardae_latent_perturb(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, z, cfg.std_scale, cfg.delta,
                                          L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb")
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
@@ -210,10 +217,17 @@ class ArdaeEngine:
             if self.overlap:
                 main = torch.cuda.current_stream()
                 self._side.wait_stream(main)
+                drawn = None
                 with torch.cuda.stream(self._side):
+                    if noise is None and len(xs) == 1:
+                        # the cDAE update's three draws need nothing but the step state: they run beside the sampler trunk
+                        self._normal(self.noise_s, 0); self._normal(self.xi, 1); self._normal(self.eps, 2)
+                        self._draws = 3
+                        drawn = torch.cuda.Event()
+                        drawn.record(self._side)
                     nv = self.vae_forward_part(x_vae, noise, beta, draw=vae_draw)
                 for xc in xs:
-                    self.cdae_phase(xc, noise)
+                    self.cdae_phase(xc, noise, drawn=drawn)
                 main.wait_stream(self._side)
             else:
                 for xc in xs:

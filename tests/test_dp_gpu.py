@@ -1,0 +1,110 @@
+"""Data parallelism with the REAL engine: two ranks share the one GPU of the test box (gloo moves the flat gradient
+buffers; RCCL refuses two ranks on one device), each runs the HIP path on its half of the image batch, and the averaged
+gradients must equal the single-process engine's on the whole batch (the same ArdaeEngine code path - eager
+launches, side stream, all-reduce before each optimiser step - that `bench.py --gpus N` runs under RCCL).
+
+Also rehearses `bench.py` itself under `torch.distributed.run` with two ranks (BENCH_BACKEND=gloo, both on cuda:0).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import ardae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MC = O.ModelCfg("mnist", 48, 12, 64, 8, 2, "softplus")
+CC = O.CdaeCfg("grad", 8, 8, 64, 3)
+B, NZ = 16, 32          # 512 Monte-Carlo rows in all, 256 per rank
+
+
+def _build(dev):
+    import ardae_amd as net
+    model = net.MNISTIPVAE(input_dim=MC.input_dim, noise_dim=MC.noise_dim, h_dim=MC.h_dim, num_hidden_layers=MC.n_layers,
+                           nonlinearity=MC.nonlin, enc_type="concat", z_dim=MC.z_dim)
+    cdae = net.MLPGradCARDAE(input_dim=CC.input_dim, context_dim=CC.context_dim, std=1., h_dim=CC.h_dim, num_hidden_layers=CC.n_layers,
+                             nonlinearity=CC.nonlin, noise_type="gaussian", enc_ctx=True, enc_input=True)
+    model.load_state_dict(O.init_params(O.model_param_spec(MC), 0, O.model_init_special(MC)))
+    cdae.load_state_dict(O.init_params(O.cdae_param_spec(CC), 1))
+    return model.to(dev), cdae.to(dev)
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(11)
+    x1 = torch.bernoulli(torch.full((B, MC.input_dim), 0.3), generator=g)
+    x2 = torch.bernoulli(torch.full((B, MC.input_dim), 0.3), generator=g)
+    noise = O.draw_step_noise(MC, O.TrainCfg(nz_cdae=NZ), B, g)
+    return x1, x2, noise
+
+
+def _grads(x1, x2, noise, per_rank_batch):
+    """cDAE-phase and VAE-phase gradients (all-reduced inside the engine when a process group is up), no parameter update."""
+    import ardae_amd as net
+    dev = torch.device("cuda", 0)
+    model, cdae = _build(dev)
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=per_rank_batch)
+    nz = {k: v.to(dev).contiguous() for k, v in noise.items()}
+    eng.cdae_phase(x1.to(dev), nz, apply_update=False)
+    eng.vae_phase(x2.to(dev), nz, apply_update=False)
+    torch.cuda.synchronize()
+    return eng.grads_c[:eng.n_c].cpu().clone(), eng.grads_m.cpu().clone(), eng.loss_c.cpu().clone()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from ardae_amd import dist
+    x1, x2, noise = _inputs()
+    lo, hi = dist.shard_rows(B)
+    n_loc = {"sampler": noise["sampler"][lo * NZ:hi * NZ], "sigma": noise["sigma"][lo:hi], "eps": noise["eps"][lo * NZ:hi * NZ],
+             "vae": noise["vae"][lo:hi]}
+    gc, gm, loss = _grads(x1[lo:hi], x2[lo:hi], n_loc, hi - lo)
+    lt = loss.clone()
+    torch.distributed.all_reduce(lt)
+    if rank == 0:
+        torch.save({"gc": gc, "gm": gm, "loss": lt / world}, out)
+    torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
+    out = str(tmp_path / "dp_gpu.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    x1, x2, noise = _inputs()
+    gc, gm, loss = _grads(x1, x2, noise, B)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert abs(float(got["loss"]) - float(loss)) <= 1e-5 * abs(float(loss))
+    # same arithmetic on the same rows; only the order of the fp32 sums over rows differs (split in two, then averaged)
+    assert rel(got["gc"], gc) < 5e-4
+    assert rel(got["gm"], gm) < 5e-4
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py under torch.distributed.run with two ranks on the one GPU: the launch contract (env rendezvous, barrier,
+    max-over-ranks timing, one JSON line from rank 0) end to end."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_ONE_GPU="1", BENCH_GLOBAL_B="32")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["per_gpu_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["roofline"]["kernel"]
+    for k in ("cdae_loss", "model_loss"):
+        assert d["losses"][k] == d["losses"][k]          # not NaN
