@@ -149,7 +149,10 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
     p.c4n = p.kw8 >> 2;
     p.kchunks = (p.K + 7) >> 3;
     const bool vec = ((p.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-    p.fast = vec && rows_full && p.kw8 == kw && (p.c4n & (p.c4n - 1)) == 0 && (256 / p.c4n) <= BM;
+    // fast path: whole float4s and a power-of-two row length (shift/mask indexing).  A ragged last panel (K = 100: 64 + 36)
+    // is widened to the next power of two with the float4s beyond K zero-filled, as long as K is a multiple of 4.
+    if (p.c4n & (p.c4n - 1)) p.c4n = 1 << (32 - __clz(p.c4n));
+    p.fast = vec && rows_full && (kw & 3) == 0 && p.c4n * 4 <= KPANEL && (256 / p.c4n) <= BM;
     return p;
   };
   f32x4 pv[MAXP];
@@ -157,11 +160,16 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
   auto panel_load = [&](const Panel& p) {
     const int sh = 31 - __clz(p.c4n);
     const int rpp = 256 >> sh, passes = BM / rpp;
-    const float* src = p.x + (size_t)(row0 + (tid >> sh)) * p.ld + p.k0 + ((tid & (p.c4n - 1)) << 2);
+    const int c = (tid & (p.c4n - 1)) << 2;
+    const bool inside = p.k0 + c + 4 <= p.K;
+    const float* src = p.x + (size_t)(row0 + (tid >> sh)) * p.ld + p.k0 + (inside ? c : 0);
     const size_t gstep = (size_t)rpp * p.ld;
 #pragma unroll
     for (int u = 0; u < MAXP; ++u)
-      if (u < passes) pv[u] = *reinterpret_cast<const f32x4*>(src + (size_t)u * gstep);
+      if (u < passes) {
+        pv[u] = *reinterpret_cast<const f32x4*>(src + (size_t)u * gstep);
+        if (!inside) pv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
   };
   auto panel_store = [&](const Panel& p, float* buf) {
     const int sh = 31 - __clz(p.c4n);

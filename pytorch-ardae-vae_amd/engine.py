@@ -225,9 +225,12 @@ class ArdaeEngine:
                         self._draws = 3
                         drawn = torch.cuda.Event()
                         drawn.record(self._side)
-                    nv = self.vae_forward_part(x_vae, noise, beta, draw=vae_draw)
+                # eager launches reach the GPU in host order: the cDAE phase (the critical path) is enqueued before the
+                # side stream's ~30 small launches, which have the whole phase to finish in
                 for xc in xs:
                     self.cdae_phase(xc, noise, drawn=drawn)
+                with torch.cuda.stream(self._side):
+                    nv = self.vae_forward_part(x_vae, noise, beta, draw=vae_draw)
                 main.wait_stream(self._side)
             else:
                 for xc in xs:
