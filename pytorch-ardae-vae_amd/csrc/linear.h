@@ -63,6 +63,9 @@ int launch_pack_batch(const PackItem* items, int n, hipStream_t st);
 // split-K 32 x 32 kernel for the per-image (B-row) problems (linear_small.hip): latency, not throughput
 bool linear_small_eligible(const LinArgs& a, int epi);
 int launch_linear_small(const LinArgs& a, int epi, hipStream_t st);
+// streaming kernel for N-row layers with Nout <= 32 and K = 256 (linear_narrow.hip): HBM-bound
+bool linear_narrow_eligible(const LinArgs& a, int epi);
+int launch_linear_narrow(const LinArgs& a, int epi, hipStream_t st);
 // software-pipelined 64 x 256 kernel (linear_wide.hip): full tiles, K % 32 == 0
 bool linear_wide_eligible(const LinArgs& a, int epi);
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);
