@@ -66,6 +66,9 @@ int launch_linear_small(const LinArgs& a, int epi, hipStream_t st);
 // streaming kernel for N-row layers with Nout <= 32 and K = 256 (linear_narrow.hip): HBM-bound
 bool linear_narrow_eligible(const LinArgs& a, int epi);
 int launch_linear_narrow(const LinArgs& a, int epi, hipStream_t st);
+// N-row forward layers with K <= 128 that is not a multiple of 32 (linear_shortk.hip): A fragments stay in registers
+bool linear_shortk_eligible(const LinArgs& a, int epi);
+int launch_linear_shortk(const LinArgs& a, int epi, hipStream_t st);
 // software-pipelined 64 x 256 kernel (linear_wide.hip): full tiles, K % 32 == 0
 bool linear_wide_eligible(const LinArgs& a, int epi);
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);

@@ -769,6 +769,10 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
     ARDAE_TRY(validate_linear(a, epi));
     return launch_linear_narrow(a, epi, st);
   }
+  if (linear_shortk_eligible(a, epi)) {
+    ARDAE_TRY(validate_linear(a, epi));
+    return launch_linear_shortk(a, epi, st);
+  }
   static const bool wide_on = !(getenv("ARDAE_WIDE") && atoi(getenv("ARDAE_WIDE")) == 0);
   if (wide_on && linear_wide_eligible(a, epi)) {
     if (epi == EPI_ACT) ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");

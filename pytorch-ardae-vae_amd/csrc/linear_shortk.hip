@@ -1,0 +1,124 @@
+// N-row layers with a SHORT reduction: Y[M, Nout] = act(X[M, K <= 128] . Wp^T + bias + per-image row bias) - the first
+// sampler layer on the B*nz Monte-Carlo rows, whose only N-row input is the noise (K = noise_dim = 100; the image part of
+// the concat enters as the per-image row bias: ivae/mnist.py:123-165, models/layers.py:681-724).  7 GFLOP, 52 MB in,
+// 134 MB out at config #2.  K = 100 fits none of the panelled kernels (64-wide LDS panels: 64 + a ragged 36), and two
+// panels per tile amortise nothing; so here a wave keeps the whole K extent of its 32 rows in registers as MFMA A-fragments
+// (<= 16 float4 per lane, read from HBM exactly once, zero beyond K) and walks the column blocks with the packed weight
+// fragments of the next block in flight from L2 behind the MFMAs of the current one.  No LDS, no barriers.
+#include <stdlib.h>
+
+#include "linear.h"
+#include "profile.h"
+
+namespace ardae {
+namespace {
+
+constexpr int SK_MAXK = 128;
+
+// SK_MAXCH: compile-time bound of the chunk count (8 k each) - it sizes the three fragment arrays, i.e. the occupancy
+template <int ACT, int SK_MAXCH>
+__global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void linear_shortk_kernel(const LinArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int row0 = (blockIdx.x * 4 + wave) * 32;
+  const int K = a.src[0].K, nch = (K + 7) >> 3;
+
+  const float* xr = a.src[0].x + (size_t)(row0 + l31) * a.src[0].ld + 4 * hh;
+  f32x4 av[SK_MAXCH];
+#pragma unroll
+  for (int c = 0; c < SK_MAXCH; ++c) {
+    av[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < nch && 8 * c + 4 * hh + 4 <= K) av[c] = *reinterpret_cast<const f32x4*>(xr + 8 * c);
+  }
+
+  const int nblk = a.Nout >> 5;
+  const float* bp = a.src[0].wp + lane * 4;
+  const size_t bstride = (size_t)nch * 256;          // floats per column block of the packed image
+  // the 32 rows of a wave share one image when the groups are multiples of 32 rows: one row-bias value per column
+  const bool rb_uniform = a.rowbias && (a.rows_per_group % 32) == 0;
+  const float* rbrow = a.rowbias ? a.rowbias + (size_t)(row0 / a.rows_per_group) * a.rowbias_ld : nullptr;
+
+  f32x4 b0[SK_MAXCH], b1[SK_MAXCH];
+  auto load_b = [&](f32x4 (&b)[SK_MAXCH], int nb) {
+#pragma unroll
+    for (int c = 0; c < SK_MAXCH; ++c)
+      if (c < nch) b[c] = *reinterpret_cast<const f32x4*>(bp + (size_t)nb * bstride + (size_t)c * 256);
+  };
+  auto block = [&](const f32x4 (&b)[SK_MAXCH], int nb) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < SK_MAXCH; ++c)
+      if (c < nch) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][q], b[c][q], acc, 0, 0, 0);
+      }
+    const int col = nb * 32 + l31;
+    float pre = a.bias ? a.bias[col] : 0.f;
+    if (rb_uniform) pre += rbrow[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      float v = acc[r] + pre;
+      if (a.rowbias && !rb_uniform) v += a.rowbias[(size_t)(row / a.rows_per_group) * a.rowbias_ld + col];
+      a.Y[(size_t)row * a.ldY + col] = act_fwd<ACT>(v);
+    }
+  };
+
+  load_b(b0, 0);
+  for (int nb = 0; nb < nblk; nb += 2) {
+    if (nb + 1 < nblk) load_b(b1, nb + 1);
+    block(b0, nb);
+    if (nb + 1 >= nblk) break;
+    if (nb + 2 < nblk) load_b(b0, nb + 2);
+    block(b1, nb + 1);
+  }
+}
+
+template <int ACT, int MAXCH>
+int launch_shortk_ch(const LinArgs& a, hipStream_t st) {
+  if (g_prof_enabled) {
+    char name[64];
+    snprintf(name, sizeof(name), "linear_shortk_kernel<%d, %d>", ACT, MAXCH);
+    const double K = a.src[0].K;
+    prof_begin(st, name, 2.0 * a.M * (double)a.Nout * K, 4.0 * ((double)a.M * K + (double)a.M * a.Nout + K * a.Nout));
+  }
+  hipLaunchKernelGGL((linear_shortk_kernel<ACT, MAXCH>), dim3(a.M / 128), dim3(256), 0, st, a);
+  prof_end(st);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int ACT>
+int launch_shortk(const LinArgs& a, hipStream_t st) {
+  const int nch = (a.src[0].K + 7) >> 3;
+  if (nch <= 8) return launch_shortk_ch<ACT, 8>(a, st);
+  if (nch <= 13) return launch_shortk_ch<ACT, 13>(a, st);
+  return launch_shortk_ch<ACT, 16>(a, st);
+}
+
+}  // namespace
+
+// One source, K <= 128 and a multiple of 4 but NOT one of the panelled kernels' shapes, whole 128-row tiles and 32-column
+// blocks, enough rows to fill the chip; forward epilogue (bias, per-image row bias, activation) only.  ARDAE_SHORTK=0: off.
+bool linear_shortk_eligible(const LinArgs& a, int epi) {
+  static const bool on = !(getenv("ARDAE_SHORTK") && atoi(getenv("ARDAE_SHORTK")) == 0);
+  if (!on || epi != EPI_ACT || a.nsrc != 1) return false;
+  const int K = a.src[0].K;
+  if (K <= 0 || K > SK_MAXK || (K & 3) || K % 32 == 0) return false;
+  if (a.M < 128 * 256 || (a.M % 128) || a.Nout <= 0 || (a.Nout % 32)) return false;
+  if ((a.src[0].ld & 3) || (reinterpret_cast<uintptr_t>(a.src[0].x) & 15)) return false;
+  if (a.rowscale || a.Y2 || a.colsum || !a.Y) return false;
+  if (a.rowbias && a.rows_per_group <= 0) return false;
+  return a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_SOFTPLUS;
+}
+
+int launch_linear_shortk(const LinArgs& a, int epi, hipStream_t st) {
+  (void)epi;
+  if (a.act == ACT_RELU) return launch_shortk<ACT_RELU>(a, st);
+  if (a.act == ACT_SOFTPLUS) return launch_shortk<ACT_SOFTPLUS>(a, st);
+  return launch_shortk<ACT_NONE>(a, st);
+}
+
+}  // namespace ardae
