@@ -181,10 +181,10 @@ def test_cdae_loss_grads_vs_oracle_nrow_kernels(kind):
     test_cdae_loss_grads_vs_oracle(kind, 32, 256, 32, 256, 3)
 
 
-@pytest.mark.parametrize("knob", ["ARDAE_FCHAIN", "ARDAE_CHAIN", "ARDAE_WIDE=0", "ARDAE_WGRAD_WIDE=0"])
+@pytest.mark.parametrize("knob", ["ARDAE_FCHAIN", "ARDAE_CHAIN", "ARDAE_WIDE=0", "ARDAE_WGRAD_WIDE=0", "ARDAE_SMALL=0", "ARDAE_NARROW=0"])
 def test_cdae_nrow_kernels_opt_in_variants(knob):
     """The opt-in / fallback code paths (fused N-row layer chains, per-image layer chains, generic linear and weight-gradient
-    kernels) must give the same answers as the defaults: the library reads its knobs once per process, so the 8192-row
+    kernels, the generic kernel in place of the per-image split-K and the narrow streaming kernels) must give the same answers as the defaults: the library reads its knobs once per process, so the 8192-row
     oracle comparison is re-run in a child process with the knob set."""
     import subprocess
     import sys

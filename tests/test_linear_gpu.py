@@ -224,6 +224,69 @@ def test_linear_dae_loss(z):
     assert abs(float(tl.sum().cpu()) - float((rho ** 2).sum())) / float((rho ** 2).sum()) < 1e-5
 
 
+@pytest.mark.parametrize("M,z,with_bias", [(1024, 32, False), (4096, 8, True), (65536, 32, True)])
+def test_linear_narrow_kernel_dae_loss(M, z, with_bias):
+    """linear_narrow_kernel (K = 256 -> Nout <= 32 on whole 128-row tiles, A fragments straight into registers) with the
+    DAE-loss epilogue, against float64: the mlp-grad score product (no bias) and the mlp-res head (bias)."""
+    g = torch.Generator().manual_seed(M + z)
+    K = 256
+    X = torch.randn(M, K, generator=g); W = torch.randn(z, K, generator=g) / 16
+    b = torch.randn(z, generator=g) if with_bias else None
+    sig = torch.randn(M, generator=g); eps = torch.randn(M, z, generator=g)
+    gref = X.double() @ W.double().T + (b.double() if with_bias else 0.0)
+    rho = sig.double()[:, None] * gref + eps.double()
+    scale = 1.0 / (M * z)
+    Y = torch.full((M, z), float("nan"), device="cuda"); Y2 = torch.full((M, z), float("nan"), device="cuda")
+    tiles = L.lib().ardae_linear_row_tiles(M, z) * L.lib().ardae_linear_col_panels(M, z)
+    assert tiles == M // 128
+    tl = torch.zeros(tiles, device="cuda")
+    kw = dict(bias=b.cuda()) if with_bias else {}
+    run_linear(L.EPI_DAE_LOSS, M, z, [(X.cuda(), pack(W.cuda()))], sigma=sig.cuda(), eps=eps.cuda(), scale=scale, Y=Y, Y2=Y2, tile_loss=tl, **kw)
+    assert relerr(Y, gref) < 2e-5
+    assert relerr(Y2, 2 * sig.double()[:, None] * rho * scale) < 2e-5
+    assert abs(float(tl.double().sum().cpu()) - float((rho ** 2).sum())) / float((rho ** 2).sum()) < 1e-5
+
+
+@pytest.mark.parametrize("M,z", [(32768, 32), (65536, 20)])
+def test_linear_narrow_kernel_bias_epilogue(M, z):
+    """The sampler's output layer on N rows (256 -> z, bias, no activation): too many rows for the per-image kernel, so it
+    streams through linear_narrow_kernel."""
+    g = torch.Generator().manual_seed(M + z)
+    X = torch.randn(M, 256, generator=g); W = torch.randn(z, 256, generator=g) / 16; b = torch.randn(z, generator=g)
+    Y = torch.full((M, z), float("nan"), device="cuda")
+    run_linear(L.EPI_ACT, M, z, [(X.cuda(), pack(W.cuda()))], act=0, bias=b.cuda(), Y=Y)
+    assert relerr(Y, X.double() @ W.double().T + b.double()) < 2e-5
+
+
+@pytest.mark.parametrize("K,Nout,rpg", [(100, 256, 256), (100, 256, 48), (36, 64, 32), (124, 512, 128)])
+@pytest.mark.parametrize("act", ["none", "relu", "softplus"])
+def test_linear_shortk_kernel(K, Nout, rpg, act):
+    """linear_shortk_kernel (N-row forward layers with K <= 128 that is not a multiple of 32: the sampler's noise layer,
+    K = 100): bias + per-image row bias (groups aligned to the 32-row wave tiles or not) + activation, against float64."""
+    M = 32768
+    g = torch.Generator().manual_seed(K * 3 + Nout + rpg)
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5; b = torch.randn(Nout, generator=g)
+    rb = torch.randn((M + rpg - 1) // rpg, Nout, generator=g)
+    pre = X.double() @ W.double().T + b.double() + rb.double().repeat_interleave(rpg, 0)[:M]
+    ref = {"none": pre, "relu": pre.clamp(min=0), "softplus": torch.nn.functional.softplus(pre)}[act]
+    Y = torch.full((M, Nout), float("nan"), device="cuda")
+    run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], bias=b.cuda(), rowbias=rb.cuda(), rows_per_group=rpg, Y=Y)
+    assert relerr(Y, ref) < 2e-5
+
+
+def test_linear_generic_kernel_fallback_paths():
+    """The shape-specialised kernels (per-image split-K, narrow, short-K) take their problems away from linear_kernel; with
+    them switched off (the library reads its knobs once per process) every test of this file must still pass on the generic
+    kernel, which stays the path for everything ragged."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ARDAE_SMALL="0", ARDAE_NARROW="0", ARDAE_SHORTK="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k", "not fallback_paths"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_linear_rejects_bad_args():
     a = L.LinearArgs()
     with pytest.raises(ValueError):
