@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ardae_amd
 from ardae_amd import _lib as L
-B, S, z, h, Ln = 512, 256, 32, 256, 3
+B, S, z, h, Ln = (int(os.environ.get(k, v)) for k, v in (("CB", 512), ("CS", 256), ("CZ", 32), ("CH", 256), ("CL", 3)))
 kind = int(os.environ.get("KIND", "0"))
 d = L.CdaeDesc(kind, z, z, h, Ln, 2)
 lib = L.lib()
@@ -27,5 +27,9 @@ t0 = time.time()
 for _ in range(it): run()
 torch.cuda.synchronize()
 dt = (time.time() - t0) / it
-flop = 2 * (N * 3 * ((z*h + 2*h*h) + ((2*h+1)*h + 2*h*h + h) + (h + 2*h*h + h*h + 2*h*h + z*h)))
+Lm = Ln - 1
+F_inp = z * h + Lm * h * h
+F_neg = (2 * h + 1) * h + Lm * h * h + (h if kind == 0 else h * z)
+S_ = (h + Lm * h * h + h * h + Lm * h * h + z * h) if kind == 0 else 0
+flop = 2 * (N * 3 * (F_inp + F_neg + S_) + B * 3 * F_inp)
 print(f"cdae update: {dt*1e3:.3f} ms  -> {flop/dt/1e12:.1f} TFLOP/s (algorithmic {flop/1e9:.1f} GFLOP), loss {float(loss):.4f}")
