@@ -18,9 +18,9 @@ constexpr int SK_MAXK = 128;
 // SK_MAXCH: compile-time bound of the chunk count (8 k each) - it sizes the three fragment arrays, i.e. the occupancy
 template <int ACT, int SK_MAXCH>
 __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void linear_shortk_kernel(const LinArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  const int row0 = (blockIdx.x * 4 + wave) * 32;
+  const int row0 = (blockIdx.x * 4 + wave) * 32;          // wave-uniform: row bases below live in SGPRs
   const int K = a.src[0].K, nch = (K + 7) >> 3;
 
   const float* xr = a.src[0].x + (size_t)(row0 + l31) * a.src[0].ld + 4 * hh;
@@ -57,12 +57,15 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void linear_shortk_ke
     const int col = nb * 32 + l31;
     float pre = a.bias ? a.bias[col] : 0.f;
     if (rb_uniform) pre += rbrow[col];
+    // stores in the scalar-base form: the row base is uniform (SALU arithmetic), the lane adds one 32-bit byte offset
+    const unsigned voff = (unsigned)((4 * hh * a.ldY + l31) * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const int rowu = row0 + (r & 3) + 8 * (r >> 2);       // + 4 hh is in voff
       float v = acc[r] + pre;
-      if (a.rowbias && !rb_uniform) v += a.rowbias[(size_t)(row / a.rows_per_group) * a.rowbias_ld + col];
-      a.Y[(size_t)row * a.ldY + col] = act_fwd<ACT>(v);
+      if (a.rowbias && !rb_uniform) v += a.rowbias[(size_t)((rowu + 4 * hh) / a.rows_per_group) * a.rowbias_ld + col];
+      char* sb = reinterpret_cast<char*>(a.Y + (size_t)rowu * a.ldY + nb * 32);
+      *reinterpret_cast<float*>(sb + voff) = act_fwd<ACT>(v);
     }
   };
 
