@@ -181,6 +181,40 @@ def test_cdae_loss_grads_vs_oracle_nrow_kernels(kind):
     test_cdae_loss_grads_vs_oracle(kind, 32, 256, 32, 256, 3)
 
 
+@pytest.mark.parametrize("kind", ["grad", "res"])
+def test_cdae_full_size_additivity_over_images(kind):
+    """BASELINE config #2 at FULL size (512 images x 256 samples = 131072 rows, h 256, L 3), which no CPU oracle finishes
+    in test time: the loss is a mean over rows and every row belongs to one image, so the update of the whole batch must
+    equal the average of the updates of its four 128-image shards (32768 rows each - the size the whole-step test pins
+    against the live oracle).  Also checks the score rows of the full launch against the shards' (row-local)."""
+    B, S, z, h, Ln = 512, 256, 32, 256, 3
+    cc = O.CdaeCfg(kind, z, z, h, Ln)
+    pc = O.init_params(O.cdae_param_spec(cc), 5)
+    g = torch.Generator().manual_seed(77)
+    N = B * S
+    xbar = torch.randn(N, z, generator=g) * 2
+    sigma = torch.randn(N, generator=g) * 0.3
+    eps = torch.randn(N, z, generator=g)
+    ctx = torch.randn(B, z, generator=g)
+    hn = CdaeHarness(cc, flat(pc, O.cdae_param_spec(cc)))
+    loss, grads, score = hn.loss_grads(xbar, sigma, eps, ctx, B, S)
+    n_used = grads.numel() - (1 if kind == "grad" else 0)          # neglogprob.fc.bias: untouched (NaN sentinel)
+    assert torch.isfinite(grads[:n_used]).all()
+    parts, Bs = 4, B // 4
+    acc_l, acc_g = 0.0, torch.zeros(n_used, dtype=torch.float64)
+    for i in range(parts):
+        r = slice(i * Bs * S, (i + 1) * Bs * S)
+        l_i, g_i, sc_i = hn.loss_grads(xbar[r], sigma[r], eps[r], ctx[i * Bs:(i + 1) * Bs], Bs, S)
+        acc_l += float(l_i) / parts
+        acc_g += g_i[:n_used].double() / parts
+        assert rel_l2(score[r], sc_i) < 1e-6
+    assert abs(float(loss) - acc_l) <= 1e-5 * abs(acc_l)
+    spec = O.cdae_param_spec(cc)
+    full, shard = split_flat(grads, spec), split_flat(torch.cat([acc_g.float(), torch.zeros(grads.numel() - n_used)]), spec)
+    for n, _ in spec[:-1] if kind == "grad" else spec:
+        assert rel_l2(full[n], shard[n]) < 2e-4, n                  # fp32 sums over 131072 rows in two different orders
+
+
 def test_cdae_loss_grads_shipped_recipe_shape():
     """The cDAE of the shipped dbMNIST recipe (run_vae_dbmnist.sh:36-37: --train-nz-cdae 625, --cdae-n-layers 5, h 256) on
     16 images = 10000 rows: groups of 625 rows are not aligned to any row tile (the per-image row bias of the first energy
@@ -200,7 +234,7 @@ def test_cdae_nrow_kernels_opt_in_variants(knob):
     k, _, v = knob.partition("=")
     env[k] = v or "1"
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
-                        "nrow_kernels and grad and not opt_in and not recipe"], env=env, capture_output=True, text=True, timeout=600)
+                        "nrow_kernels and grad and not opt_in and not recipe and not additivity"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "2 passed" in r.stdout, r.stdout[-500:]      # both cDAE kinds ran (mlp-grad, mlp-res) and nothing else
 
