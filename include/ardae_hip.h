@@ -184,10 +184,12 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
                        void* stream);
 /* The two sampler calls that open a cDAE update (ivae_ardae.py:735,749) on the same images in one pass: z0 = encode(x, std=0)
  * [B, z] and z = forward_hidden(x, nz) [B*nz, z] share the per-image trunk (inp_encode and the image half of the first
- * concat layer), which is computed once.  Workspace: ardae_model_workspace_floats(d, B, nz, 3). */
+ * concat layer), which is computed once.  Workspace: ardae_model_workspace_floats(d, B, nz, 3).
+ * phase 0: everything; phase 1: trunk + z0 only (no noise needed yet); phase 2: the B*nz-row part only, reading the trunk a
+ * phase-1 call left in the same workspace - so a caller can wait for its noise between the two. */
 int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
                             const float* noise, int B, int nz, float* workspace, size_t workspace_floats, float* z0_out,
-                            float* z_out, void* stream);
+                            float* z_out, int phase, void* stream);
 /* ImplicitPosteriorVAE.forward (ivae/mnist.py:267-301): z_out [B*nz, z]; losses[3] = {loss, recon.mean, prior.mean}
  * (device); activations stay in `workspace` for the backward call */
 int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
@@ -206,6 +208,16 @@ int ardae_model_loss_rows(const ardae_model_desc* d, const float* out0, const fl
 int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
                              const float* noise, int B, int nz, float beta, float dloss, const float* dz_extra,
                              float* workspace, size_t workspace_floats, float* grads, float grads_beta, void* stream);
+/* The same backward in two calls, for callers that compute the entropy seed late (ivae_ardae.py:829-834: it needs the UPDATED
+ * cDAE): _decoder = model_loss.backward() through the decoder down to dL/dz (:804; needs only the vae_forward workspace, so it
+ * can run beside the cDAE update), _sampler = dL/dz += seed_scale * dz_extra (:834), back-propagation through the sampler and
+ * all weight gradients.  MLP models (kind 0 / 1); the conv model keeps the single call. */
+int ardae_model_vae_backward_decoder(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                                     const float* noise, int B, int nz, float beta, float dloss, float* workspace,
+                                     size_t workspace_floats, void* stream);
+int ardae_model_vae_backward_sampler(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                                     const float* noise, int B, int nz, const float* dz_extra, float seed_scale,
+                                     float* workspace, size_t workspace_floats, float* grads, float grads_beta, void* stream);
 
 
 /* ---- live per-kernel timing (bench.py roofline): HIP events around every launch on the launch stream ---------- */

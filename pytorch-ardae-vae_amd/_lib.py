@@ -109,7 +109,7 @@ EXPORTS = {
     "ardae_model_encode": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_model_encode_pair": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
-                                                ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+                                                ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "ardae_model_decode": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_model_loss_rows": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
@@ -120,6 +120,11 @@ EXPORTS = {
     "ardae_model_vae_backward": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                                  ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
+    "ardae_model_vae_backward_decoder": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "ardae_model_vae_backward_sampler": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+                                                         ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
     "ardae_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "ardae_profile_report": (ctypes.c_int, [ctypes.POINTER(ProfileEntry), ctypes.c_int]),
     "ardae_cdae_score": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int,

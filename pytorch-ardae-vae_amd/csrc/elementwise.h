@@ -37,6 +37,8 @@ int launch_adam_ref(float* p, const float* g, float* m, float* v, float* vmax, i
 int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, double lr, double alpha, double eps,
                    double momentum, hipStream_t st);
 
+// y += alpha*x (the entropy-gradient seed of ivae_ardae.py:834 added to dL/dz)
+int launch_axpy(const float* x, int64_t n, float alpha, float* y, hipStream_t st);
 // y = alpha*x + beta (the encoder's 2x-1 rescale, ivae/mnist.py:81)
 int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t st);
 // Row losses of ImplicitPosteriorVAE.loss (ivae/mnist.py:240-249, toy.py:777-786) and, when write_grads, their gradients:

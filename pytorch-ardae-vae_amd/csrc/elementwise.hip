@@ -253,6 +253,10 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
   }
 }
 
+__global__ void axpy_kernel(const float* __restrict__ x, int64_t n, float alpha, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
 __global__ void affine_kernel(const float* __restrict__ x, int64_t n, float alpha, float beta, float* __restrict__ y) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = alpha * x[i] + beta;
 }
@@ -462,6 +466,14 @@ int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, d
   ARDAE_CHECK_ARG(p && g && sq && n > 0 && (momentum <= 0.0 || buf), "rmsprop: bad arguments");
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, sq, buf, n, (float)lr, (float)alpha, (float)eps,
                      (float)momentum);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_axpy(const float* x, int64_t n, float alpha, float* y, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
+  ARDAE_CHECK_ARG(x && y && n > 0, "axpy: bad arguments");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, alpha, y);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

@@ -328,13 +328,16 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
 }
 
 int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
-                            int B, int nz, float* workspace, size_t workspace_floats_, float* z0_out, float* z_out, void* stream) {
+                            int B, int nz, float* workspace, size_t workspace_floats_, float* z0_out, float* z_out, int phase,
+                            void* stream) {
   ARDAE_TRY(desc_ok(d));
-  ARDAE_CHECK_ARG(params && packed && x && noise && workspace && z0_out && z_out, "model_encode_pair: null pointer argument");
+  ARDAE_CHECK_ARG(phase >= 0 && phase <= 2, "model_encode_pair: phase must be 0 (all), 1 (trunk + z0) or 2 (N-row stack)");
+  ARDAE_CHECK_ARG(params && packed && x && (noise || phase == 1) && workspace && z0_out && z_out, "model_encode_pair: null pointer argument");
   ARDAE_CHECK_ARG(B > 0 && nz > 0 && (int64_t)B * nz < (int64_t)1 << 30, "model_encode_pair: bad batch (B=%d nz=%d)", B, nz);
   ARDAE_CHECK_ARG(workspace_floats_ >= ardae_model_workspace_floats(d, B, nz, 3), "model_encode_pair: workspace too small");
   if (d->kind == 2) {   // conv sampler: two passes over the same workspace
-    ARDAE_TRY(ardae_model_encode(d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, stream));
+    if (phase != 2) ARDAE_TRY(ardae_model_encode(d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, stream));
+    if (phase == 1) return 0;
     return ardae_model_encode(d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, stream);
   }
   hipStream_t st = (hipStream_t)stream;
@@ -348,10 +351,12 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
   for (size_t i = 1; i < P.stack.size(); ++i) t0[i] = ws.take((size_t)B * P.h);
   float* zero = ws.take((size_t)B * P.nd);
   ARDAE_CHECK_ARG(ws.ok, "model_encode_pair: internal workspace accounting error");
-  ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * P.nd * sizeof(float), st));
-  ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
-  ARDAE_TRY(encode_stack(P, K, params, packed, zero, B, 1, W.rb, t0, z0_out, st));      // encode(x, std=0): the draw is multiplied by 0
-  ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, st));   // forward_hidden(x, nz)
+  if (phase != 2) {
+    ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * P.nd * sizeof(float), st));
+    ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
+    ARDAE_TRY(encode_stack(P, K, params, packed, zero, B, 1, W.rb, t0, z0_out, st));    // encode(x, std=0): the draw is multiplied by 0
+  }
+  if (phase != 1) ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, st));   // forward_hidden(x, nz); W.rb from phase 1
   return chain_scope.finish();
 }
 
@@ -421,15 +426,13 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   return launch_vae_loss_finalize(W.rec_row, W.pri_row, R, beta, losses, st);
 }
 
-int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
-                             int B, int nz, float beta, float dloss, const float* dz_extra, float* workspace,
-                             size_t workspace_floats_, float* grads, float grads_beta, void* stream) {
-  ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
-  ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
-  hipStream_t st = (hipStream_t)stream;
+// phases: 1 = loss gradients + decoder backward up to dz (needs nothing from the cDAE), 2 = entropy seed + sampler backward +
+// weight gradients, 3 = both.  With phases == 3 the (pre-scaled) seed enters through the loss kernel; with phases == 2 it is
+// added to dz as seed_scale * dz_extra.
+static int vae_backward_impl(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
+                             int B, int nz, float beta, float dloss, const float* dz_extra, float seed_scale, float* workspace,
+                             size_t workspace_floats_, float* grads, float grads_beta, int phases, hipStream_t st) {
   ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
-  if (d->kind == 2)
-    return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
   Bump ws(workspace, workspace_floats_);
@@ -438,8 +441,9 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   const int R = B * nz, h = P.h, act = P.act;
   const size_t ns = P.stack.size(), ndec = P.dec.size(), ninp = P.inp.size(), nh = P.heads.size();
   const float gscale = dloss / (float)R;
-  ARDAE_TRY(launch_vae_loss(P.kind, W.o[0], P.kind == 1 ? W.o[1] : nullptr, x, W.z, R, nz, P.D, P.zd, beta, 1, gscale, dz_extra,
-                            W.rec_row, W.pri_row, W.dox[0], P.kind == 1 ? W.dox[1] : nullptr, W.dzq, st));
+  if (phases & 1) {
+  ARDAE_TRY(launch_vae_loss(P.kind, W.o[0], P.kind == 1 ? W.o[1] : nullptr, x, W.z, R, nz, P.D, P.zd, beta, 1, gscale,
+                            phases == 3 ? dz_extra : nullptr, W.rec_row, W.pri_row, W.dox[0], P.kind == 1 ? W.dox[1] : nullptr, W.dzq, st));
   // decoder backward
   {
     LinArgs A{}; A.S = W.dcd[ndec]; A.ldS = h; A.Y = W.ddec[ndec]; A.ldY = h; A.M = R; A.Nout = h; A.act = act; A.nsrc = (int)nh;
@@ -454,6 +458,9 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
     LinArgs A{}; A.S = W.dzq; A.ldS = P.zd; A.Q = W.dzq; A.ldQ = P.zd; A.Y = W.dz; A.ldY = P.zd;
     ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, R, P.zd, W.ddec[1], h, h, packed + K.dec_b[0], A, st));
   }
+  }
+  if (!(phases & 2)) return chain_scope.finish();
+  if (phases == 2 && dz_extra) ARDAE_TRY(launch_axpy(dz_extra, (int64_t)R * P.zd, seed_scale, W.dz, st));   // + the entropy seed
   // sampler backward
   for (size_t i = ns - 1; i >= 1; --i) {
     LinArgs A{}; A.S = W.t[i]; A.ldS = h; A.Y = W.dt[i]; A.ldY = h;
@@ -503,6 +510,39 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
          grads + P.inp[l - 1].b);
   ARDAE_CHECK_ARG(ws.ok, "model_vae_backward: internal workspace accounting error");
   return launch_wgrad_batch(probs.data(), (int)probs.size(), st);
+}
+
+int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
+                             int B, int nz, float beta, float dloss, const float* dz_extra, float* workspace,
+                             size_t workspace_floats_, float* grads, float grads_beta, void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
+  ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->kind == 2) {
+    ChainScope chain_scope(st);
+    return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
+  }
+  return vae_backward_impl(d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, 1.f, workspace, workspace_floats_, grads, grads_beta, 3, st);
+}
+
+int ardae_model_vae_backward_decoder(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                                     const float* noise, int B, int nz, float beta, float dloss, float* workspace,
+                                     size_t workspace_floats_, void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
+  ARDAE_CHECK_ARG(noise, "model_vae_backward_decoder: null pointer argument");
+  ARDAE_CHECK_ARG(d->kind != 2, "model_vae_backward_decoder: the conv model has no split backward (use ardae_model_vae_backward)");
+  return vae_backward_impl(d, params, packed, x, noise, B, nz, beta, dloss, nullptr, 0.f, workspace, workspace_floats_, nullptr, 0.f, 1,
+                           (hipStream_t)stream);
+}
+
+int ardae_model_vae_backward_sampler(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
+                                     const float* noise, int B, int nz, const float* dz_extra, float seed_scale, float* workspace,
+                                     size_t workspace_floats_, float* grads, float grads_beta, void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
+  ARDAE_CHECK_ARG(noise && grads, "model_vae_backward_sampler: null pointer argument");
+  ARDAE_CHECK_ARG(d->kind != 2, "model_vae_backward_sampler: the conv model has no split backward (use ardae_model_vae_backward)");
+  return vae_backward_impl(d, params, packed, x, noise, B, nz, 0.f, 0.f, dz_extra, seed_scale, workspace, workspace_floats_, grads,
+                           grads_beta, 2, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -92,6 +92,8 @@ class ArdaeEngine:
         # The first half of the VAE update (sampler + decoder + ELBO pieces on the VAE batch, ~25 per-image launches) needs
         # nothing from the cDAE update: step() runs it on a side stream next to the cDAE phase's N-row kernels.
         self.overlap = os.environ.get("ARDAE_OVERLAP", "1") != "0"
+        # MLP models: the decoder half of the VAE backward (down to dL/dz) joins the forward half on the side stream
+        self.split_backward = int(md.kind) != 2 and os.environ.get("ARDAE_SPLIT_BACKWARD", "1") != "0"
         self._side = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self.repack()
 
@@ -144,12 +146,24 @@ class ArdaeEngine:
             ns, xi, eps = noise["sampler"], noise["sigma"].reshape(-1), noise["eps"]
         elif drawn is not None:
             ns, xi, eps = self.noise_s, self.xi, self.eps
-            torch.cuda.current_stream().wait_event(drawn)
         else:
             ns, xi, eps = self._normal(self.noise_s), self._normal(self.xi), self._normal(self.eps)
-        # context == latent_mean == encode(x, std=0) (lt0) and forward_hidden(x, nz) share the per-image trunk: one pass
-        L.check(lib.ardae_model_encode_pair(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(ns), B, nz,
-                                            L.ptr(self.ws), self.ws.numel(), L.ptr(self.z0), L.ptr(self.latent), st), "ardae_model_encode_pair")
+        # context == latent_mean == encode(x, std=0) (lt0) and forward_hidden(x, nz) share the per-image trunk: one pass,
+        # cut in two where the noise is first needed when it is being drawn on the side stream
+        def pair(phase):
+            L.check(lib.ardae_model_encode_pair(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(ns), B, nz,
+                                                L.ptr(self.ws), self.ws.numel(), L.ptr(self.z0), L.ptr(self.latent), phase, st),
+                    "ardae_model_encode_pair")
+        # (opt-in, ARDAE_PAIR_SPLIT=1: under HIP-graph replay the extra mid-chain cross-stream edge cost 0.22 ms per step on
+        # MI355X / ROCm 7.2, while eager launches gained 0.02 - so the default waits for the draws up front)
+        if drawn is not None and not noise and os.environ.get("ARDAE_PAIR_SPLIT", "0") == "1":
+            pair(1)
+            torch.cuda.current_stream().wait_event(drawn)
+            pair(2)
+        else:
+            if drawn is not None and not noise:
+                torch.cuda.current_stream().wait_event(drawn)
+            pair(0)
         L.check(lib.ardae_latent_perturb(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, z, cfg.std_scale, cfg.delta,
                                          L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb")
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
@@ -172,6 +186,11 @@ class ArdaeEngine:
                 "ardae_model_vae_forward")
         self._encode(x, None, 1, self.z0v, self.ws_small_v)
         L.check(lib.ardae_center_scale(L.ptr(self.zv), L.ptr(self.z0v), B, nz, self.model.z_dim, cfg.std_scale, L.ptr(self.u), st))
+        if self.split_backward:
+            # model_loss.backward() through the decoder down to dL/dz (ivae_ardae.py:804) needs nothing from the cDAE either
+            L.check(lib.ardae_model_vae_backward_decoder(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
+                                                         float(beta), 1.0, L.ptr(self.ws_vae), self.ws_vae.numel(), st),
+                    "ardae_model_vae_backward_decoder")
         return nv
 
     def vae_backward_part(self, x, nv, beta=None, apply_update=True):
@@ -184,10 +203,16 @@ class ArdaeEngine:
                                      L.ptr(self.g), st), "ardae_cdae_score")
         # seed of (s (z - z0)).backward(beta g / (B nz)) w.r.t. z  (ivae_ardae.py:834); B is the per-rank batch because the
         # ranks' gradients are averaged afterwards (mean over ranks of 1/B_local == 1/B_global sum)
-        self.g.mul_(dist.entropy_seed_scale(cfg.std_scale, beta, B, nz))
-        L.check(lib.ardae_model_vae_backward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
-                                             float(beta), 1.0, L.ptr(self.g), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.grads_m),
-                                             0.0, st), "ardae_model_vae_backward")
+        seed_scale = dist.entropy_seed_scale(cfg.std_scale, beta, B, nz)
+        if self.split_backward:      # the decoder half already ran in vae_forward_part
+            L.check(lib.ardae_model_vae_backward_sampler(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
+                                                         L.ptr(self.g), float(seed_scale), L.ptr(self.ws_vae), self.ws_vae.numel(),
+                                                         L.ptr(self.grads_m), 0.0, st), "ardae_model_vae_backward_sampler")
+        else:
+            self.g.mul_(seed_scale)
+            L.check(lib.ardae_model_vae_backward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
+                                                 float(beta), 1.0, L.ptr(self.g), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.grads_m),
+                                                 0.0, st), "ardae_model_vae_backward")
         self._allreduce_mean(self.grads_m)
         if apply_update:
             if self._in_step:      # t and the bias corrections come from the device step state (advanced by step())
@@ -219,7 +244,7 @@ class ArdaeEngine:
                 self._side.wait_stream(main)
                 drawn = None
                 with torch.cuda.stream(self._side):
-                    if noise is None and len(xs) == 1:
+                    if noise is None and len(xs) == 1 and os.environ.get("ARDAE_SIDE_RNG", "1") != "0":
                         # the cDAE update's three draws need nothing but the step state: they run beside the sampler trunk
                         self._normal(self.noise_s, 0); self._normal(self.xi, 1); self._normal(self.eps, 2)
                         self._draws = 3
