@@ -182,27 +182,41 @@ __device__ __forceinline__ void wgrad_reduce_store(const WgradProblem& P, size_t
   *dst = (P.beta != 0.f ? P.beta * *dst : 0.f) + s;
 }
 
-__global__ void wgrad_reduce_kernel(const WgradBatchDev batch) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradBatchDev batch) {
+  // 256 threads = 64 consecutive float4 of the matrix x 4 split groups: group g sums splits g, g+4, ... (four of its loads
+  // in flight), the groups meet in LDS in a fixed order.  One thread per element left each thread a chain of ~50 dependent
+  // round trips (43 us for 64 MB); this way it is ~4.
+  __shared__ f32x4 red[4][64];
   const WgradProblem& P = batch.p[blockIdx.y];
   const size_t n_mat = (size_t)P.O * P.I;
   const size_t n_vec = (P.bias_pair >= 0 && P.partial_vec) ? 2 * (size_t)P.O : 0;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
   const int S = P.splits;
+  const int lane64 = threadIdx.x & 63, sg = threadIdx.x >> 6;
   if ((n_mat & 3) == 0 && (reinterpret_cast<uintptr_t>(P.partial) & 15) == 0) {
     const size_t n4 = n_mat >> 2;
-    for (size_t q = tid; q < n4; q += nthr) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(P.partial) + q;
+    for (size_t q0 = (size_t)blockIdx.x * 64; q0 < n4; q0 += (size_t)gridDim.x * 64) {   // uniform per workgroup
+      const size_t q = q0 + lane64;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      int sp = 0;
-      for (; sp + 4 <= S; sp += 4) {
-        const f32x4 v0 = src[(size_t)sp * n4], v1 = src[(size_t)(sp + 1) * n4], v2 = src[(size_t)(sp + 2) * n4], v3 = src[(size_t)(sp + 3) * n4];
-        acc += (v0 + v1) + (v2 + v3);
+      if (q < n4) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(P.partial) + q;
+        int sp = sg;
+        for (; sp + 12 < S; sp += 16) {
+          const f32x4 v0 = src[(size_t)sp * n4], v1 = src[(size_t)(sp + 4) * n4], v2 = src[(size_t)(sp + 8) * n4], v3 = src[(size_t)(sp + 12) * n4];
+          acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; sp < S; sp += 4) acc += src[(size_t)sp * n4];
       }
-      for (; sp < S; ++sp) acc += src[(size_t)sp * n4];
+      red[sg][lane64] = acc;
+      __syncthreads();
+      if (sg == 0 && q < n4) {
+        const f32x4 t = (red[0][lane64] + red[1][lane64]) + (red[2][lane64] + red[3][lane64]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wgrad_reduce_store(P, 4 * q + j, acc[j]);
+        for (int j = 0; j < 4; ++j) wgrad_reduce_store(P, 4 * q + j, t[j]);
+      }
+      __syncthreads();
     }
   } else {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
     for (size_t e = tid; e < n_mat; e += nthr) {
       float s = 0.f;
       int sp = 0;
@@ -213,19 +227,29 @@ __global__ void wgrad_reduce_kernel(const WgradBatchDev batch) {
       wgrad_reduce_store(P, e, s);
     }
   }
-  for (size_t v = tid; v < n_vec; v += nthr) {
-    const int which = (int)(v / P.O), o = (int)(v % P.O);
-    float* dst = which == 0 ? (P.out_bias ? P.out_bias + o : nullptr)
-                            : (P.out_rowscale ? P.out_rowscale + (size_t)o * P.ld_rowscale : nullptr);
-    if (dst) {
-      const float* pv = P.partial_vec + (size_t)which * P.O + o;
-      const size_t st2 = 2 * (size_t)P.O;
-      float s = 0.f;
-      int sp = 0;
-      for (; sp + 4 <= S; sp += 4) s += (pv[sp * st2] + pv[(sp + 1) * st2]) + (pv[(sp + 2) * st2] + pv[(sp + 3) * st2]);
-      for (; sp < S; ++sp) s += pv[sp * st2];
-      *dst = (P.beta != 0.f ? P.beta * *dst : 0.f) + s;
+  // bias / sigma-column sums: the same four split groups per output
+  for (size_t v0 = (size_t)blockIdx.x * 64; v0 < n_vec; v0 += (size_t)gridDim.x * 64) {
+    const size_t v = v0 + lane64;
+    float s = 0.f;
+    float* dst = nullptr;
+    if (v < n_vec) {
+      const int which = (int)(v / P.O), o = (int)(v % P.O);
+      dst = which == 0 ? (P.out_bias ? P.out_bias + o : nullptr) : (P.out_rowscale ? P.out_rowscale + (size_t)o * P.ld_rowscale : nullptr);
+      if (dst) {
+        const float* pv = P.partial_vec + (size_t)which * P.O + o;
+        const size_t st2 = 2 * (size_t)P.O;
+        int sp = sg;
+        for (; sp + 12 < S; sp += 16) s += (pv[sp * st2] + pv[(sp + 4) * st2]) + (pv[(sp + 8) * st2] + pv[(sp + 12) * st2]);
+        for (; sp < S; sp += 4) s += pv[sp * st2];
+      }
     }
+    red[sg][lane64][0] = s;
+    __syncthreads();
+    if (sg == 0 && dst) {
+      const float t = (red[0][lane64][0] + red[1][lane64][0]) + (red[2][lane64][0] + red[3][lane64][0]);
+      *dst = (P.beta != 0.f ? P.beta * *dst : 0.f) + t;
+    }
+    __syncthreads();
   }
 }
 
@@ -304,7 +328,7 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
   memset(&b, 0, sizeof(b));
   b.nprob = nprob;
   for (int i = 0; i < nprob; ++i) b.p[i] = local[i];
-  const int rb = (int)ceil_div64((int64_t)max_elems, 256);
+  const int rb = (int)ceil_div64((int64_t)max_elems, 256);   // 256 elements = 64 float4 per workgroup pass
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb < 1024 ? rb : 1024, nprob), dim3(256), 0, st, b);
   ARDAE_LAUNCH_CHECK();
   return 0;
