@@ -155,6 +155,74 @@ __global__ __launch_bounds__(256) void latent_perturb_kernel(const float* __rest
   }
 }
 
+// Register-resident variant for nz * zd == 256 * NV with zd a power of two: thread t owns elements t + 256 j (all of the same
+// latent dimension d = t % zd, samples r = t / zd + (256 / zd) j - the same assignment and summation order as the kernel
+// above, so the results are bit-identical), loaded ONCE with all NV loads in flight instead of three dependent passes.
+template <int NV>
+__global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __restrict__ latent, const float* __restrict__ z0,
+                                                                 const float* __restrict__ xi, const float* __restrict__ eps, int nz,
+                                                                 int zd, float std_scale, float delta, float* __restrict__ xbar,
+                                                                 float* __restrict__ sigma, float* __restrict__ std_b) {
+  __shared__ float red[256];
+  __shared__ float stat[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int d = t & (zd - 1), RG = 256 / zd;
+  const size_t base = (size_t)b * nz * zd;
+  const float* lat = latent + base;
+  const float z0d = z0[(size_t)b * zd + d];
+  float u[NV], ev[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) u[j] = lat[t + 256 * j];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) ev[j] = eps[base + t + 256 * j];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    u[j] = std_scale * (u[j] - z0d);
+    s += u[j];
+  }
+  red[t] = s;
+  __syncthreads();
+  if (t < zd) {
+    float acc = 0.f;
+    for (int g = 0; g < RG; ++g) acc += red[g * zd + t];
+    stat[t] = acc / (float)nz;
+  }
+  __syncthreads();
+  const float mean = stat[d];
+  __syncthreads();
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float c = u[j] - mean;
+    ss += c * c;
+  }
+  red[t] = ss;
+  __syncthreads();
+  if (t < zd) {
+    float acc = 0.f;
+    for (int g = 0; g < RG; ++g) acc += red[g * zd + t];
+    stat[t] = sqrtf(acc / (float)(nz - 1));
+  }
+  __syncthreads();
+  if (t == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < zd; ++i) acc += stat[i];
+    red[0] = delta * (acc / (float)zd);
+  }
+  __syncthreads();
+  const float sb = red[0];
+  if (t == 0) std_b[b] = sb;
+  const int r0 = t / zd;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const size_t row = (size_t)b * nz + r0 + RG * j;
+    const float sg = sb * xi[row];
+    xbar[base + t + 256 * j] = u[j] + sg * ev[j];
+    if (d == 0) sigma[row] = sg;
+  }
+}
+
 __global__ void center_scale_kernel(const float* __restrict__ latent, const float* __restrict__ z0, int64_t n, int nz, int zd,
                                     float std_scale, float* __restrict__ u) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -350,8 +418,19 @@ int launch_latent_perturb(const float* latent, const float* z0, const float* xi,
   ARDAE_CHECK_ARG(B > 0 && nz >= 2 && zd >= 1 && zd <= 256, "latent_perturb: need B>0, nz>=2 (unbiased std), 1<=z<=256 (B=%d nz=%d z=%d)", B, nz, zd);
   int zp = 1;
   while (zp < zd) zp <<= 1;
-  hipLaunchKernelGGL(latent_perturb_kernel, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, zp, std_scale, delta, xbar,
-                     sigma, std_b);
+  const int64_t per_image = (int64_t)nz * zd;
+  const bool reg_ok = zp == zd && per_image % 256 == 0;
+#define ARDAE_LP_REG(NV_)                                                                                                          \
+  hipLaunchKernelGGL(latent_perturb_reg_kernel<NV_>, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, std_scale, delta, xbar, \
+                     sigma, std_b)
+  if (reg_ok && per_image == 256 * 8) ARDAE_LP_REG(8);
+  else if (reg_ok && per_image == 256 * 16) ARDAE_LP_REG(16);
+  else if (reg_ok && per_image == 256 * 32) ARDAE_LP_REG(32);
+  else if (reg_ok && per_image == 256 * 64) ARDAE_LP_REG(64);
+  else
+    hipLaunchKernelGGL(latent_perturb_kernel, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, zp, std_scale, delta, xbar,
+                       sigma, std_b);
+#undef ARDAE_LP_REG
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

@@ -262,7 +262,7 @@ int wgrad_splits(int M, int O, int I, int nproblems_hint) {
   const int tiles = ceil_div(O, BO) * ceil_div(I, BI);
   const int target = 1024;   // ~2 resident workgroups per CU x 256 CUs x 2 waves of work
   int s = target / (tiles * (nproblems_hint > 0 ? nproblems_hint : 1));
-  const int max_s = ceil_div(M, 4 * RC);   // at least 4 chunks of rows per split
+  const int max_s = ceil_div(M, 2 * RC);   // at least 2 chunks of rows per split (per-image problems are latency: more, shorter workgroups)
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   return s;

@@ -396,3 +396,27 @@ def test_on_device_data_helpers():
     strong = net.data.dynamic_binarize((probs > 0.5).float())               # probabilities 0 / 1 are reproduced exactly
     assert torch.equal(strong, (probs > 0.5).float())
     assert not torch.equal(net.data.dynamic_binarize(probs), xb)            # a fresh draw every call
+
+
+@pytest.mark.parametrize("B,nz,z", [(5, 256, 32), (3, 512, 32), (4, 64, 32), (3, 70, 5), (2, 1024, 32), (6, 256, 2)])
+def test_latent_perturb_kernels(B, nz, z):
+    """Latent statistics + perturbation (ivae_ardae.py:753-767, graddae/mlp.py:21-23) against the oracle's restatement: the
+    register-resident kernel (nz * z a multiple of 256 up to 64 values per thread, z a power of two) and the generic one."""
+    import ctypes
+    from ardae_amd import _lib as L
+    g = torch.Generator().manual_seed(B * 1000 + nz + z)
+    z0 = torch.randn(B, z, generator=g)
+    latent = z0[:, None, :] + 0.05 * torch.randn(B, nz, z, generator=g)
+    xi, eps = torch.randn(B, nz, 1, generator=g), torch.randn(B * nz, z, generator=g)
+    u, std = O.latent_stats(latent, z0.view(B, 1, z), 1e4, 0.1)
+    sigma_ref = (std * xi).reshape(-1)
+    xbar_ref = u.reshape(-1, z) + sigma_ref[:, None] * eps
+    d = lambda t: t.contiguous().cuda()
+    lat_d, z0_d, xi_d, eps_d = d(latent), d(z0), d(xi.reshape(-1)), d(eps)
+    xbar, sigma, std_b = torch.empty(B * nz, z, device="cuda"), torch.empty(B * nz, device="cuda"), torch.empty(B, device="cuda")
+    L.check(L.lib().ardae_latent_perturb(L.ptr(lat_d), L.ptr(z0_d), L.ptr(xi_d), L.ptr(eps_d), B, nz, z, 1e4, 0.1, L.ptr(xbar), L.ptr(sigma),
+                                         L.ptr(std_b), L.stream_ptr()), "ardae_latent_perturb")
+    torch.cuda.synchronize()
+    assert rel_l2(std_b, std.reshape(-1)) < 1e-5
+    assert rel_l2(sigma, sigma_ref) < 1e-5
+    assert rel_l2(xbar, xbar_ref) < 1e-5
