@@ -1,0 +1,61 @@
+"""Whole-step time of the BASELINE.json configs' per-GPU shards on one MI355X (scratch; the contract bench is bench.py = config #2).
+
+    python scratch/bench_configs.py [1 2 4 5]
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ardae_amd as net
+
+def cfg(i):
+    if i == 1:   # 25 Gaussians, ToyIPVAE concat z=2, relu; cdae mlp-grad h=256 L=3; batch 512 x nz 256
+        m = net.ToyIPVAE(input_dim=2, noise_dim=10, h_dim=256, num_hidden_layers=2, nonlinearity="relu", enc_type="concat", z_dim=2)
+        c = net.MLPGradCARDAE(input_dim=2, context_dim=2, std=1., h_dim=256, num_hidden_layers=3, nonlinearity="softplus",
+                              noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 512, 256, lambda B, dev: net.data.gaussians25(25 * ((B + 24) // 25))[0][torch.randperm(25 * ((B + 24) // 25))[:B].to(dev)].contiguous(), dict(z=2, h=256, L=3, kind="grad")
+    if i == 2:
+        m = net.MNISTIPVAE(input_dim=784, noise_dim=100, h_dim=256, num_hidden_layers=2, nonlinearity="softplus", enc_type="concat", z_dim=32)
+        c = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=256, num_hidden_layers=3, nonlinearity="softplus",
+                              noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 512, 256, lambda B, dev: (torch.rand(B, 784, device=dev) < 0.13).float(), dict(z=32, h=256, L=3, kind="grad")
+    if i == 4:   # conv model, cdae h=512 L=4, batch 1024 x nz 512 over 4 GPUs -> 256 images per GPU
+        m = net.ConvIPVAE(input_height=28, input_channels=1, z_dim=32, noise_dim=100, nonlinearity="softplus")
+        c = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=512, num_hidden_layers=4, nonlinearity="softplus",
+                              noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 256, 512, lambda B, dev: (torch.rand(B, 1, 28, 28, device=dev) < 0.13).float(), dict(z=32, h=512, L=4, kind="grad")
+    if i == 5:   # 3072-pixel flat images, resdae h=1024 L=6, batch 2048 x nz 1024 over 8 GPUs -> 256 images per GPU
+        m = net.MNISTIPVAE(input_dim=3072, noise_dim=100, h_dim=256, num_hidden_layers=2, nonlinearity="softplus", enc_type="concat", z_dim=32)
+        c = net.MLPResCARDAE(input_dim=32, context_dim=32, std=1., h_dim=1024, num_hidden_layers=6, nonlinearity="softplus",
+                             noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 256, 1024, lambda B, dev: (torch.rand(B, 3072, device=dev) < 0.5).float(), dict(z=32, h=1024, L=6, kind="res")
+    raise SystemExit(f"no config {i}")
+
+def cdae_flops(B, nz, z, h, L, kind):
+    N, Lm = B * nz, L - 1
+    F_inp = z * h + Lm * h * h
+    F_neg = (2 * h + 1) * h + Lm * h * h + (h if kind == "grad" else h * z)
+    S = (h + Lm * h * h + h * h + Lm * h * h + z * h) if kind == "grad" else 0
+    return 2 * (N * 3 * (F_inp + F_neg + S) + B * 3 * F_inp)
+
+for i in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5]:
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m, c, B, nz, data, shp = cfg(i)
+    m, c = m.to(dev), c.to(dev)
+    eng = net.ArdaeEngine(m, c, net.TrainConfig(nz_cdae=nz), batch_size=B)
+    x1, x2 = data(B, dev), data(B, dev)
+    steps = 20 if i < 4 else 5
+    for _ in range(3):
+        eng.step(x1, x2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(x1, x2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = cdae_flops(B, nz, **shp)
+    st = eng.stats()
+    print(f"config #{i}: {B} images x {nz} samples per GPU: {dt*1e3:8.2f} ms/step  {1/dt:7.1f} steps/s  cDAE-update FLOPs {fl/1e12:.3f} T -> >= {fl/dt/1e12:5.1f} TFLOP/s"
+          f"  (cdae_loss {st['cdae_loss']:.4f}, model_loss {st['model_loss']:.2f})", flush=True)
+    del eng, m, c
+    torch.cuda.empty_cache()
