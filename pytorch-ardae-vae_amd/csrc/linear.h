@@ -76,10 +76,5 @@ int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);
 bool linear_fchain_layer_ok(const LinArgs& a, int epi);
 int linear_fchain_length();
 int launch_linear_fchain(const LinArgs* layers, int nl, int epi, hipStream_t st);
-// warp-specialised persistent variant (linear_ws.hip) for the big N-row layers
-bool linear_ws_eligible(const LinArgs& a, int epi);
-int launch_linear_ws(const LinArgs& a, int epi, hipStream_t st);
-bool linear_ws2_eligible(const LinArgs& a, int epi);
-int launch_linear_ws2(const LinArgs& a, int epi, hipStream_t st);
 
 }  // namespace ardae

@@ -751,16 +751,6 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
     ARDAE_CHECK_ARG(a.src[s].x && a.src[s].wp && a.src[s].K > 0 && a.src[s].ld >= a.src[s].K,
                     "linear: bad source %d (K=%d ld=%d)", s, a.src[s].K, a.src[s].ld);
   ARDAE_CHECK_ARG(a.Y || epi == EPI_DAE_LOSS, "linear: Y is null");
-  // The warp-specialised persistent kernel (linear_ws.hip) is opt-in (ARDAE_WS=1) until its weight fragments come from LDS:
-  // streaming them from L2 inside the MFMA wave queues behind the producers' HBM traffic ("what was measured").
-  static const char* ws_env = getenv("ARDAE_WS");
-  static const int ws_mode = ws_env ? atoi(ws_env) : 0;          // 1: weights from L2 in the MFMA wave, 2: both operands via LDS
-  if (ws_mode && (epi == EPI_DACT || epi == EPI_CHAIN)) {
-    ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT/EPI_CHAIN need S");
-    if (epi == EPI_CHAIN) ARDAE_CHECK_ARG(a.R && a.Y2, "linear: EPI_CHAIN needs R and Y2");
-  }
-  if (ws_mode == 2 && linear_ws2_eligible(a, epi)) return launch_linear_ws2(a, epi, st);
-  if (ws_mode == 1 && linear_ws_eligible(a, epi) && a.src[0].K <= 256) return launch_linear_ws(a, epi, st);
   if (linear_small_eligible(a, epi)) {
     ARDAE_TRY(validate_linear(a, epi));
     return launch_linear_small(a, epi, st);

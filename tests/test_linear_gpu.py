@@ -55,7 +55,7 @@ def d1(act, a):
 
 @pytest.mark.parametrize("M,K,Nout", [(64, 256, 256), (200, 100, 256), (131, 37, 96), (512, 784, 256),
                                       (96, 256, 32), (300, 64, 8), (64, 2, 64), (1024, 512, 512), (70, 266, 2),
-                                      # big-M shapes take the warp-specialised persistent kernel (linear_ws.hip)
+                                      # big-M shapes: the software-pipelined wide kernel where the shape allows, else the generic 64 x 256 tiling
                                       (4096, 256, 256), (8192, 32, 256), (4128, 256, 64), (4096, 64, 192)])
 @pytest.mark.parametrize("act", ["none", "relu", "softplus"])
 def test_linear_act(M, K, Nout, act):
@@ -106,7 +106,7 @@ def test_linear_transposed_pack_and_two_sources():
 def test_linear_wide_kernel_epilogues(M, K, Nout, epi):
     """The software-pipelined N-row kernel (linear_wide_kernel: >= 128 tiles of 64 rows, K in {256, 32}): one tile per
     workgroup (8192 rows), one or two (24576: deferred stores carried into the next tile), four (65536)."""
-    test_linear_warp_specialised_epilogues(M, K, Nout, epi, rpg=64)
+    test_linear_big_m_epilogues(M, K, Nout, epi, rpg=64)
 
 
 @pytest.mark.parametrize("epi", ["act", "dact_q", "chain"])
@@ -145,8 +145,8 @@ def test_linear_wide_kernel_full_size_matches_generic_kernel(epi):
 
 @pytest.mark.parametrize("M,K,Nout", [(4096, 256, 256), (12288, 32, 256), (4096, 256, 128)])
 @pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
-def test_linear_warp_specialised_epilogues(M, K, Nout, epi, rpg=16):
-    """Same operators on the persistent warp-specialised kernel (M >= 4096, K % 32 == 0)."""
+def test_linear_big_m_epilogues(M, K, Nout, epi, rpg=16):
+    """The derivative / score-seed epilogues at a few thousand rows (M >= 4096, K % 32 == 0), against float64."""
     g = torch.Generator().manual_seed(M + K + Nout)
     X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5
     S = torch.nn.functional.softplus(torch.randn(M, Nout, generator=g) * 3)

@@ -61,7 +61,7 @@ def main(src, dst_prefix):
         out[k] = e
     # bench.py looks kernels up by the template-argument form it prints; add those aliases
     for k in list(out):
-        m = re.match(r"(linear_kernel|linear_ws2?_kernel)<(.*)>", k)
+        m = re.match(r"(linear_kernel)<(.*)>", k)
         if m:
             out[f"{m.group(1)}<{m.group(2)}>"] = out[k]
         m = re.match(r"linear_wide_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", k)
