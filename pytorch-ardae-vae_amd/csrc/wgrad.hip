@@ -262,6 +262,11 @@ int wgrad_splits(int M, int O, int I, int nproblems_hint) {
   const int tiles = ceil_div(O, BO) * ceil_div(I, BI);
   const int target = 1024;   // ~2 resident workgroups per CU x 256 CUs x 2 waves of work
   int s = target / (tiles * (nproblems_hint > 0 ? nproblems_hint : 1));
+  // N-row problems whose shape keeps them off the software-pipelined kernels (I = z_dim = 2 of the toy model, ragged conv
+  // shapes) share THIS launch only with a few per-image problems - the regular ones of the batch run in wgrad_wide.hip - so the
+  // hint over-divides: 102 workgroups streamed 268 MB in 279 us at config #1.  Give such a problem the chip.
+  const bool wide_shape = O % 256 == 0 && (I % 256 == 0 || (I % 32 == 0 && I <= 64)) && M % RC == 0;
+  if (!wide_shape && M >= 16384 && s < 512 / tiles) s = 512 / tiles;
   const int max_s = ceil_div(M, 2 * RC);   // at least 2 chunks of rows per split (per-image problems are latency: more, shorter workgroups)
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
