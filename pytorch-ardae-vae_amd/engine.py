@@ -87,7 +87,7 @@ class ArdaeEngine:
         self.state = torch.zeros(4, dtype=torch.int64, device=self.dev)
         self.use_graph = bool(graph) and os.environ.get("ARDAE_GRAPH", "1") != "0" and \
             (self.world == 1 or os.environ.get("ARDAE_GRAPH_DP") == "1")
-        self._graph, self._graph_key, self._xc, self._xv = None, None, None, None
+        self._graph, self._graph_key, self._xc, self._xv = None, None, None, None      # _xc: list of static batch buffers
         self._in_step, self._draws, self._warmed = False, 0, False
         # The first half of the VAE update (sampler + decoder + ELBO pieces on the VAE batch, ~25 per-image launches) needs
         # nothing from the cDAE update: step() runs it on a side stream next to the cDAE phase's N-row kernels.
@@ -239,6 +239,9 @@ class ArdaeEngine:
             L.check(self.lib.ardae_step_state_advance(ctypes.c_void_p(self.state.data_ptr()), ctypes.c_uint64(self.RNG_STRIDE), cfg.m_lr, cfg.m_beta1, 0.999,
                                                       L.stream_ptr()), "ardae_step_state_advance")
             vae_draw = self.RNG_STRIDE - 1            # the VAE sampler's noise keeps its own offset whatever the launch order
+            # injected noise: one dict for everything, or a list with one dict per cDAE update (the last one also holds "vae")
+            nlist = list(noise) if isinstance(noise, (list, tuple)) else [noise] * len(xs)
+            noise = None if noise is None else nlist[0]
             if self.overlap:
                 main = torch.cuda.current_stream()
                 self._side.wait_stream(main)
@@ -252,15 +255,15 @@ class ArdaeEngine:
                         drawn.record(self._side)
                 # eager launches reach the GPU in host order: the cDAE phase (the critical path) is enqueued before the
                 # side stream's ~30 small launches, which have the whole phase to finish in
-                for xc in xs:
-                    self.cdae_phase(xc, noise, drawn=drawn)
+                for i, xc in enumerate(xs):
+                    self.cdae_phase(xc, nlist[i], drawn=drawn)
                 with torch.cuda.stream(self._side):
-                    nv = self.vae_forward_part(x_vae, noise, beta, draw=vae_draw)
+                    nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
                 main.wait_stream(self._side)
             else:
-                for xc in xs:
-                    self.cdae_phase(xc, noise)
-                nv = self.vae_forward_part(x_vae, noise, beta, draw=vae_draw)
+                for i, xc in enumerate(xs):
+                    self.cdae_phase(xc, nlist[i])
+                nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
             self.vae_backward_part(x_vae, nv, beta)
         finally:
             self._in_step = False
@@ -269,38 +272,42 @@ class ArdaeEngine:
         """One iteration of the reference loop: num_cdae_updates cDAE updates (each on its own batch in the reference; the
         caller passes a list of batches when num_cdae_updates > 1) followed by one VAE update."""
         many = isinstance(x_cdae, (list, tuple))
-        if self.use_graph and noise is None and not many and self.cfg.num_cdae_updates == 1:
+        xs = list(x_cdae) if many else [x_cdae] * self.cfg.num_cdae_updates
+        if 3 * len(xs) >= self.RNG_STRIDE:
+            raise ValueError("at most %d cDAE updates per step (Philox offsets reserved per step)" % ((self.RNG_STRIDE - 1) // 3))
+        if self.use_graph and noise is None:
             b = float(self.cfg.beta if beta is None else beta)
-            if self._xc is None:
-                self._xc, self._xv = torch.empty_like(x_cdae), torch.empty_like(x_vae)
-            if x_cdae is not self._xc:
-                self._xc.copy_(x_cdae)
+            # static copies of the batches (one per DISTINCT batch object: --num-cdae-updates k on one tensor shares its copy)
+            if self._xc is None or len(self._xc) != len(xs):
+                self._xc, self._xv, self._graph = [torch.empty_like(x) for x in xs], torch.empty_like(x_vae), None
+            for buf, x in zip(self._xc, xs):
+                if x is not buf:
+                    buf.copy_(x)
             if x_vae is not self._xv:
                 self._xv.copy_(x_vae)
-            key = (b, tuple(self._xc.shape), tuple(self._xv.shape))
+            key = (b, tuple(tuple(x.shape) for x in self._xc), tuple(self._xv.shape))
             if self._graph is not None and self._graph_key == key:
                 self._graph.replay()
             elif not self._warmed:
                 # first iteration of this engine eagerly: every kernel gets loaded outside of a capture
-                self._step_body([self._xc], self._xv, None, b)
+                self._step_body(self._xc, self._xv, None, b)
                 self._warmed = True
             else:
                 g = torch.cuda.CUDAGraph()
                 try:
                     with torch.cuda.graph(g):
-                        self._step_body([self._xc], self._xv, None, b)
+                        self._step_body(self._xc, self._xv, None, b)
                 except Exception as exc:   # capture refused (e.g. a collective): eager from now on
                     self.use_graph = False
                     self._graph = None
                     import warnings
                     warnings.warn(f"ArdaeEngine: HIP graph capture failed ({exc}); continuing with eager launches")
-                    self._step_body([self._xc], self._xv, None, b)
+                    self._step_body(self._xc, self._xv, None, b)
                 else:
                     self._graph, self._graph_key = g, key
                     g.replay()
             self.step_count += 1
             return
-        xs = x_cdae if many else [x_cdae] * self.cfg.num_cdae_updates
         self._step_body(xs, x_vae, noise, beta)
         self.step_count += 1
 

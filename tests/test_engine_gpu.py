@@ -420,3 +420,69 @@ def test_latent_perturb_kernels(B, nz, z):
     assert rel_l2(std_b, std.reshape(-1)) < 1e-5
     assert rel_l2(sigma, sigma_ref) < 1e-5
     assert rel_l2(xbar, xbar_ref) < 1e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_engine_two_cdae_updates_per_step(graph):
+    """--num-cdae-updates 2 (the shipped mnist-conv / auxresconvct recipes, run_vae_dbmnist.sh): two cDAE updates on their own
+    batches, then the VAE update against the twice-updated cDAE (ivae_ardae.py:713-846), against the oracle run the same way.
+    graph=False injects the oracle's draws (tight comparison); graph=True checks that the captured two-update step replays
+    with fresh batches and noise (own Philox stream, so only finiteness / movement / bit-identity of two engines is checked)."""
+    mc = O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus")
+    cc = O.CdaeCfg("grad", 8, 8, 64, 3)
+    tc = O.TrainCfg(nz_cdae=8)
+    B = 4
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc))
+    pc = O.init_params(O.cdae_param_spec(cc), 1)
+    gen = torch.Generator().manual_seed(21)
+    xs = [torch.bernoulli(torch.full((B, 24), 0.3), generator=gen) for _ in range(3)]
+    noises = [O.draw_step_noise(mc, tc, B, gen) for _ in range(2)]
+
+    def make():
+        model, cdae = build(mc, cc)
+        model.load_state_dict(pm); cdae.load_state_dict(pc)
+        model, cdae = model.to("cuda"), cdae.to("cuda")
+        return model, cdae, net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=8, num_cdae_updates=2), batch_size=B, graph=graph)
+
+    if not graph:
+        model, cdae, eng = make()
+        dn = [{k: v.cuda().contiguous() for k, v in n.items()} for n in noises]
+        eng.step([xs[0].cuda(), xs[1].cuda()], xs[2].cuda(), noise=dn)
+        got = eng.stats()
+        rpm, rpc = {k: v.clone() for k, v in pm.items()}, {k: v.clone() for k, v in pc.items()}
+        st_m, st_c = {}, {}
+        for i in range(2):
+            closs, gc, _ = O.cdae_update_grads(mc, cc, tc, rpm, rpc, xs[i], noises[i])
+            with torch.no_grad():
+                O.rmsprop_step(rpc, gc, st_c, tc.d_lr, tc.d_momentum)
+        mloss, rec, pri, _, gm = O.vae_update_grads(mc, cc, tc, rpm, rpc, xs[2], noises[1])
+        with torch.no_grad():
+            O.adam_ref_step(rpm, gm, st_m, tc.m_lr, tc.m_beta1)
+        assert rel(got["cdae_loss"], closs) < 1e-4 and rel(got["model_loss"], mloss) < 1e-4
+        assert rel(got["recon"], rec) < 2e-5 and rel(got["prior"], pri) < 2e-5
+        flat = lambda p, spec: torch.cat([p[n].reshape(-1) for n, _ in spec])
+
+        def updates_agree(after, before, ref_after, what):
+            # sign-like first optimiser steps (|update| ~ lr whatever |grad| is): elements whose gradient sits at the fp32 noise
+            # floor may flip, and the second cDAE update / the VAE update inherit the first one's flips - so: the typical element
+            # agrees tightly and only a small fraction disagrees at all (cf. assert_update_close, whose L2 bound is for one update)
+            upd, ref = (after - before).double(), (ref_after - before).double()
+            err = (upd - ref).abs() / (ref.abs() + 1e-12)
+            assert float(err.median()) < 1e-3, what
+            assert float((err > 1e-2).double().mean()) < 2e-2, what
+        updates_agree(cdae.flat_params().cpu()[:-1], flat(pc, O.cdae_param_spec(cc))[:-1], flat(rpc, O.cdae_param_spec(cc))[:-1], "cdae after two updates")
+        updates_agree(model.flat_params().cpu(), flat(pm, O.model_param_spec(mc)), flat(rpm, O.model_param_spec(mc)), "model")
+        return
+    outs = []
+    for _ in range(2):
+        net.manual_seed(5)
+        model, cdae, eng = make()
+        for t in range(4):                       # eager warm step, capture, two replays - with changing batches
+            eng.step([xs[t % 3].cuda(), xs[(t + 1) % 3].cuda()], xs[(t + 2) % 3].cuda())
+        torch.cuda.synchronize()
+        assert eng._graph is not None and len(eng._xc) == 2
+        st = eng.stats()
+        assert all(v == v for v in st.values())
+        outs.append((model.flat_params().clone(), cdae.flat_params().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][1].cpu(), torch.cat([pc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)]))
