@@ -259,6 +259,14 @@ int wgrad_splits(int M, int O, int I, int nproblems_hint) {
   // first-layer shapes (I = z_dim): the 256 x 32 geometry of wgrad_wide.hip streams G once, one workgroup per CU, and is
   // latency-bound per workgroup - give it the whole chip
   if (O % 256 == 0 && I % 32 == 0 && I <= 64 && M % RC == 0 && M >= 64 * RC) return 256 / ((O / 256) * (I / 32));
+  // 256 x 256 tiles of the same kernel: a problem with many tiles (h_dim 512 / 1024: 4 / 16) must still be allowed the
+  // splits that fill 256 CUs when it shares a launch with few others (the launch lowers the count to 256 / tiles in it)
+  if (O % 256 == 0 && I % 256 == 0 && M % RC == 0 && M >= 64 * RC && (O / 256) * (I / 256) > 1) {
+    const int t = (O / 256) * (I / 256);
+    const int s_sq = t >= 32 ? 8 : 256 / (2 * t);          // at least two such problems per launch
+    const int hinted = 1024 / (ceil_div(O, BO) * ceil_div(I, BI) * (nproblems_hint > 0 ? nproblems_hint : 1));
+    return s_sq > hinted ? s_sq : (hinted < 1 ? 1 : hinted);
+  }
   const int tiles = ceil_div(O, BO) * ceil_div(I, BI);
   const int target = 1024;   // ~2 resident workgroups per CU x 256 CUs x 2 waves of work
   int s = target / (tiles * (nproblems_hint > 0 ? nproblems_hint : 1));
@@ -280,7 +288,7 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
   // the big regular problems go to the software-pipelined kernel (which may lower their split count), the rest to
   // wgrad_kernel; one reduction for all
   WgradProblem local[WGRAD_MAX_PROBLEMS];
-  int wide_idx[WGRAD_MAX_PROBLEMS], nwide = 0, wide_tiles[3] = {0, 0, 0};
+  int wide_idx[WGRAD_MAX_PROBLEMS], nwide = 0, wide_geo[WGRAD_MAX_PROBLEMS] = {0}, wide_ntiles[WGRAD_MAX_PROBLEMS] = {0};
   size_t max_elems = 0;
   for (int i = 0; i < nprob; ++i) {
     const WgradProblem& p = probs[i];
@@ -296,14 +304,29 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
     if (el > max_elems) max_elems = el;
     const int geo = wgrad_wide_geometry(p);
     const int tiles = geo == 1 ? (p.O / 256) * (p.I / 256) : geo == 2 ? (p.O / 256) * (p.I / 32) : 0;
-    if (geo != 0 && wide_tiles[geo] + tiles <= 32) {
+    if (geo != 0 && tiles <= 32) {
       wide_idx[nwide++] = i;
-      wide_tiles[geo] += tiles;
+      wide_geo[i] = geo;
+      wide_ntiles[i] = tiles;
     }
   }
-  if (nwide > 0) {
-    const int rc = launch_wgrad_wide(local, wide_idx, nwide, st);
-    if (rc < 0) return rc;
+  // one software-pipelined launch holds up to 32 tiles of a geometry (its argument block): h_dim 1024 has 16 tiles per
+  // matrix, so its eleven N-row problems go out as six launches of two - each launch fills the chip through its row splits
+  for (int geo = 1; geo <= 2; ++geo) {
+    int group[WGRAD_MAX_PROBLEMS], ng = 0, gt = 0;
+    for (int w = 0; w <= nwide; ++w) {
+      const bool end = w == nwide;
+      const int i = end ? -1 : wide_idx[w];
+      if (!end && wide_geo[i] != geo) continue;
+      if (end || gt + wide_ntiles[i] > 32) {
+        if (ng > 0) {
+          const int rc = launch_wgrad_wide(local, group, ng, st);
+          if (rc < 0) return rc;
+        }
+        ng = 0; gt = 0;
+      }
+      if (!end) { group[ng++] = i; gt += wide_ntiles[i]; }
+    }
   }
   WgradBatchDev b;   // the remaining problems for wgrad_kernel
   memset(&b, 0, sizeof(b));

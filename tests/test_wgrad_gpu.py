@@ -72,3 +72,12 @@ def test_wgrad_wide_uneven_splits():
 def test_wgrad_full_size():
     # BASELINE config #2: 131072 rows (reference in float64 on the GPU)
     run_batch([(131072, 256, 256, 2, True, True), (131072, 256, 32, 2, True, False)], seed=4)
+
+
+def test_wgrad_many_tiles_several_launches():
+    # h_dim 1024 (BASELINE config #5): 16 tiles of 256 x 256 per matrix, 32 per software-pipelined launch - three such
+    # problems go out as two launches, each with the row splits that fill the chip (one of them with bias + sigma column);
+    # plus h_dim 512 shapes (4 tiles) and a toy-model first layer (I = 2: the ragged N-row problem on the generic kernel)
+    run_batch([(4096, 1024, 1024, 2, True, True), (4096, 1024, 1024, 1, True, False), (4096, 1024, 1024, 2, False, False),
+               (4096, 512, 512, 2, True, False), (4096, 1024, 32, 2, True, False)], seed=5)
+    run_batch([(32768, 256, 2, 2, True, False), (32768, 512, 512, 1, True, False)], seed=6)
