@@ -28,6 +28,11 @@ def cfg(i):
         c = net.MLPResCARDAE(input_dim=32, context_dim=32, std=1., h_dim=1024, num_hidden_layers=6, nonlinearity="softplus",
                              noise_type="gaussian", enc_ctx=True, enc_input=True)
         return m, c, 256, 1024, lambda B, dev: (torch.rand(B, 3072, device=dev) < 0.5).float(), dict(z=32, h=1024, L=6, kind="res")
+    if i == 6:   # the shipped dbMNIST recipe for the mlp model (run_vae_dbmnist.sh: mnist-concat, batch 128, nz_cdae 625, cdae L 5)
+        m = net.MNISTIPVAE(input_dim=784, noise_dim=100, h_dim=256, num_hidden_layers=2, nonlinearity="softplus", enc_type="concat", z_dim=32)
+        c = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=256, num_hidden_layers=5, nonlinearity="softplus",
+                              noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 128, 625, lambda B, dev: (torch.rand(B, 784, device=dev) < 0.13).float(), dict(z=32, h=256, L=5, kind="grad")
     raise SystemExit(f"no config {i}")
 
 def cdae_flops(B, nz, z, h, L, kind):
