@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void latent_perturb_kernel(const float* __rest
   }
 }
 
-// Register-resident variant for nz * zd == 256 * NV with zd a power of two: thread t owns elements t + 256 j (all of the same
+// Register-resident variant for nz * zd <= 256 * NV with zd a power of two: thread t owns elements t + 256 j (all of the same
 // latent dimension d = t % zd, samples r = t / zd + (256 / zd) j - the same assignment and summation order as the kernel
 // above, so the results are bit-identical), loaded ONCE with all NV loads in flight instead of three dependent passes.
 template <int NV>
@@ -170,16 +170,17 @@ __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __
   const size_t base = (size_t)b * nz * zd;
   const float* lat = latent + base;
   const float z0d = z0[(size_t)b * zd + d];
+  const int per_image = nz * zd;                 // elements beyond it (last pass of a ragged image) are masked out
   float u[NV], ev[NV];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) u[j] = lat[t + 256 * j];
+  for (int j = 0; j < NV; ++j) u[j] = (t + 256 * j < per_image) ? lat[t + 256 * j] : z0d;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) ev[j] = eps[base + t + 256 * j];
+  for (int j = 0; j < NV; ++j) ev[j] = (t + 256 * j < per_image) ? eps[base + t + 256 * j] : 0.f;
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     u[j] = std_scale * (u[j] - z0d);
-    s += u[j];
+    if (t + 256 * j < per_image) s += u[j];
   }
   red[t] = s;
   __syncthreads();
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const float c = u[j] - mean;
-    ss += c * c;
+    if (t + 256 * j < per_image) ss += c * c;
   }
   red[t] = ss;
   __syncthreads();
@@ -216,10 +217,12 @@ __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __
   const int r0 = t / zd;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const size_t row = (size_t)b * nz + r0 + RG * j;
-    const float sg = sb * xi[row];
-    xbar[base + t + 256 * j] = u[j] + sg * ev[j];
-    if (d == 0) sigma[row] = sg;
+    if (t + 256 * j < per_image) {
+      const size_t row = (size_t)b * nz + r0 + RG * j;
+      const float sg = sb * xi[row];
+      xbar[base + t + 256 * j] = u[j] + sg * ev[j];
+      if (d == 0) sigma[row] = sg;
+    }
   }
 }
 
@@ -419,14 +422,15 @@ int launch_latent_perturb(const float* latent, const float* z0, const float* xi,
   int zp = 1;
   while (zp < zd) zp <<= 1;
   const int64_t per_image = (int64_t)nz * zd;
-  const bool reg_ok = zp == zd && per_image % 256 == 0;
+  const bool reg_ok = zp == zd && zd <= 256 && per_image >= 256 * 4;
 #define ARDAE_LP_REG(NV_)                                                                                                          \
   hipLaunchKernelGGL(latent_perturb_reg_kernel<NV_>, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, std_scale, delta, xbar, \
                      sigma, std_b)
-  if (reg_ok && per_image == 256 * 8) ARDAE_LP_REG(8);
-  else if (reg_ok && per_image == 256 * 16) ARDAE_LP_REG(16);
-  else if (reg_ok && per_image == 256 * 32) ARDAE_LP_REG(32);
-  else if (reg_ok && per_image == 256 * 64) ARDAE_LP_REG(64);
+  if (reg_ok && per_image <= 256 * 8) ARDAE_LP_REG(8);
+  else if (reg_ok && per_image <= 256 * 16) ARDAE_LP_REG(16);
+  else if (reg_ok && per_image <= 256 * 32) ARDAE_LP_REG(32);
+  else if (reg_ok && per_image <= 256 * 64) ARDAE_LP_REG(64);
+  else if (reg_ok && per_image <= 256 * 96) ARDAE_LP_REG(96);       // nz_cdae 625 of the shipped recipes: 79 values per thread
   else
     hipLaunchKernelGGL(latent_perturb_kernel, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, zp, std_scale, delta, xbar,
                        sigma, std_b);
