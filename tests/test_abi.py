@@ -97,3 +97,41 @@ def test_state_dict_roundtrip_keeps_flat_views():
         off += p.numel()
     m2 = m.double().float()                                               # _apply keeps the views linked
     assert all(p.data_ptr() >= m2.flat_params().data_ptr() for p in m2.parameters())
+
+
+def test_argument_validation_of_the_step_entry_points():
+    """Error behaviour of the entry points a caller can misuse (all checks run before any HIP call, so no GPU is needed):
+    negative status + a message on the error channel; nothing is launched, nothing is written."""
+    lib = L.lib()
+    md = L.ModelDesc(0, 24, 10, 64, 8, 2, 2)
+    conv = L.ModelDesc(2, 784, 100, 800, 32, 1, 2)
+    cd = L.CdaeDesc(0, 8, 8, 64, 3, 2)
+    one = ctypes.c_void_p(64)                     # any non-null address: validation must fail before it is dereferenced
+    big = ctypes.c_size_t(1 << 40)
+
+    def fails(rc, fragment):
+        assert rc < 0
+        assert fragment.encode() in lib.ardae_last_error(), lib.ardae_last_error()
+
+    # empty / oversized batches
+    fails(lib.ardae_cdae_loss_grads(ctypes.byref(cd), one, one, one, one, one, one, 0, 8, one, big, one, one, None, None), "bad batch")
+    fails(lib.ardae_cdae_loss_grads(ctypes.byref(cd), one, one, one, one, one, one, 1 << 20, 1 << 12, one, big, one, one, None, None), "bad batch")
+    # workspace smaller than ardae_*_workspace_floats asks for
+    fails(lib.ardae_cdae_loss_grads(ctypes.byref(cd), one, one, one, one, one, one, 4, 8, one, ctypes.c_size_t(16), one, one, None, None),
+          "workspace too small")
+    fails(lib.ardae_model_encode_pair(ctypes.byref(md), one, one, one, one, 4, 8, one, ctypes.c_size_t(16), one, one, 0, None), "workspace too small")
+    # encode_pair: phase out of range, missing noise for the phases that need it
+    fails(lib.ardae_model_encode_pair(ctypes.byref(md), one, one, one, one, 4, 8, one, big, one, one, 7, None), "phase")
+    fails(lib.ardae_model_encode_pair(ctypes.byref(md), one, one, one, None, 4, 8, one, big, one, one, 2, None), "null pointer")
+    # the split backward exists for the MLP models only
+    fails(lib.ardae_model_vae_backward_decoder(ctypes.byref(conv), one, one, one, one, 4, 1, 1.0, 1.0, one, big, None), "conv model")
+    fails(lib.ardae_model_vae_backward_sampler(ctypes.byref(conv), one, one, one, one, 4, 1, one, 1.0, one, big, one, 0.0, None), "conv model")
+    # unknown network kinds / activations a score network cannot use (mlp-grad needs a twice differentiable activation)
+    bad = L.CdaeDesc(0, 8, 8, 64, 3, 1)
+    assert lib.ardae_cdae_workspace_floats(ctypes.byref(bad), 4, 8, 1) == 0
+    fails(lib.ardae_cdae_pack(ctypes.byref(bad), one, one, None), "twice differentiable")
+    assert lib.ardae_cdae_param_floats(ctypes.byref(L.CdaeDesc(5, 8, 8, 64, 3, 2))) == 0
+    # weight-gradient batches: problem count and shapes
+    probs = (L.WgradProblem * 1)()
+    fails(lib.ardae_wgrad_batch(probs, 0, None), "problems per batch")
+    fails(lib.ardae_wgrad_batch(probs, 1, None), "empty problem")
