@@ -107,7 +107,7 @@ def main():
     cdae = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=256, num_hidden_layers=3, nonlinearity="softplus",
                              noise_type="gaussian", enc_ctx=True, enc_input=True).to(dev)
     eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=B)
-    net.manual_seed(42 + rank)                            # different noise / images per rank (different shards)
+    net.manual_seed(42)                                   # one noise stream: every rank draws its rows of the global draw (engine._normal)
     g = torch.Generator(device="cpu").manual_seed(1234)
     pimg = ((torch.rand(784, generator=g) < 0.2).float() * 0.6 + 0.03).to(dev)
     xc, xv = torch.empty(B, 784, device=dev), torch.empty(B, 784, device=dev)

@@ -125,6 +125,11 @@ int ardae_adam_ref_step(float* p, const float* g, float* exp_avg, float* exp_avg
 #define ARDAE_STEP_STATE_BYTES 32
 int ardae_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, void* stream);
 int ardae_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, void* stream);
+/* Elements [first_element, first_element + n) of the draw identified by (seed, offset + state.rng_offset): a rank that holds
+ * rows [r0, r1) of a [rows, cols] draw passes first_element = r0 * cols (a multiple of 4) and gets exactly the numbers a single
+ * process would have put there, so a data-parallel run does not depend on the number of ranks.  state may be NULL. */
+int ardae_philox_normal_at(float* out, int64_t n, uint64_t seed, uint64_t offset, const void* state, uint64_t first_element,
+                           void* stream);
 int ardae_adam_ref_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
                             double beta1, double beta2, double eps, const void* state, void* stream);
 /* torch.optim.RMSprop(lr, momentum) as built at ivae_ardae.py:625-626 (alpha .99, eps 1e-8, not centred) */

@@ -93,6 +93,8 @@ EXPORTS = {
                                        ctypes.c_uint64, ctypes.c_void_p]),
     "ardae_step_state_advance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
     "ardae_philox_normal_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "ardae_philox_normal_at": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                               ctypes.c_void_p]),
     "ardae_adam_ref_step_dev": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 3 + [ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_adam_ref_step": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_int, ctypes.c_void_p]),
     "ardae_rmsprop_step": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_void_p]),

@@ -68,6 +68,9 @@ int ardae_step_state_advance(void* state, uint64_t rng_inc, double lr, double be
 int ardae_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, void* stream) {
   return launch_philox_normal_dev(out, n, seed, state, offset_add, (hipStream_t)stream);
 }
+int ardae_philox_normal_at(float* out, int64_t n, uint64_t seed, uint64_t offset, const void* state, uint64_t first_element, void* stream) {
+  return launch_philox_normal_at(out, n, seed, offset, state, first_element, (hipStream_t)stream);
+}
 int ardae_adam_ref_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
                             double beta1, double beta2, double eps, const void* state, void* stream) {
   return launch_adam_ref_dev(p, g, exp_avg, exp_avg_sq, max_exp_avg_sq, n, beta1, beta2, eps, state, (hipStream_t)stream);

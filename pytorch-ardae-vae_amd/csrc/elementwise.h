@@ -24,6 +24,8 @@ int launch_gather_strided(const float* src, int stride, int n, float* dst, hipSt
 int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st);
 // device-resident step state (graph-replayable step): see ardae_step_state_advance in ardae_hip.h
 int launch_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, hipStream_t st);
+// elements [first_element, first_element + n) of the draw (seed, offset [+ state]); state may be null
+int launch_philox_normal_at(float* out, int64_t n, uint64_t seed, uint64_t offset, const void* state, uint64_t first_element, hipStream_t st);
 int launch_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, hipStream_t st);
 int launch_adam_ref_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double beta1, double beta2, double eps,
                         const void* state, hipStream_t st);

@@ -50,12 +50,14 @@ __global__ void step_state_advance_kernel(StepState* s, uint64_t rng_inc, double
   s->adam_sqrt_bc2 = (float)sqrt(bc2);
 }
 
-__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, const StepState* state) {
+// q0: first counter of this launch - a rank that owns rows [r0, r1) of a draw generates elements [first, first + n) of the
+// GLOBAL draw (first = 4 q0), so the numbers do not depend on how the rows are partitioned over ranks
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, const StepState* state, uint64_t q0) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one counter = 4 normals
   if (q * 4 >= n) return;
   if (state) offset += state->rng_offset;
   uint32_t r[4];
-  philox4(seed, offset, (uint64_t)q, r);
+  philox4(seed, offset, q0 + (uint64_t)q, r);
   float v[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -481,19 +483,25 @@ int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, 
   ARDAE_CHECK_ARG(out && n > 0, "philox_normal: bad arguments");
   const int64_t q = (n + 3) / 4;
   hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset,
-                     (const StepState*)nullptr);
+                     (const StepState*)nullptr, (uint64_t)0);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_philox_normal_at(float* out, int64_t n, uint64_t seed, uint64_t offset, const void* state, uint64_t first_element, hipStream_t st) {
+  ARDAE_TRY(flush_active_chain());
+  ARDAE_CHECK_ARG(out && n > 0, "philox_normal_at: bad arguments");
+  ARDAE_CHECK_ARG((first_element & 3) == 0, "philox_normal_at: first_element must be a multiple of 4 (one Philox counter = 4 normals)");
+  const int64_t q = (n + 3) / 4;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset,
+                     (const StepState*)state, first_element >> 2);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* state, uint64_t offset_add, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
-  ARDAE_CHECK_ARG(out && n > 0 && state, "philox_normal_dev: bad arguments");
-  const int64_t q = (n + 3) / 4;
-  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset_add,
-                     (const StepState*)state);
-  ARDAE_LAUNCH_CHECK();
-  return 0;
+  ARDAE_CHECK_ARG(state, "philox_normal_dev: bad arguments");
+  return launch_philox_normal_at(out, n, seed, offset_add, state, 0, st);
 }
 
 int launch_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, hipStream_t st) {

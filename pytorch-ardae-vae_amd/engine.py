@@ -57,6 +57,7 @@ class ArdaeEngine:
         self.lib = L.lib()
         self.pg = process_group
         self.world = dist.world_size(process_group)
+        self.rank = dist.rank(process_group)
         md, cd = model._desc, cdae._desc
         B, nzc, nzm = self.B, cfg.nz_cdae, cfg.nz_model
         N = B * nzc
@@ -122,8 +123,9 @@ class ArdaeEngine:
         """One standard-normal draw.  Inside `step()` the offset comes from the device step state (graph-replayable);
         phase calls made directly use the host-side stream of `rng`.  `draw`: fixed index of the draw inside the step
         (so that the numbers do not depend on the order in which concurrent parts of the step are launched)."""
+        first = self.rank * out.numel()        # equal shards: this rank's rows of the global draw (independent of the rank count)
         if not self._in_step:
-            return rng.normal(None, self.dev, out=out)
+            return rng.normal(None, self.dev, out=out, first_element=first)
         if draw is None:
             k = self._draws
             self._draws += 1
@@ -131,8 +133,8 @@ class ArdaeEngine:
             k = draw
         if k >= self.RNG_STRIDE:
             raise RuntimeError("more Philox draws in one step than RNG_STRIDE reserves")
-        L.check(self.lib.ardae_philox_normal_dev(L.ptr(out), out.numel(), ctypes.c_uint64(rng.get_state()["seed"]), ctypes.c_void_p(self.state.data_ptr()),
-                                                 ctypes.c_uint64(k), L.stream_ptr()), "ardae_philox_normal_dev")
+        L.check(self.lib.ardae_philox_normal_at(L.ptr(out), out.numel(), ctypes.c_uint64(rng.get_state()["seed"]), ctypes.c_uint64(k),
+                                                ctypes.c_void_p(self.state.data_ptr()), ctypes.c_uint64(first), L.stream_ptr()), "ardae_philox_normal_at")
         return out
 
     # ------------------------------------------------------------------------------------------------------------

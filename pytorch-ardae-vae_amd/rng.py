@@ -28,10 +28,12 @@ def _next_offset():
     return o
 
 
-def normal(shape, device, out=None):
+def normal(shape, device, out=None, first_element=0):
+    """first_element: this tensor is the slice [first_element, first_element + numel) of a larger draw (data parallelism:
+    rank r of R equal shards passes r * numel and gets the numbers a single process would have generated there)."""
     t = out if out is not None else torch.empty(shape, device=device, dtype=torch.float32)
-    L.check(L.lib().ardae_philox_normal(L.ptr(t), t.numel(), ctypes.c_uint64(_state["seed"]), ctypes.c_uint64(_next_offset()),
-                                        L.stream_ptr()), "ardae_philox_normal")
+    L.check(L.lib().ardae_philox_normal_at(L.ptr(t), t.numel(), ctypes.c_uint64(_state["seed"]), ctypes.c_uint64(_next_offset()), None,
+                                           ctypes.c_uint64(first_element), L.stream_ptr()), "ardae_philox_normal_at")
     return t
 
 

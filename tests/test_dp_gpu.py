@@ -44,12 +44,15 @@ def _inputs():
 
 
 def _grads(x1, x2, noise, per_rank_batch):
-    """cDAE-phase and VAE-phase gradients (all-reduced inside the engine when a process group is up), no parameter update."""
+    """cDAE-phase and VAE-phase gradients (all-reduced inside the engine when a process group is up), no parameter update.
+    noise=None: the engine's own Philox stream - every rank generates ITS ROWS of the global draws, so the result must not
+    depend on the number of ranks either."""
     import ardae_amd as net
     dev = torch.device("cuda", 0)
     model, cdae = _build(dev)
+    net.manual_seed(99)
     eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=per_rank_batch)
-    nz = {k: v.to(dev).contiguous() for k, v in noise.items()}
+    nz = None if noise is None else {k: v.to(dev).contiguous() for k, v in noise.items()}
     eng.cdae_phase(x1.to(dev), nz, apply_update=False)
     eng.vae_phase(x2.to(dev), nz, apply_update=False)
     torch.cuda.synchronize()
@@ -68,8 +71,11 @@ def _worker(rank, world, port, out):
     gc, gm, loss = _grads(x1[lo:hi], x2[lo:hi], n_loc, hi - lo)
     lt = loss.clone()
     torch.distributed.all_reduce(lt)
+    gc2, gm2, loss2 = _grads(x1[lo:hi], x2[lo:hi], None, hi - lo)        # own noise stream
+    lt2 = loss2.clone()
+    torch.distributed.all_reduce(lt2)
     if rank == 0:
-        torch.save({"gc": gc, "gm": gm, "loss": lt / world}, out)
+        torch.save({"gc": gc, "gm": gm, "loss": lt / world, "gc_own": gc2, "gm_own": gm2, "loss_own": lt2 / world}, out)
     torch.distributed.destroy_process_group()
 
 
@@ -90,6 +96,11 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
     # same arithmetic on the same rows; only the order of the fp32 sums over rows differs (split in two, then averaged)
     assert rel(got["gc"], gc) < 5e-4
     assert rel(got["gm"], gm) < 5e-4
+    # the engine's own draws: rank r generated rows [r B/2, (r+1) B/2) of the same global noise tensors
+    gc, gm, loss = _grads(x1, x2, None, B)
+    assert abs(float(got["loss_own"]) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert rel(got["gc_own"], gc) < 5e-4
+    assert rel(got["gm_own"], gm) < 5e-4
 
 
 def test_bench_two_ranks_rehearsal(tmp_path):
