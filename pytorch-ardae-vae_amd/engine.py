@@ -90,6 +90,7 @@ class ArdaeEngine:
             (self.world == 1 or os.environ.get("ARDAE_GRAPH_DP") == "1")
         self._graph, self._graph_key, self._xc, self._xv = None, None, None, None      # _xc: list of static batch buffers
         self._in_step, self._draws, self._warmed = False, 0, False
+        self._last_beta, self._beta_stable = None, 0
         # The first half of the VAE update (sampler + decoder + ELBO pieces on the VAE batch, ~25 per-image launches) needs
         # nothing from the cDAE update: step() runs it on a side stream next to the cDAE phase's N-row kernels.
         self.overlap = os.environ.get("ARDAE_OVERLAP", "1") != "0"
@@ -288,8 +289,14 @@ class ArdaeEngine:
             if x_vae is not self._xv:
                 self._xv.copy_(x_vae)
             key = (b, tuple(tuple(x.shape) for x in self._xc), tuple(self._xv.shape))
+            # beta annealing (utils/msc.py:53-55) changes a frozen kernel argument every step: capture only once beta has stood
+            # still for two steps, run eagerly while it moves (a capture per step would cost far more than replay saves)
+            self._beta_stable = self._beta_stable + 1 if b == self._last_beta else 0
+            self._last_beta = b
             if self._graph is not None and self._graph_key == key:
                 self._graph.replay()
+            elif self._warmed and self._beta_stable < 2:
+                self._step_body(self._xc, self._xv, None, b)
             elif not self._warmed:
                 # first iteration of this engine eagerly: every kernel gets loaded outside of a capture
                 self._step_body(self._xc, self._xv, None, b)

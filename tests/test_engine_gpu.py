@@ -486,3 +486,34 @@ def test_engine_two_cdae_updates_per_step(graph):
         outs.append((model.flat_params().clone(), cdae.flat_params().clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert not torch.equal(outs[0][1].cpu(), torch.cat([pc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)]))
+
+
+def test_engine_beta_annealing_under_graph_mode():
+    """--beta-annealing (utils/msc.py:53-55, ivae_ardae.py:800): beta is a kernel argument frozen in a captured graph, so the
+    engine launches eagerly while beta moves and captures once it has settled - with the same parameters, bit for bit, as an
+    engine that never uses graphs."""
+    mc = O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus")
+    cc = O.CdaeCfg("grad", 8, 8, 64, 3)
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc))
+    pc = O.init_params(O.cdae_param_spec(cc), 1)
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.bernoulli(torch.full((4, 24), 0.3), generator=gen).cuda() for _ in range(8)]
+    betas = [net.annealing_func(0.1, 1.0, 3, t) for t in range(8)]          # 0.1, 0.4, 0.7, 1.0, 1.0, ...
+    assert betas[0] == pytest.approx(0.1) and betas[3] == betas[7] == pytest.approx(1.0)
+    outs = []
+    for graph in (True, False):
+        net.manual_seed(17)
+        model, cdae = build(mc, cc)
+        model.load_state_dict(pm); cdae.load_state_dict(pc)
+        model, cdae = model.to("cuda"), cdae.to("cuda")
+        eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=8), batch_size=4, graph=graph)
+        captured_at = None
+        for t in range(8):
+            eng.step(xs[t], xs[(t + 3) % 8], beta=betas[t])
+            if captured_at is None and eng._graph is not None:
+                captured_at = t
+        torch.cuda.synchronize()
+        if graph:
+            assert captured_at is not None and captured_at >= 5 and betas[captured_at] == betas[7]     # never while beta was moving
+        outs.append((model.flat_params().clone(), cdae.flat_params().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
