@@ -80,6 +80,7 @@ class TrainCfg:
     m_beta1: float = 0.5
     d_lr: float = 1e-4
     d_momentum: float = 0.5
+    ctx_type: str = "lt0"        # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens)
 
 
 # --------------------------------------------------------------------------- #
@@ -124,6 +125,19 @@ def model_param_spec(c: ModelCfg):
         s += [("decode.deconv1.weight", (32, 32, 5, 5)), ("decode.deconv1.bias", (32,)),
               ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
               ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
+        return s
+    if c.kind == "auxmnist":
+        # models/ivae/auxmnist.py:47-132 (Encoder = AuxEncoder + SimpleEncoder of models/vae/auxmnist.py:31-190, enc_input = enc_noise
+        # = False: the images and z0 enter encode.fc directly) + models/vae/mnist.py Decoder (n_layers - 1 hidden layers)
+        s = _mlp_spec("encode.aux_encode.main.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += [("encode.aux_encode.reparam.mean_fn.weight", (c.noise_dim, c.h_dim)), ("encode.aux_encode.reparam.mean_fn.bias", (c.noise_dim,)),
+              ("encode.aux_encode.reparam.logvar_fn.weight", (c.noise_dim, c.h_dim)), ("encode.aux_encode.reparam.logvar_fn.bias", (c.noise_dim,))]
+        s += _mlp_spec("encode.encode.fc.", c.input_dim + c.noise_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += [("encode.encode.reparam.mean_fn.weight", (c.z_dim, c.h_dim)), ("encode.encode.reparam.mean_fn.bias", (c.z_dim,)),
+              ("encode.encode.reparam.logvar_fn.weight", (c.z_dim, c.h_dim)), ("encode.encode.reparam.logvar_fn.bias", (c.z_dim,))]
+        s += _mlp_spec("decode.main.", c.z_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += [("decode.reparam.logit_fn.weight", (c.input_dim, c.h_dim)),
+              ("decode.reparam.logit_fn.bias", (c.input_dim,))]
         return s
     if c.kind == "toy":
         s = _mlp_spec("encode.inp_encode.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
@@ -193,6 +207,8 @@ def model_init_special(c: ModelCfg):
                 continue
             sp[name] = ("xavier",) if name.endswith("weight") else ("zeros",)
         return sp
+    if c.kind == "auxmnist":   # do_xavier=True: self.apply(weight_init) on the whole model (ivae/auxmnist.py:172-174)
+        return {name: (("xavier",) if name.endswith("weight") else ("zeros",)) for name, _ in spec}
     for name, _ in spec:
         if name.startswith("decode.") and c.kind == "mnist":
             sp[name] = ("xavier",) if name.endswith("weight") else ("zeros",)
@@ -260,15 +276,56 @@ def encode(c: ModelCfg, p, x, noise, nz):
     elif c.kind == "toy":
         inp = mlp(p, "encode.inp_encode.", x, c.n_layers - 1, c.nonlin, True)
         z = ctxcat_mlp(p, "encode.fc.", expand_rows(inp, nz), noise, c.n_layers, c.nonlin)
+    elif c.kind == "auxmnist":
+        z = aux_encode(c, p, x, noise, nz)["z"]
     else:
         raise NotImplementedError
     return z.view(B, nz, c.z_dim)
 
 
+def aux_encode(c: ModelCfg, p, x, noise, nz):
+    """Hierarchical sampler of the aux models (ivae/auxmnist.py:75-108): noise = (eps0 [B*nz, noise_dim], eps [B*nz, z_dim]), both
+    already scaled by std (std = 0 -> zeros: z0 = mu0(x), z = mu(x, z0)).
+      h0 = MLP(2x-1);  (mu0, lv0) = heads(h0);  z0 = mu0[b] + exp(lv0[b]/2) eps0         (per image -> per sample)
+      h  = MLP(cat[2x-1, z0]);  (mu, lv) = heads(h);  z = mu + exp(lv/2) eps
+    (--model-clip-z0-logvar / --model-clip-z-logvar are 'none' in the shipped recipes: the log-variances are the plain Linear outputs.)"""
+    eps0, eps = noise
+    B = x.size(0)
+    xs = 2 * x.reshape(B, c.input_dim) - 1
+    h0 = mlp(p, "encode.aux_encode.main.", xs, c.n_layers - 1, c.nonlin, True)
+    mu0 = F.linear(h0, p["encode.aux_encode.reparam.mean_fn.weight"], p["encode.aux_encode.reparam.mean_fn.bias"])
+    lv0 = F.linear(h0, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"])
+    z0 = expand_rows(mu0, nz) + torch.exp(0.5 * expand_rows(lv0, nz)) * eps0
+    h = mlp(p, "encode.encode.fc.", torch.cat([expand_rows(xs, nz), z0], 1), c.n_layers - 1, c.nonlin, True)
+    mu = F.linear(h, p["encode.encode.reparam.mean_fn.weight"], p["encode.encode.reparam.mean_fn.bias"])
+    lv = F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"])
+    z = mu + torch.exp(0.5 * lv) * eps
+    return {"z": z, "h0": h0, "h": h, "z0": z0, "mu0": mu0, "lv0": lv0, "mu": mu, "lv": lv}
+
+
+def zero_noise(c: ModelCfg, rows, like):
+    """The draws of an encode(x, std=0) call, multiplied by 0."""
+    if c.kind == "auxmnist":
+        return (like.new_zeros(rows, c.noise_dim), like.new_zeros(rows, c.z_dim))
+    return like.new_zeros(rows, c.noise_dim)
+
+
+def cdae_context(c: ModelCfg, tc, p, x):
+    """--cdae-ctx-type (ivae_ardae.py:729-741): lt0 -> encode(x, std=0) [B, z]; hidden1a -> cat(h0, h) of the std=0 pass [B, 2h]."""
+    B = x.size(0)
+    if tc.ctx_type == "lt0":
+        return encode(c, p, x, zero_noise(c, B, x), 1).reshape(B, c.z_dim)
+    if tc.ctx_type == "hidden1a":
+        assert c.kind == "auxmnist", "hidden1a is the aux models' context"
+        a = aux_encode(c, p, x, zero_noise(c, B, x), 1)
+        return torch.cat([a["h0"], a["h"]], 1)
+    raise NotImplementedError(tc.ctx_type)
+
+
 def decode(c: ModelCfg, p, z):
     """Returns the decoder's distribution parameters for z [R, z_dim]."""
-    if c.kind == "mnist":
-        h = mlp(p, "decode.main.", z, c.n_layers, c.nonlin, True)
+    if c.kind in ("mnist", "auxmnist"):
+        h = mlp(p, "decode.main.", z, c.n_layers if c.kind == "mnist" else c.n_layers - 1, c.nonlin, True)
         return (F.linear(h, p["decode.reparam.logit_fn.weight"], p["decode.reparam.logit_fn.bias"]),)
     if c.kind == "conv":
         f = act(c.nonlin)
@@ -284,7 +341,7 @@ def decode(c: ModelCfg, p, z):
 
 
 def recon_rows(c: ModelCfg, dist, target):
-    if c.kind in ("mnist", "conv"):
+    if c.kind in ("mnist", "conv", "auxmnist"):
         (logit,) = dist
         return F.binary_cross_entropy_with_logits(logit, target, reduction="none").sum(1)
     mu, logvar = dist
@@ -398,12 +455,21 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
     The std=0 encodes consume a draw that is multiplied by 0, so they are skipped here
     (they only advance the reference's RNG stream)."""
     N = B * tc.nz_cdae
-    return {
-        "sampler": torch.randn(N, mc.noise_dim, generator=gen),          # forward_hidden
-        "sigma": torch.randn(B, tc.nz_cdae * tc.nstd, 1, generator=gen),  # stdmat
-        "eps": torch.randn(N * tc.nstd, mc.z_dim, generator=gen),         # add_gaussian_noise
-        "vae": torch.randn(B * tc.nz_model, mc.noise_dim, generator=gen),
-    }
+    aux = mc.kind == "auxmnist"       # a second draw per sampler call: eps of z = mu + exp(lv/2) eps (ivae/auxmnist.py:113-114)
+    n = {"sampler": torch.randn(N, mc.noise_dim, generator=gen)}          # forward_hidden
+    if aux:
+        n["sampler_z"] = torch.randn(N, mc.z_dim, generator=gen)
+    n["sigma"] = torch.randn(B, tc.nz_cdae * tc.nstd, 1, generator=gen)   # stdmat
+    n["eps"] = torch.randn(N * tc.nstd, mc.z_dim, generator=gen)          # add_gaussian_noise
+    n["vae"] = torch.randn(B * tc.nz_model, mc.noise_dim, generator=gen)
+    if aux:
+        n["vae_z"] = torch.randn(B * tc.nz_model, mc.z_dim, generator=gen)
+    return n
+
+
+def sampler_noise(mc: ModelCfg, noise, which):
+    """The sampler's draws out of a step's noise dict: which = "sampler" (cDAE phase) | "vae"."""
+    return (noise[which], noise[which + "_z"]) if mc.kind == "auxmnist" else noise[which]
 
 
 # --------------------------------------------------------------------------- #
@@ -420,14 +486,14 @@ def cdae_update_grads(mc, cc, tc, pm, pc, x, noise):
     Returns loss, grads dict (None for tensors the loss does not reach), std [B,1,1]."""
     B = x.size(0)
     with torch.no_grad():
-        zero = torch.zeros(B, mc.noise_dim)
-        z0 = encode(mc, pm, x, zero, 1)                          # context == latent_mean (lt0)
-        latent = encode(mc, pm, x, noise["sampler"], tc.nz_cdae)
+        z0 = encode(mc, pm, x, zero_noise(mc, B, x), 1)          # latent_mean (and the context for lt0)
+        ctx = z0 if tc.ctx_type == "lt0" else cdae_context(mc, tc, pm, x).unsqueeze(1)
+        latent = encode(mc, pm, x, sampler_noise(mc, noise, "sampler"), tc.nz_cdae)
         u, std = latent_stats(latent, z0, tc.std_scale, tc.delta)
         stdmat = std * noise["sigma"]
         u_exp = u.unsqueeze(2).expand(B, tc.nz_cdae, tc.nstd, mc.z_dim).reshape(B, tc.nz_cdae * tc.nstd, mc.z_dim)
     pc_req = {k: v.detach().requires_grad_(True) for k, v in pc.items()}
-    loss = cdae_forward(cc, pc_req, u_exp, z0, stdmat, noise["eps"])
+    loss = cdae_forward(cc, pc_req, u_exp, ctx, stdmat, noise["eps"])
     grads = _grads_of(loss, pc_req)
     return loss.detach(), grads, std
 
@@ -437,12 +503,13 @@ def vae_update_grads(mc, cc, tc, pm, pc, x, noise, beta=None):
     beta = tc.beta if beta is None else beta
     B = x.size(0)
     pm_req = {k: v.detach().requires_grad_(True) for k, v in pm.items()}
-    z, loss, rec, pri, _ = vae_forward(mc, pm_req, x, noise["vae"], beta, tc.nz_model)
+    z, loss, rec, pri, _ = vae_forward(mc, pm_req, x, sampler_noise(mc, noise, "vae"), beta, tc.nz_model)
     with torch.no_grad():
-        z0 = encode(mc, pm, x, torch.zeros(B, mc.noise_dim), 1)
+        z0 = encode(mc, pm, x, zero_noise(mc, B, x), 1)
+        ctx = z0 if tc.ctx_type == "lt0" else cdae_context(mc, tc, pm, x).unsqueeze(1)
     u = (tc.std_scale * (z - z0)).detach()
-    stdmat = torch.zeros(B, tc.nz_model, 1)
-    g = cdae_glogprob(cc, pc, u, z0, stdmat)
+    stdmat = x.new_zeros(B, tc.nz_model, 1)
+    g = cdae_glogprob(cc, pc, u, ctx, stdmat)
     seed = beta * g / float(B * tc.nz_model)
     # loss.backward(); (s*(z - z0)).backward(seed)  ==  d/dp [loss + sum(s*z*seed)]
     total = loss + (tc.std_scale * (z - z0) * seed).sum()

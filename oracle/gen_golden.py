@@ -60,6 +60,9 @@ def import_reference():
 def build_reference(net, mc, cc, pm, pc, dtype):
     if mc.kind == "conv":
         model = net.ConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, noise_dim=mc.noise_dim, nonlinearity=mc.nonlin)
+    elif mc.kind == "auxmnist":   # ivae_ardae.py:455-466 with --model-clip-z0-logvar / --model-clip-z-logvar none
+        model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
+                                  nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
     elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
                                num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
@@ -87,7 +90,10 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
     model.train(); cdae.train()
     c_opt.zero_grad()
     B = x_cdae.size(0)
-    context = model.encode(x_cdae, std=0).detach()
+    if tc.ctx_type == "hidden1a":   # ivae_ardae.py:737-739
+        context = model.encode.forward_hidden(x_cdae, std=0).detach().unsqueeze(1)
+    else:
+        context = model.encode(x_cdae, std=0).detach()
     latent_mean = model.encode(x_cdae, std=0).detach()
     latent = model.forward_hidden(x_cdae, nz=tc.nz_cdae).detach()
     u = tc.std_scale * (latent - latent_mean)
@@ -109,7 +115,10 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
     B = x_vae.size(0)
     _, _, latent, mloss, rec, pri = model(x_vae, beta=tc.beta, eta=0., lmbd=0., nz=tc.nz_model)
     mloss.backward(retain_graph=True)
-    context = model.encode(x_vae, std=0).detach()
+    if tc.ctx_type == "hidden1a":   # ivae_ardae.py:815-817
+        context = model.encode.forward_hidden(x_vae, std=0).detach().unsqueeze(1)
+    else:
+        context = model.encode(x_vae, std=0).detach()
     latent_mean = model.encode(x_vae, std=0).detach()
     lsm = tc.std_scale * (latent - latent_mean).detach()
     stdmat = torch.zeros(B, tc.nz_model, 1, dtype=lsm.dtype)
@@ -126,6 +135,23 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
 def replay_noise(mc, tc, B_c, B_v, seed, dtype):
     """Re-draw, with the same seed and call sizes, what ref_step consumed (SURVEY 8 a-R)."""
     torch.manual_seed(seed)
+    if mc.kind == "auxmnist":
+        # one Encoder._forward call (ivae/auxmnist.py:110-116) draws eps0 [R, noise_dim] and eps [R, 1, z]; the two reparam modules
+        # it runs then draw samples nobody uses (AuxEncoder.forward: randn_like [B, noise_dim], vae/auxmnist.py:66;
+        # SimpleEncoder._forward_all: randn_like [R, z], :189)
+        def fwd(B, nz):
+            e0 = torch.randn(B * nz, mc.noise_dim)
+            e = torch.randn(B * nz, 1, mc.z_dim)
+            torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * nz, mc.z_dim, dtype=dtype)   # randn_like(std): the model's dtype
+            return e0, e.reshape(B * nz, mc.z_dim)
+        fwd(B_c, 1)                                          # context: forward_hidden(std=0)
+        fwd(B_c, 1)                                          # latent_mean: encode(std=0)
+        n = {}
+        n["sampler"], n["sampler_z"] = fwd(B_c, tc.nz_cdae)
+        n["sigma"] = torch.randn(B_c, tc.nz_cdae * tc.nstd, 1, dtype=dtype)
+        n["eps"] = torch.randn(B_c * tc.nz_cdae * tc.nstd, mc.z_dim, dtype=dtype)
+        n["vae"], n["vae_z"] = fwd(B_v, tc.nz_model)
+        return {k: v.to(dtype) for k, v in n.items()}
     torch.randn(B_c, mc.noise_dim)                       # context encode (x0)
     torch.randn(B_c, mc.noise_dim)                       # latent_mean encode (x0)
     n = {}
@@ -143,7 +169,7 @@ def rel_l2(a, b):
 
 def synth_x(mc, B, seed):
     g = torch.Generator().manual_seed(seed)
-    if mc.kind in ("mnist", "conv"):
+    if mc.kind in ("mnist", "conv", "auxmnist"):
         p = (torch.rand(mc.input_dim, generator=g) < 0.2).float() * 0.6 + 0.03
         return torch.bernoulli(p.expand(B, -1), generator=g)
     mu = (torch.randint(0, 5, (B, mc.input_dim), generator=g).float() - 2) * 2
@@ -265,6 +291,11 @@ def main():
     net, rutils = import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
     f32, f64 = torch.float32, torch.float64
+    only = set(sys.argv[1:])                                  # optional: names of the fixtures to (re)generate
+    if only:
+        real_run_case, real_iwae = run_case, run_iwae_case
+        globals()["run_case"] = lambda net_, ru_, name, *a, **k: real_run_case(net_, ru_, name, *a, **k) if name in only else None
+        globals()["run_iwae_case"] = lambda net_, name, *a, **k: real_iwae(net_, name, *a, **k) if name in only else None
     tiny_m = O.ModelCfg("mnist", input_dim=24, noise_dim=10, h_dim=64, z_dim=8, n_layers=2, nonlin="softplus")
     tiny_c = O.CdaeCfg("grad", input_dim=8, context_dim=8, h_dim=64, n_layers=3)
     tc = O.TrainCfg(nz_cdae=8)
@@ -288,6 +319,13 @@ def main():
     conv_c = O.CdaeCfg("grad", 32, 32, 64, 2)
     run_case(net, rutils, "conv_b4_nz8", conv_m, conv_c, O.TrainCfg(nz_cdae=8), B=4, steps=2, dtype=f32, store_full=False)
     run_iwae_case(net, "iwae_tiny", tiny_m, B=3, k=16, dtype=f64)
+    # hierarchical (aux) sampler of the shipped "hierarchical mlp" recipe (run_vae_dbmnist.sh: --model auxmnist --cdae-ctx-type hidden1a):
+    # oracle pin only so far - the HIP path for this family is the next row to build
+    aux_m = O.ModelCfg("auxmnist", input_dim=24, noise_dim=10, h_dim=48, z_dim=8, n_layers=2, nonlin="softplus")
+    aux_c = O.CdaeCfg("grad", input_dim=8, context_dim=96, h_dim=64, n_layers=3)
+    aux_t = O.TrainCfg(nz_cdae=8, ctx_type="hidden1a")
+    run_case(net, rutils, "tiny_auxmnist_grad_f64", aux_m, aux_c, aux_t, B=4, steps=1, dtype=f64, store_full=True)
+    run_case(net, rutils, "tiny_auxmnist_grad", aux_m, aux_c, aux_t, B=4, steps=2, dtype=f32, store_full=True)
 
 
 if __name__ == "__main__":

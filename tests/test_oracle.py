@@ -12,6 +12,10 @@ CASES = {
     "tiny_mnist_grad_f64": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, torch.float64),
     "tiny_mnist_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("res", 8, 8, 64, 3), 8, torch.float32),
     "tiny_toy_grad": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3), 8, torch.float32),
+    # hierarchical (aux) sampler + hidden1a context of the shipped "hierarchical mlp" recipe: the oracle of SURVEY 8 f-3's first
+    # family is pinned against the reference's MNISTAuxIPVAE here; its HIP path is the next row to build
+    "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, torch.float32),
+    "tiny_auxmnist_grad_f64": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, torch.float64),
 }
 
 
@@ -23,13 +27,13 @@ def rel_l2(a, b):
 def test_oracle_step_matches_reference_fixture(golden_dir, name):
     mc, cc, nz, dt = CASES[name]
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-    tc = O.TrainCfg(nz_cdae=nz)
+    tc = O.TrainCfg(nz_cdae=nz, ctx_type="hidden1a" if mc.kind == "auxmnist" else "lt0")
     tol = 2e-4 if dt == torch.float32 else 1e-9    # another CPU/BLAS than the one that wrote the fixture: fp32 noise x 1e4 (std_scale)
     pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
     pc = {n: torch.tensor(fx["pc/" + n]) for n, _ in O.cdae_param_spec(cc)}
     for t in range(int(fx["meta_steps"])):
         pre = f"s{t}/"
-        noise = {k: torch.tensor(fx[pre + "noise/" + k]) for k in ("sampler", "sigma", "eps", "vae")}
+        noise = {k[len(pre + "noise/"):]: torch.tensor(v) for k, v in fx.items() if k.startswith(pre + "noise/")}
         xc, xv = torch.tensor(fx[pre + "x_cdae"]), torch.tensor(fx[pre + "x_vae"])
         closs, gc, std = O.cdae_update_grads(mc, cc, tc, pm, pc, xc, noise)
         assert abs(float(closs) - float(fx[pre + "cdae_loss"])) / float(fx[pre + "cdae_loss"]) < tol
