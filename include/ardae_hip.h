@@ -200,6 +200,11 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
 int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
                             const float* noise, int B, int nz, float beta, float* workspace, size_t workspace_floats,
                             float* z_out, float* losses, void* stream);
+/* Aux models (kind 3): the std = 0 pass of the sampler, returning the latent mean z0 [B, z] (may be NULL) AND the encoder hiddens
+ * cat(h0, h) [B, 2 h] that --cdae-ctx-type hidden1a uses as the cDAE context (ivae_ardae.py:737-739, ivae/auxmnist.py:125-132).
+ * Workspace: mode 0 with nz = 1. */
+int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B,
+                              float* workspace, size_t workspace_floats, float* z0_out, float* hidden_out, void* stream);
 /* Decoder.forward (ivae/mnist.py:188-199, toy.py:725-737) without the sample: head outputs for z [R, z_dim]:
  * out0 = logits (kind 0) / mean (kind 1) [R, input_dim], out1 = logvar (kind 1) or NULL.  Workspace: mode 2.
  * Used by the IWAE evaluator (ivae/mnist.py:420-425). */

@@ -12,6 +12,7 @@
 
 #include "ardae_hip.h"
 #include "common.h"
+#include "auxmodel.h"
 #include "convmodel.h"
 #include "elementwise.h"
 #include "linear.h"
@@ -88,7 +89,7 @@ struct Bump {
 
 int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d != nullptr, "model: desc is NULL");
-  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 2, "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat) or 2 (ConvIPVAE)");
+  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 3, "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE) or 3 (MNISTAuxIPVAE)");
   if (d->kind == 2) {
     ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1, "model: ConvIPVAE is hard-wired to 28x28x1 inputs (input_dim 784)");
     ARDAE_CHECK_ARG(d->act == ACT_SOFTPLUS || d->act == ACT_RELU, "model: activation must be softplus or relu");
@@ -247,14 +248,17 @@ extern "C" {
 
 size_t ardae_model_param_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
+  if (d->kind == 3) return aux_model_param_floats(*d);
   return d->kind == 2 ? conv_model_param_floats(*d) : ModelLayout(*d).total;
 }
 size_t ardae_model_packed_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
+  if (d->kind == 3) return aux_model_packed_floats(*d);
   return d->kind == 2 ? conv_model_packed_floats(*d) : ModelPacked(ModelLayout(*d)).total;
 }
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
   if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
+  if (d->kind == 3) return aux_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 2) return conv_model_workspace_floats(*d, B, nz, mode == 3 ? 0 : mode);
   const ModelLayout P(*d);
   if (mode == 2) return P.dec.size() * al64((size_t)B * nz * P.h);
@@ -267,6 +271,7 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
   ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
+  if (d->kind == 3) return aux_model_pack(*d, params, packed, st);
   if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
   std::vector<PackItem> pack_items__;
   const ModelLayout P(*d);
@@ -309,6 +314,10 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   ARDAE_CHECK_ARG(z_out, "model_encode: z_out is NULL");
   hipStream_t st = (hipStream_t)stream;
   ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
+  if (d->kind == 3) {
+    ARDAE_TRY(aux_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st));
+    return chain_scope.finish();
+  }
   if (d->kind == 2) return conv_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
@@ -335,7 +344,7 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
   ARDAE_CHECK_ARG(params && packed && x && (noise || phase == 1) && workspace && z0_out && z_out, "model_encode_pair: null pointer argument");
   ARDAE_CHECK_ARG(B > 0 && nz > 0 && (int64_t)B * nz < (int64_t)1 << 30, "model_encode_pair: bad batch (B=%d nz=%d)", B, nz);
   ARDAE_CHECK_ARG(workspace_floats_ >= ardae_model_workspace_floats(d, B, nz, 3), "model_encode_pair: workspace too small");
-  if (d->kind == 2) {   // conv sampler: two passes over the same workspace
+  if (d->kind == 2 || d->kind == 3) {   // conv / aux samplers: two passes over the same workspace
     if (phase != 2) ARDAE_TRY(ardae_model_encode(d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, stream));
     if (phase == 1) return 0;
     return ardae_model_encode(d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, stream);
@@ -360,6 +369,17 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
   return chain_scope.finish();
 }
 
+int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B, float* workspace,
+                              size_t workspace_floats_, float* z0_out, float* hidden_out, void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, 1, workspace, workspace_floats_, 0));
+  ARDAE_CHECK_ARG(d->kind == 3, "model_encode_hidden: the hidden1a context exists for the aux models only (kind 3)");
+  ARDAE_CHECK_ARG(hidden_out, "model_encode_hidden: hidden_out is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  ChainScope chain_scope(st);
+  ARDAE_TRY(aux_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
+  return chain_scope.finish();
+}
+
 int ardae_model_decode(const ardae_model_desc* d, const float* params, const float* packed, const float* z, int R, float* workspace,
                        size_t workspace_floats_, float* out0, float* out1, void* stream) {
   ARDAE_TRY(desc_ok(d));
@@ -367,6 +387,12 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
   if (d->kind == 2) {
     ARDAE_CHECK_ARG(workspace_floats_ >= conv_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
     return conv_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
+  }
+  if (d->kind == 3) {
+    ARDAE_CHECK_ARG(workspace_floats_ >= aux_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
+    ChainScope aux_scope((hipStream_t)stream);
+    ARDAE_TRY(aux_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream));
+    return aux_scope.finish();
   }
   const ModelLayout P(*d);
   const ModelPacked K(P);
@@ -404,6 +430,10 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   ARDAE_CHECK_ARG(noise && z_out && losses, "model_vae_forward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
   ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
+  if (d->kind == 3) {
+    ARDAE_TRY(aux_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st));
+    return chain_scope.finish();
+  }
   if (d->kind == 2) return conv_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
@@ -522,6 +552,10 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
     ChainScope chain_scope(st);
     return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
+  if (d->kind == 3) {
+    ChainScope chain_scope(st);
+    return aux_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
+  }
   return vae_backward_impl(d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, 1.f, workspace, workspace_floats_, grads, grads_beta, 3, st);
 }
 
@@ -530,7 +564,7 @@ int ardae_model_vae_backward_decoder(const ardae_model_desc* d, const float* par
                                      size_t workspace_floats_, void* stream) {
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise, "model_vae_backward_decoder: null pointer argument");
-  ARDAE_CHECK_ARG(d->kind != 2, "model_vae_backward_decoder: the conv model has no split backward (use ardae_model_vae_backward)");
+  ARDAE_CHECK_ARG(d->kind < 2, "model_vae_backward_decoder: the conv model and the aux model have no split backward (use ardae_model_vae_backward)");
   return vae_backward_impl(d, params, packed, x, noise, B, nz, beta, dloss, nullptr, 0.f, workspace, workspace_floats_, nullptr, 0.f, 1,
                            (hipStream_t)stream);
 }
@@ -540,7 +574,7 @@ int ardae_model_vae_backward_sampler(const ardae_model_desc* d, const float* par
                                      size_t workspace_floats_, float* grads, float grads_beta, void* stream) {
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && grads, "model_vae_backward_sampler: null pointer argument");
-  ARDAE_CHECK_ARG(d->kind != 2, "model_vae_backward_sampler: the conv model has no split backward (use ardae_model_vae_backward)");
+  ARDAE_CHECK_ARG(d->kind < 2, "model_vae_backward_sampler: the conv model and the aux model have no split backward (use ardae_model_vae_backward)");
   return vae_backward_impl(d, params, packed, x, noise, B, nz, 0.f, 0.f, dz_extra, seed_scale, workspace, workspace_floats_, grads,
                            grads_beta, 2, (hipStream_t)stream);
 }

@@ -29,6 +29,7 @@ class TrainConfig:
     m_beta1: float = 0.5
     d_lr: float = 1e-4            # --d-lr, RMSprop momentum d_momentum
     d_momentum: float = 0.5
+    cdae_ctx_type: str = "lt0"    # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens)
 
 
 def annealing_func(val_init, val_fin, val_annealing, step):
@@ -61,7 +62,15 @@ class ArdaeEngine:
         md, cd = model._desc, cdae._desc
         B, nzc, nzm = self.B, cfg.nz_cdae, cfg.nz_model
         N = B * nzc
-        z, nd = model.z_dim, model.noise_dim
+        z, nd = model.z_dim, model._noise_width          # floats per row of a sampler draw (aux models: [eps0 | eps])
+        if cfg.cdae_ctx_type not in ("lt0", "hidden1a"):
+            raise NotImplementedError(f"cdae_ctx_type {cfg.cdae_ctx_type!r}")          # ivae_ardae.py:743-744
+        if cfg.cdae_ctx_type == "hidden1a" and model._kind != "auxmnist":
+            raise NotImplementedError("hidden1a is the aux models' context (ivae_ardae.py:572-580)")
+        self.hidden_ctx = cfg.cdae_ctx_type == "hidden1a"
+        ctx_dim = 2 * model.h_dim if self.hidden_ctx else z
+        if int(cdae.context_dim) != ctx_dim:
+            raise ValueError(f"cdae.context_dim = {cdae.context_dim}, but the {cfg.cdae_ctx_type} context has {ctx_dim} columns")
         f = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
         lib = self.lib
         ws_floats = max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, nzc, 1),
@@ -76,6 +85,7 @@ class ArdaeEngine:
         self.xbar, self.sigma, self.std_b = f(N, z), f(N), f(B)
         self.noise_v, self.zv, self.z0v, self.u, self.g = f(B * nzm, nd), f(B * nzm, z), f(B, z), f(B * nzm, z), f(B * nzm, z)
         self.sigma0 = torch.zeros(B * nzm, device=self.dev)
+        self.ctx_c, self.ctx_v = (f(B, ctx_dim), f(B, ctx_dim)) if self.hidden_ctx else (self.z0, self.z0v)
         self.loss_c, self.losses_m = f(1), f(3)
         self.grads_c = torch.zeros_like(cdae._flat)
         self.grads_m = torch.zeros_like(model._flat)
@@ -95,7 +105,7 @@ class ArdaeEngine:
         # nothing from the cDAE update: step() runs it on a side stream next to the cDAE phase's N-row kernels.
         self.overlap = os.environ.get("ARDAE_OVERLAP", "1") != "0"
         # MLP models: the decoder half of the VAE backward (down to dL/dz) joins the forward half on the side stream
-        self.split_backward = int(md.kind) != 2 and os.environ.get("ARDAE_SPLIT_BACKWARD", "1") != "0"
+        self.split_backward = int(md.kind) < 2 and os.environ.get("ARDAE_SPLIT_BACKWARD", "1") != "0"
         self._side = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self.repack()
 
@@ -116,6 +126,10 @@ class ArdaeEngine:
         L.check(self.lib.ardae_model_encode(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x),
                                             L.ptr(noise) if noise is not None else None, x.size(0), nz, L.ptr(ws), ws.numel(),
                                             L.ptr(out), L.stream_ptr()), "ardae_model_encode")
+
+    def _hidden(self, x, out, ws):
+        L.check(self.lib.ardae_model_encode_hidden(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), x.size(0),
+                                                   L.ptr(ws), ws.numel(), None, L.ptr(out), L.stream_ptr()), "ardae_model_encode_hidden")
 
     def _allreduce_mean(self, t):
         dist.allreduce_mean_(t, self.pg)
@@ -169,8 +183,10 @@ class ArdaeEngine:
             pair(0)
         L.check(lib.ardae_latent_perturb(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, z, cfg.std_scale, cfg.delta,
                                          L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb")
+        if self.hidden_ctx:      # hidden = model.encode.forward_hidden(x, std=0) (ivae_ardae.py:737-739)
+            self._hidden(x, self.ctx_c, self.ws_small)
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
-                                          L.ptr(self.sigma), L.ptr(eps), L.ptr(self.z0), B, nz, L.ptr(self.ws), self.ws.numel(),
+                                          L.ptr(self.sigma), L.ptr(eps), L.ptr(self.ctx_c), B, nz, L.ptr(self.ws), self.ws.numel(),
                                           L.ptr(self.loss_c), L.ptr(self.grads_c), None, st), "ardae_cdae_loss_grads")
         self._allreduce_mean(self.grads_c[:self.n_c])
         if apply_update:
@@ -188,6 +204,8 @@ class ArdaeEngine:
                                             float(beta), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.zv), L.ptr(self.losses_m), st),
                 "ardae_model_vae_forward")
         self._encode(x, None, 1, self.z0v, self.ws_small_v)
+        if self.hidden_ctx:      # ivae_ardae.py:815-817
+            self._hidden(x, self.ctx_v, self.ws_small_v)
         L.check(lib.ardae_center_scale(L.ptr(self.zv), L.ptr(self.z0v), B, nz, self.model.z_dim, cfg.std_scale, L.ptr(self.u), st))
         if self.split_backward:
             # model_loss.backward() through the decoder down to dL/dz (ivae_ardae.py:804) needs nothing from the cDAE either
@@ -202,7 +220,7 @@ class ArdaeEngine:
         beta = cfg.beta if beta is None else beta
         B, nz, md = self.B, cfg.nz_model, self.model._desc
         L.check(lib.ardae_cdae_score(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.u),
-                                     L.ptr(self.sigma0), L.ptr(self.z0v), B, nz, L.ptr(self.ws_small), self.ws_small.numel(),
+                                     L.ptr(self.sigma0), L.ptr(self.ctx_v), B, nz, L.ptr(self.ws_small), self.ws_small.numel(),
                                      L.ptr(self.g), st), "ardae_cdae_score")
         # seed of (s (z - z0)).backward(beta g / (B nz)) w.r.t. z  (ivae_ardae.py:834); B is the per-rank batch because the
         # ranks' gradients are averaged afterwards (mean over ranks of 1/B_local == 1/B_global sum)

@@ -32,6 +32,14 @@ class _EncodeBox(_Box):
         o = self._owner_ref()
         return o._sample(o._x(x), nz, std, noise)
 
+    def forward_hidden(self, x, std=None, nz=1):
+        """Aux models: `model.encode.forward_hidden(x, std=0)` -> cat(h0, h) [B, 2 h], the `hidden1a` cDAE context
+        (ivae/auxmnist.py:125-132, ivae_ardae.py:737-739)."""
+        assert nz == 1                                    # ivae/auxmnist.py:126
+        if std is None or float(std) != 0.0:
+            raise NotImplementedError("forward_hidden is implemented for std=0 (its only use in ivae_ardae.py)")
+        return self._owner_ref()._hidden(x)
+
 
 class FlatParamModule(nn.Module):
     def _build_params(self, spec, boxes=None):
@@ -246,11 +254,12 @@ class _VaeFn(torch.autograd.Function):
 
 class ImplicitPosteriorVAE(FlatParamModule):
     _kind = None
+    _enc_types = ("concat",)
 
     def __init__(self, energy_func=normal_energy_func, input_dim=784, noise_dim=100, h_dim=300, z_dim=32, nonlinearity="softplus",
                  num_hidden_layers=1, init="gaussian", enc_type="concat"):
         super().__init__()
-        assert enc_type in ["concat"]                    # ivae/mnist.py:224; the other toy encoders are out of scope
+        assert enc_type in self._enc_types               # ivae/mnist.py:224; the other toy encoders are out of scope
         if energy_func is not normal_energy_func:
             raise NotImplementedError("only utils.normal_energy_func is implemented on the HIP path")
         if nonlinearity not in ("softplus", "relu"):
@@ -259,8 +268,10 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self.input_dim, self.noise_dim, self.h_dim, self.z_dim = input_dim, noise_dim, h_dim, z_dim
         self.latent_dim = z_dim
         self.nonlinearity, self.num_hidden_layers, self.init, self.enc_type = nonlinearity, num_hidden_layers, init, enc_type
-        self._desc = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2}[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers,
+        self._desc = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3}[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers,
                                  L.ACT[nonlinearity])
+        # floats per row of a sampler draw: the aux models take two draws per call, laid out side by side [eps0 | eps]
+        self._noise_width = noise_dim + z_dim if self._kind == "auxmnist" else noise_dim
         self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers), {"encode": _EncodeBox})
         object.__setattr__(self.encode, "_owner_ref", weakref.ref(self))   # `model.encode(x, std=0)` (ivae_ardae.py:735)
         self.reset_parameters()
@@ -269,6 +280,11 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self._default_init()
         with torch.no_grad():
             p = dict(self.named_parameters())
+            if self._kind == "auxmnist":                  # self.apply(weight_init) on the whole model (ivae/auxmnist.py:172-174)
+                if self.do_xavier:
+                    for t in p.values():
+                        nn.init.xavier_uniform_(t) if t.dim() == 2 else t.zero_()
+                return
             if self._kind == "conv":                      # self.apply(weight_init): xavier-uniform on Conv2d / Linear, zero biases;
                 if self.do_xavier:                        # ConvTranspose2d keeps torch's default init (vae/auxconv.py:18-23)
                     for name, t in p.items():
@@ -306,10 +322,10 @@ class ImplicitPosteriorVAE(FlatParamModule):
             nptr = None                                   # encode(x, std=0): the draw is multiplied by zero
         else:
             if noise is None:
-                noise = rng.normal((B * nz, self.noise_dim), x.device)
+                noise = rng.normal((B * nz, self._noise_width), x.device)
                 if std is not None:
                     noise = noise * float(std)
-            noise = _f32c(noise).view(B * nz, self.noise_dim)
+            noise = self._noise_rows(noise, B * nz)
             nptr = L.ptr(noise)
         lib = L.lib()
         ws = self._ws(lib.ardae_model_workspace_floats(ctypes.byref(self._desc), B, nz, 0))
@@ -318,8 +334,26 @@ class ImplicitPosteriorVAE(FlatParamModule):
                                        L.ptr(ws), ws.numel(), L.ptr(z), L.stream_ptr()), "ardae_model_encode")
         return z.view(B, nz, self.z_dim)
 
+    def _noise_rows(self, noise, rows):
+        """[rows, noise width] fp32 contiguous; the aux models also take the pair (eps0 [rows, noise_dim], eps [rows, z_dim])."""
+        if isinstance(noise, (tuple, list)):
+            noise = torch.cat([_f32c(n).view(rows, -1) for n in noise], 1)
+        return _f32c(noise).view(rows, self._noise_width)
+
     def forward_hidden(self, input, std=None, nz=1, noise=None):
         return self._sample(self._x(input), nz, std, noise)
+
+    def _hidden(self, input):
+        """cat(h0, h) [B, 2 h] of the std = 0 pass (aux models; the `hidden1a` cDAE context)."""
+        if self._kind != "auxmnist":
+            raise NotImplementedError("hidden contexts exist for the aux models only")
+        x = self._x(input)
+        B, lib = x.size(0), L.lib()
+        ws = self._ws(lib.ardae_model_workspace_floats(ctypes.byref(self._desc), B, 1, 0))
+        hid = torch.empty(B, 2 * self.h_dim, device=x.device)
+        L.check(lib.ardae_model_encode_hidden(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(x), B, L.ptr(ws),
+                                              ws.numel(), None, L.ptr(hid), L.stream_ptr()), "ardae_model_encode_hidden")
+        return hid
 
     def forward(self, input, beta=1.0, eta=0.0, lmbd=0.0, std=None, nz=1, noise=None):
         """-> (None, None, z, loss, recon.detach(), prior.detach()).  The first two entries (a decoder sample and its mean,
@@ -329,10 +363,10 @@ class ImplicitPosteriorVAE(FlatParamModule):
         x = self._x(input)
         B = x.size(0)
         if noise is None:
-            noise = rng.normal((B * nz, self.noise_dim), x.device)
+            noise = rng.normal((B * nz, self._noise_width), x.device)
             if std is not None:
                 noise = noise * float(std)
-        noise = _f32c(noise).view(B * nz, self.noise_dim)
+        noise = self._noise_rows(noise, B * nz)
         z, loss, losses = _VaeFn.apply(self, x, noise, beta, nz, *self.parameters())
         return None, None, z, loss, losses[1].detach(), losses[2].detach()
 
@@ -403,6 +437,24 @@ class ConvIPVAE(ImplicitPosteriorVAE):
             raise NotImplementedError("ConvIPVAE: the reference decoder (models/vae/conv.py:79-136) is hard-wired to 28x28x1")
         self.input_height, self.input_channels, self.do_xavier = input_height, input_channels, do_xavier
         super().__init__(energy_func, input_height * input_height * input_channels, noise_dim, 800, z_dim, nonlinearity, 1, "none", "concat")
+
+
+class MNISTAuxIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/auxmnist.py::ImplicitPosteriorVAE (`--model auxmnist`, the shipped "hierarchical mlp" recipe): AuxEncoder -> z0 ->
+    SimpleEncoder -> z, both Gaussian reparameterisations, `enc_type='simple'`, no log-variance clipping.  A sampler call takes two draws;
+    `noise=` accepts the pair (eps0 [rows, noise_dim], eps [rows, z_dim]) or one [rows, noise_dim + z_dim] tensor."""
+    _kind = "auxmnist"
+    _enc_types = ("simple",)
+
+    def __init__(self, energy_func=normal_energy_func, input_dim=784, noise_dim=100, h_dim=300, z_dim=32, nonlinearity="softplus",
+                 num_hidden_layers=2, enc_type="simple", clip_z0_logvar=None, clip_z_logvar=None, do_xavier=True):
+        for c in (clip_z0_logvar, clip_z_logvar):
+            if c not in (None, "none"):
+                raise NotImplementedError("log-variance clipping (the shipped recipes pass 'none')")
+        if enc_type != "simple":
+            raise NotImplementedError                     # ivae/auxmnist.py:72-73
+        self.do_xavier, self.clip_z0_logvar, self.clip_z_logvar = do_xavier, None, None
+        super().__init__(energy_func, input_dim, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, "none", enc_type)
 
 
 class ToyIPVAE(ImplicitPosteriorVAE):

@@ -21,11 +21,16 @@ CASES = {
     "cfg2_b8_nz16": (O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus"), O.CdaeCfg("grad", 32, 32, 256, 3), 16, False),
     "cfg1_b8_nz16": (O.ModelCfg("toy", 2, 10, 256, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 256, 3), 16, False),
     "conv_b4_nz8": (O.ModelCfg("conv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 32, 64, 2), 8, False),   # cfg #4 model
+    # the shipped "hierarchical mlp" recipe's model family: aux sampler + hidden1a context (run_vae_dbmnist.sh --model auxmnist)
+    "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, True),
 }
 
 
 def build(mc, cc):
-    if mc.kind == "conv":
+    if mc.kind == "auxmnist":
+        model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
+                                  nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
+    elif mc.kind == "conv":
         model = net.ConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, noise_dim=mc.noise_dim, nonlinearity=mc.nonlin)
     else:
         ctor = net.MNISTIPVAE if mc.kind == "mnist" else net.ToyIPVAE
@@ -70,7 +75,15 @@ def assert_update_close(after, before, ref_after, what):
 
 
 def noise_of(fx, t, dev):
-    return {k: torch.tensor(fx[f"s{t}/noise/{k}"]).to(dev).contiguous() for k in ("sampler", "sigma", "eps", "vae")}
+    n = {k: torch.tensor(fx[f"s{t}/noise/{k}"]) for k in ("sampler", "sigma", "eps", "vae")}
+    for k in ("sampler", "vae"):        # aux models: the second draw of a sampler call sits beside the first, rows [eps0 | eps]
+        if f"s{t}/noise/{k}_z" in fx:
+            n[k] = torch.cat([n[k], torch.tensor(fx[f"s{t}/noise/{k}_z"])], 1)
+    return {k: v.to(dev).contiguous() for k, v in n.items()}
+
+
+def train_config(mc, nz, **kw):
+    return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a" if mc.kind == "auxmnist" else "lt0", **kw)
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -82,7 +95,7 @@ def test_engine_trajectory_golden(golden_dir, name):
     model.load_state_dict(pm); cdae.load_state_dict(pc)
     model, cdae = model.to("cuda"), cdae.to("cuda")
     B, steps = int(fx["meta_B"]), int(fx["meta_steps"])
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=nz), batch_size=B)
+    eng = net.ArdaeEngine(model, cdae, train_config(mc, nz), batch_size=B)
     for t in range(steps):
         pre = f"s{t}/"
         xc, xv = torch.tensor(fx[pre + "x_cdae"]).cuda(), torch.tensor(fx[pre + "x_vae"]).cuda()
@@ -157,7 +170,7 @@ def test_engine_step_production_kernels_vs_oracle(kind):
     assert_update_close(model.flat_params().cpu(), before_m, ref_m, "model update")
 
 
-@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res"])
+@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad"])
 def test_vae_phase_grads_golden(golden_dir, name):
     mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, name)
     model, cdae = build(mc, cc)
@@ -167,7 +180,7 @@ def test_vae_phase_grads_golden(golden_dir, name):
     with torch.no_grad():
         cdae.flat_params().copy_(torch.cat([torch.tensor(fx["s0/cdae_params_after/" + n]).reshape(-1) for n, _ in O.cdae_param_spec(cc)]).cuda())
     B = int(fx["meta_B"])
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=nz), batch_size=B)
+    eng = net.ArdaeEngine(model, cdae, train_config(mc, nz), batch_size=B)
     eng.vae_phase(torch.tensor(fx["s0/x_vae"]).cuda(), noise=noise_of(fx, 0, "cuda"), apply_update=False)
     torch.cuda.synchronize()
     assert rel_l2(eng.zv, fx["s0/vae_latent"].reshape(B, -1)) < 1e-5
@@ -517,3 +530,37 @@ def test_engine_beta_annealing_under_graph_mode():
             assert captured_at is not None and captured_at >= 5 and betas[captured_at] == betas[7]     # never while beta was moving
         outs.append((model.flat_params().clone(), cdae.flat_params().clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_aux_model_module_surface(golden_dir):
+    """MNISTAuxIPVAE through the reference's call surface (ivae_ardae.py:737-749,801-834): the hidden1a context, the latent mean,
+    the sampler with a pair of draws, and the loss / gradients of model(...) + latent.backward(seed) against the oracle."""
+    mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, "tiny_auxmnist_grad")
+    model, _ = build(mc, cc)
+    model.load_state_dict(pm)
+    model = model.to("cuda")
+    x = torch.tensor(fx["s0/x_cdae"])
+    B = x.size(0)
+    hid = model.encode.forward_hidden(x.cuda(), std=0)
+    ref_hid = O.cdae_context(mc, O.TrainCfg(ctx_type="hidden1a"), pm, x)
+    assert hid.shape == (B, 2 * mc.h_dim) and rel_l2(hid, ref_hid) < 1e-5
+    z0 = model.encode(x.cuda(), std=0)
+    assert z0.shape == (B, 1, mc.z_dim) and rel_l2(z0.reshape(B, -1), fx["s0/z0"].reshape(B, -1)) < 1e-5
+    e0, e = torch.tensor(fx["s0/noise/sampler"]), torch.tensor(fx["s0/noise/sampler_z"])
+    z = model.forward_hidden(x.cuda(), nz=nz, noise=(e0.cuda(), e.cuda()))
+    assert z.shape == (B, nz, mc.z_dim) and rel_l2(z.reshape(B * nz, -1), O.encode(mc, pm, x, (e0, e), nz).reshape(B * nz, -1)) < 1e-5
+    # loss + both backward calls of the VAE phase, with an arbitrary seed
+    xv = torch.tensor(fx["s0/x_vae"])
+    nv = (torch.tensor(fx["s0/noise/vae"]), torch.tensor(fx["s0/noise/vae_z"]))
+    seed = torch.tensor(fx["s0/score"]).reshape(B, 1, mc.z_dim) * 0.01
+    _, _, latent, loss, rec, pri = model(xv.cuda(), beta=1.0, eta=0., lmbd=0., nz=1, noise=(nv[0].cuda(), nv[1].cuda()))
+    loss.backward(retain_graph=True)
+    latent.backward(seed.cuda())
+    preq = {k: v.clone().requires_grad_(True) for k, v in pm.items()}
+    zr, lr_, recr, prir, _ = O.vae_forward(mc, preq, xv, nv, 1.0, 1)
+    (lr_ + (zr * seed).sum()).backward()
+    assert rel(loss.item(), lr_.item()) < 1e-4 and rel(rec.item(), recr.item()) < 2e-5 and rel(pri.item(), prir.item()) < 2e-5
+    for n, p in model.named_parameters():
+        assert rel_l2(p.grad.cpu(), preq[n].grad) < 2e-4, n
+    with pytest.raises(NotImplementedError):
+        net.MNISTAuxIPVAE(clip_z_logvar="spm4")
