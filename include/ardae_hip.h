@@ -170,7 +170,12 @@ int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float*
  *   kind 0 (MNISTIPVAE): encode.inp_encode.{layers.0..n_layers, fc}, encode.fc.{layers.0, fc}, decode.main.{layers.*, fc},
  *                        decode.reparam.logit_fn;   Bernoulli decoder, x rescaled to 2x-1 inside the encoder
  *   kind 1 (ToyIPVAE)  : encode.inp_encode.{layers.0..n_layers-2, fc}, encode.fc.{layers.0..n_layers-1, fc} (ContextConcatMLP:
- *                        every layer eats [hidden, noise]), decode.main.*, decode.reparam.{mean_fn, logvar_fn}; Gaussian decoder */
+ *                        every layer eats [hidden, noise]), decode.main.*, decode.reparam.{mean_fn, logvar_fn}; Gaussian decoder
+ *   kind 2 (ConvIPVAE) : models/ivae/conv.py (28 x 28 x 1 only)
+ *   kind 3 (MNISTAuxIPVAE, models/ivae/auxmnist.py): encode.aux_encode.{main.*, reparam.{mean_fn, logvar_fn}},
+ *                        encode.encode.{fc.*, reparam.{mean_fn, logvar_fn}}, decode.main.*, decode.reparam.logit_fn.  Its sampler takes TWO
+ *                        draws per call: every `noise` argument of this kind is ONE [rows, noise_dim + z_dim] tensor, row = [eps0 | eps]
+ *                        (z0 = mu0 + exp(lv0/2) eps0,  z = mu + exp(lv/2) eps) */
 typedef struct ardae_model_desc {
   int kind;
   int input_dim, noise_dim, h_dim, z_dim;

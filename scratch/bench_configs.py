@@ -33,6 +33,12 @@ def cfg(i):
         c = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=256, num_hidden_layers=5, nonlinearity="softplus",
                               noise_type="gaussian", enc_ctx=True, enc_input=True)
         return m, c, 128, 625, lambda B, dev: (torch.rand(B, 784, device=dev) < 0.13).float(), dict(z=32, h=256, L=5, kind="grad")
+    if i == 7:   # the shipped "hierarchical mlp" recipe (run_vae_dbmnist.sh: --model auxmnist h 300, --cdae-ctx-type hidden1a, nz_cdae 625, L 5)
+        m = net.MNISTAuxIPVAE(input_dim=784, noise_dim=100, h_dim=300, num_hidden_layers=2, nonlinearity="softplus", enc_type="simple", z_dim=32,
+                              clip_z0_logvar="none", clip_z_logvar="none")
+        c = net.MLPGradCARDAE(input_dim=32, context_dim=600, std=1., h_dim=256, num_hidden_layers=5, nonlinearity="softplus",
+                              noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 128, 625, lambda B, dev: (torch.rand(B, 784, device=dev) < 0.13).float(), dict(z=32, h=256, L=5, kind="grad", ctx="hidden1a")
     raise SystemExit(f"no config {i}")
 
 def cdae_flops(B, nz, z, h, L, kind):
@@ -47,7 +53,7 @@ for i in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5]:
     torch.manual_seed(0)
     m, c, B, nz, data, shp = cfg(i)
     m, c = m.to(dev), c.to(dev)
-    eng = net.ArdaeEngine(m, c, net.TrainConfig(nz_cdae=nz), batch_size=B)
+    eng = net.ArdaeEngine(m, c, net.TrainConfig(nz_cdae=nz, cdae_ctx_type=shp.pop("ctx", "lt0")), batch_size=B)
     x1, x2 = data(B, dev), data(B, dev)
     steps = 20 if i < 4 else 5
     for _ in range(3):
