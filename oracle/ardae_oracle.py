@@ -539,10 +539,16 @@ def iwae_logprob(mc: ModelCfg, pm, x, sample_size, enc_noise, prop_noise):
     B = x.size(0)
     x = x.reshape(B, mc.input_dim)
     with torch.no_grad():
-        z = encode(mc, pm, x, enc_noise.reshape(B * sample_size, mc.noise_dim), sample_size)   # [B,k,z]
+        if mc.kind == "auxmnist":      # enc_noise = (eps0 [B,k,noise_dim], eps [B,k,z]); ivae/auxmnist.py:306-326
+            noise = (enc_noise[0].reshape(B * sample_size, mc.noise_dim), enc_noise[1].reshape(B * sample_size, mc.z_dim))
+        else:
+            noise = enc_noise.reshape(B * sample_size, mc.noise_dim)
+        z = encode(mc, pm, x, noise, sample_size)   # [B,k,z]
         mu = z.mean(1)
         zc = z - mu.unsqueeze(1)
         cov = zc.transpose(1, 2) @ zc / (sample_size - 1)
+        if mc.kind == "auxmnist":
+            cov = cov + 1e-5 * torch.eye(mc.z_dim, dtype=cov.dtype)      # ivae/auxmnist.py:321
         Lc = torch.linalg.cholesky(cov)
         newz = mu.unsqueeze(1) + prop_noise @ Lc.transpose(1, 2)
         half_logdet = torch.log(torch.diagonal(Lc, dim1=1, dim2=2)).sum(1, keepdim=True)

@@ -262,7 +262,7 @@ def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0
 def run_iwae_case(net, name, mc, B, k, dtype):
     """models/ivae/mnist.py:378-437 with the per-image draws captured by replaying the seed."""
     pm = O.init_params(O.model_param_spec(mc), 7, O.model_init_special(mc), dtype)
-    cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=mc.z_dim, h_dim=32, n_layers=2)
+    cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=2 * mc.h_dim if mc.kind == "auxmnist" else mc.z_dim, h_dim=32, n_layers=2)
     pc = O.init_params(O.cdae_param_spec(cc), 8, None, dtype)
     model, _ = build_reference(net, mc, cc, pm, pc, dtype)
     x = synth_x(mc, B, 55).to(dtype)
@@ -271,14 +271,23 @@ def run_iwae_case(net, name, mc, B, k, dtype):
     with torch.no_grad():
         ref = model.logprob(x, sample_size=k)
     torch.manual_seed(99)
-    enc = torch.stack([torch.randn(k, mc.noise_dim) for _ in range(B)]).to(dtype)
+    if mc.kind == "auxmnist":   # ONE Encoder._forward(nz=k) call for all images (ivae/auxmnist.py:314), then the per-image proposals
+        e0 = torch.randn(B * k, mc.noise_dim)
+        e = torch.randn(B * k, 1, mc.z_dim)
+        torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * k, mc.z_dim, dtype=dtype)     # the two unused reparam samples
+        enc = (e0.to(dtype).reshape(B, k, -1), e.to(dtype).reshape(B, k, -1))
+    else:
+        enc = torch.stack([torch.randn(k, mc.noise_dim) for _ in range(B)]).to(dtype)
     # MultivariateNormal.rsample(torch.Size([1, k])) draws standard normals of shape [1, k, z]
     prop = torch.stack([torch.randn(1, k, mc.z_dim, dtype=dtype)[0] for _ in range(B)])
     mine = O.iwae_logprob(mc, pm, x, k, enc, prop)
     err = abs(float(mine) - float(ref)) / abs(float(ref))
     assert err < (1e-4 if dtype == torch.float32 else 1e-9), (float(mine), float(ref))
-    fx = {"x": x.numpy(), "enc_noise": enc.numpy(), "prop_noise": prop.numpy(), "logprob": ref.numpy(),
-          "meta_k": np.int64(k)}
+    fx = {"x": x.numpy(), "prop_noise": prop.numpy(), "logprob": ref.numpy(), "meta_k": np.int64(k)}
+    if mc.kind == "auxmnist":
+        fx["enc_noise"], fx["enc_noise_z"] = enc[0].numpy(), enc[1].numpy()
+    else:
+        fx["enc_noise"] = enc.numpy()
     for kk, v in pm.items():
         fx["pm/" + kk] = v.numpy()
     path = os.path.join(GOLDEN, name + ".npz")
@@ -326,6 +335,7 @@ def main():
     aux_t = O.TrainCfg(nz_cdae=8, ctx_type="hidden1a")
     run_case(net, rutils, "tiny_auxmnist_grad_f64", aux_m, aux_c, aux_t, B=4, steps=1, dtype=f64, store_full=True)
     run_case(net, rutils, "tiny_auxmnist_grad", aux_m, aux_c, aux_t, B=4, steps=2, dtype=f32, store_full=True)
+    run_iwae_case(net, "iwae_tiny_auxmnist", aux_m, B=3, k=16, dtype=f64)
 
 
 if __name__ == "__main__":

@@ -394,15 +394,21 @@ class ImplicitPosteriorVAE(FlatParamModule):
         """IWAE-k bound with a full-covariance Gaussian fitted to the encoder samples as proposal
         (logprob_w_cov_gaussian_posterior, ivae/mnist.py:378-437).  All images are processed at once: sampler and decoder
         are the HIP kernels, the k x z covariance / Cholesky / log-mean-exp glue is batched torch (off the timed path).
-        enc_noise [B, k, noise_dim] / prop_noise [B, k, z] inject the two draws."""
+        enc_noise [B, k, noise_dim] (aux models: the pair ([B, k, noise_dim], [B, k, z])) / prop_noise [B, k, z] inject the draws."""
         x = self._x(input)
         B, k, zd = x.size(0), sample_size, self.z_dim
         assert sample_size >= 2 * self.z_dim                 # ivae/mnist.py:382
         with torch.no_grad():
-            zs = self._sample(x, k, std, enc_noise.reshape(B * k, self.noise_dim) if enc_noise is not None else None)   # [B,k,z]
+            if isinstance(enc_noise, (tuple, list)):
+                enc_noise = tuple(n.reshape(B * k, -1) for n in enc_noise)
+            elif enc_noise is not None:
+                enc_noise = enc_noise.reshape(B * k, self._noise_width)
+            zs = self._sample(x, k, std, enc_noise)           # [B,k,z]
             mu = zs.mean(1)
             zc = zs - mu.unsqueeze(1)
             cov = zc.transpose(1, 2) @ zc / (k - 1)           # utils/stat.py:127-158
+            if self._kind == "auxmnist":
+                cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321
             try:
                 Lc = torch.linalg.cholesky(cov)
             except RuntimeError:                              # no device solver in this build: 32x32 factorisations on the host

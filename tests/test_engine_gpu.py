@@ -564,3 +564,21 @@ def test_aux_model_module_surface(golden_dir):
         assert rel_l2(p.grad.cpu(), preq[n].grad) < 2e-4, n
     with pytest.raises(NotImplementedError):
         net.MNISTAuxIPVAE(clip_z_logvar="spm4")
+
+
+def test_iwae_logprob_golden_aux(golden_dir):
+    """MNISTAuxIPVAE.logprob (ivae/auxmnist.py:300-356: the same IWAE-k bound, proposal covariance + 1e-5 I) against the reference's
+    value with injected draws."""
+    fx = dict(np.load(os.path.join(golden_dir, "iwae_tiny_auxmnist.npz")))
+    mc = O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus")
+    model, _ = build(mc, O.CdaeCfg("grad", 8, 96, 32, 2))
+    model.load_state_dict({n: torch.tensor(fx["pm/" + n]).float() for n, _ in O.model_param_spec(mc)})
+    model = model.to("cuda")
+    k = int(fx["meta_k"])
+    got = model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=k,
+                        enc_noise=(torch.tensor(fx["enc_noise"]).float().cuda(), torch.tensor(fx["enc_noise_z"]).float().cuda()),
+                        prop_noise=torch.tensor(fx["prop_noise"]).float().cuda())
+    ref = float(fx["logprob"])
+    assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
+    _, mean, z = model.generate(5)
+    assert mean.shape == (5, 24) and z.shape == (5, 8)
