@@ -127,9 +127,10 @@ class ArdaeEngine:
                                             L.ptr(noise) if noise is not None else None, x.size(0), nz, L.ptr(ws), ws.numel(),
                                             L.ptr(out), L.stream_ptr()), "ardae_model_encode")
 
-    def _hidden(self, x, out, ws):
+    def _hidden(self, x, z0_out, out, ws):
+        """The std = 0 pass of an aux sampler: latent mean z0 AND the hidden1a context in one go."""
         L.check(self.lib.ardae_model_encode_hidden(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), x.size(0),
-                                                   L.ptr(ws), ws.numel(), None, L.ptr(out), L.stream_ptr()), "ardae_model_encode_hidden")
+                                                   L.ptr(ws), ws.numel(), L.ptr(z0_out), L.ptr(out), L.stream_ptr()), "ardae_model_encode_hidden")
 
     def _allreduce_mean(self, t):
         dist.allreduce_mean_(t, self.pg)
@@ -173,7 +174,14 @@ class ArdaeEngine:
                     "ardae_model_encode_pair")
         # (opt-in, ARDAE_PAIR_SPLIT=1: under HIP-graph replay the extra mid-chain cross-stream edge cost 0.22 ms per step on
         # MI355X / ROCm 7.2, while eager launches gained 0.02 - so the default waits for the draws up front)
-        if drawn is not None and not noise and os.environ.get("ARDAE_PAIR_SPLIT", "0") == "1":
+        if self.hidden_ctx:
+            # aux models: hidden = model.encode.forward_hidden(x, std=0) and latent_mean = model.encode(x, std=0) are ONE std = 0 pass
+            # (ivae_ardae.py:737-739,748), then the N-row pass
+            if drawn is not None and not noise:
+                torch.cuda.current_stream().wait_event(drawn)
+            self._hidden(x, self.z0, self.ctx_c, self.ws_small)
+            self._encode(x, ns, nz, self.latent, self.ws)
+        elif drawn is not None and not noise and os.environ.get("ARDAE_PAIR_SPLIT", "0") == "1":
             pair(1)
             torch.cuda.current_stream().wait_event(drawn)
             pair(2)
@@ -183,8 +191,6 @@ class ArdaeEngine:
             pair(0)
         L.check(lib.ardae_latent_perturb(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, z, cfg.std_scale, cfg.delta,
                                          L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb")
-        if self.hidden_ctx:      # hidden = model.encode.forward_hidden(x, std=0) (ivae_ardae.py:737-739)
-            self._hidden(x, self.ctx_c, self.ws_small)
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
                                           L.ptr(self.sigma), L.ptr(eps), L.ptr(self.ctx_c), B, nz, L.ptr(self.ws), self.ws.numel(),
                                           L.ptr(self.loss_c), L.ptr(self.grads_c), None, st), "ardae_cdae_loss_grads")
@@ -203,9 +209,10 @@ class ArdaeEngine:
         L.check(lib.ardae_model_vae_forward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
                                             float(beta), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.zv), L.ptr(self.losses_m), st),
                 "ardae_model_vae_forward")
-        self._encode(x, None, 1, self.z0v, self.ws_small_v)
-        if self.hidden_ctx:      # ivae_ardae.py:815-817
-            self._hidden(x, self.ctx_v, self.ws_small_v)
+        if self.hidden_ctx:      # context and latent mean of the VAE batch: one std = 0 pass (ivae_ardae.py:815-817,826)
+            self._hidden(x, self.z0v, self.ctx_v, self.ws_small_v)
+        else:
+            self._encode(x, None, 1, self.z0v, self.ws_small_v)
         L.check(lib.ardae_center_scale(L.ptr(self.zv), L.ptr(self.z0v), B, nz, self.model.z_dim, cfg.std_scale, L.ptr(self.u), st))
         if self.split_backward:
             # model_loss.backward() through the decoder down to dL/dz (ivae_ardae.py:804) needs nothing from the cDAE either
