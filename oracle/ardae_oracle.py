@@ -139,6 +139,24 @@ def model_param_spec(c: ModelCfg):
         s += [("decode.reparam.logit_fn.weight", (c.input_dim, c.h_dim)),
               ("decode.reparam.logit_fn.bias", (c.input_dim,))]
         return s
+    if c.kind == "auxconv":
+        # models/ivae/auxconv.py:48-126 (AuxEncoder + Encoder of models/vae/auxconv.py:32-140: two conv trunks 1->16->32->32, k5 s2 p2) +
+        # models/vae/conv.py Decoder; 28x28x1 only; noise_dim = z0_dim, h_dim = 800 (the fc width)
+        def trunk(prefix, fc_in):
+            return [(prefix + "conv1.weight", (16, 1, 5, 5)), (prefix + "conv1.bias", (16,)),
+                    (prefix + "conv2.weight", (32, 16, 5, 5)), (prefix + "conv2.bias", (32,)),
+                    (prefix + "conv3.weight", (32, 32, 5, 5)), (prefix + "conv3.bias", (32,)),
+                    (prefix + "fc.weight", (800, fc_in)), (prefix + "fc.bias", (800,))]
+        def heads(prefix, out):
+            return [(prefix + "reparam.mean_fn.weight", (out, 800)), (prefix + "reparam.mean_fn.bias", (out,)),
+                    (prefix + "reparam.logvar_fn.weight", (out, 800)), (prefix + "reparam.logvar_fn.bias", (out,))]
+        s = trunk("encode.aux_encode.", 512) + heads("encode.aux_encode.", c.noise_dim)
+        s += trunk("encode.encode.", 512 + c.noise_dim) + heads("encode.encode.", c.z_dim)
+        s += _mlp_spec("decode.fc.", c.z_dim, 300, 512, 1)
+        s += [("decode.deconv1.weight", (32, 32, 5, 5)), ("decode.deconv1.bias", (32,)),
+              ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
+              ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
+        return s
     if c.kind == "toy":
         s = _mlp_spec("encode.inp_encode.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
         s += _ctxcat_mlp_spec("encode.fc.", c.h_dim, c.noise_dim, c.h_dim, c.z_dim, c.n_layers)
@@ -201,7 +219,7 @@ def model_init_special(c: ModelCfg):
     """Init overrides of the reference constructors."""
     sp = {}
     spec = model_param_spec(c)
-    if c.kind == "conv":   # self.apply(weight_init): xavier-uniform on every Conv2d/Linear (NOT ConvTranspose2d), zero biases
+    if c.kind in ("conv", "auxconv"):   # self.apply(weight_init): xavier-uniform on every Conv2d/Linear (NOT ConvTranspose2d), zero biases
         for name, shape in spec:
             if "deconv" in name or "logit_fn" in name:
                 continue
@@ -276,7 +294,7 @@ def encode(c: ModelCfg, p, x, noise, nz):
     elif c.kind == "toy":
         inp = mlp(p, "encode.inp_encode.", x, c.n_layers - 1, c.nonlin, True)
         z = ctxcat_mlp(p, "encode.fc.", expand_rows(inp, nz), noise, c.n_layers, c.nonlin)
-    elif c.kind == "auxmnist":
+    elif c.kind in ("auxmnist", "auxconv"):
         z = aux_encode(c, p, x, noise, nz)["z"]
     else:
         raise NotImplementedError
@@ -291,6 +309,24 @@ def aux_encode(c: ModelCfg, p, x, noise, nz):
     (--model-clip-z0-logvar / --model-clip-z-logvar are 'none' in the shipped recipes: the log-variances are the plain Linear outputs.)"""
     eps0, eps = noise
     B = x.size(0)
+    if c.kind == "auxconv":   # models/vae/auxconv.py:60-81,115-140: conv trunks in place of the MLPs, fc width 800
+        f = act(c.nonlin)
+        def trunk(prefix):
+            hh = (2 * x.reshape(B, 784) - 1).view(B, 1, 28, 28)
+            for i in (1, 2, 3):
+                hh = f(F.conv2d(hh, p[f"{prefix}conv{i}.weight"], p[f"{prefix}conv{i}.bias"], stride=2, padding=2))
+            return hh.reshape(B, -1)
+        def heads(prefix, hh):
+            return (F.linear(hh, p[prefix + "reparam.mean_fn.weight"], p[prefix + "reparam.mean_fn.bias"]),
+                    F.linear(hh, p[prefix + "reparam.logvar_fn.weight"], p[prefix + "reparam.logvar_fn.bias"]))
+        h0 = f(F.linear(trunk("encode.aux_encode."), p["encode.aux_encode.fc.weight"], p["encode.aux_encode.fc.bias"]))
+        mu0, lv0 = heads("encode.aux_encode.", h0)
+        z0 = expand_rows(mu0, nz) + torch.exp(0.5 * expand_rows(lv0, nz)) * eps0
+        h3 = trunk("encode.encode.")
+        h = f(F.linear(torch.cat([expand_rows(h3, nz), z0], 1), p["encode.encode.fc.weight"], p["encode.encode.fc.bias"]))
+        mu, lv = heads("encode.encode.", h)
+        z = mu + torch.exp(0.5 * lv) * eps
+        return {"z": z, "h0": h0, "h": h, "z0": z0, "mu0": mu0, "lv0": lv0, "mu": mu, "lv": lv}
     xs = 2 * x.reshape(B, c.input_dim) - 1
     h0 = mlp(p, "encode.aux_encode.main.", xs, c.n_layers - 1, c.nonlin, True)
     mu0 = F.linear(h0, p["encode.aux_encode.reparam.mean_fn.weight"], p["encode.aux_encode.reparam.mean_fn.bias"])
@@ -305,7 +341,7 @@ def aux_encode(c: ModelCfg, p, x, noise, nz):
 
 def zero_noise(c: ModelCfg, rows, like):
     """The draws of an encode(x, std=0) call, multiplied by 0."""
-    if c.kind == "auxmnist":
+    if c.kind in ("auxmnist", "auxconv"):
         return (like.new_zeros(rows, c.noise_dim), like.new_zeros(rows, c.z_dim))
     return like.new_zeros(rows, c.noise_dim)
 
@@ -316,7 +352,7 @@ def cdae_context(c: ModelCfg, tc, p, x):
     if tc.ctx_type == "lt0":
         return encode(c, p, x, zero_noise(c, B, x), 1).reshape(B, c.z_dim)
     if tc.ctx_type == "hidden1a":
-        assert c.kind == "auxmnist", "hidden1a is the aux models' context"
+        assert c.kind in ("auxmnist", "auxconv"), "hidden1a is the aux models' context"
         a = aux_encode(c, p, x, zero_noise(c, B, x), 1)
         return torch.cat([a["h0"], a["h"]], 1)
     raise NotImplementedError(tc.ctx_type)
@@ -327,7 +363,7 @@ def decode(c: ModelCfg, p, z):
     if c.kind in ("mnist", "auxmnist"):
         h = mlp(p, "decode.main.", z, c.n_layers if c.kind == "mnist" else c.n_layers - 1, c.nonlin, True)
         return (F.linear(h, p["decode.reparam.logit_fn.weight"], p["decode.reparam.logit_fn.bias"]),)
-    if c.kind == "conv":
+    if c.kind in ("conv", "auxconv"):
         f = act(c.nonlin)
         h = mlp(p, "decode.fc.", z, 1, c.nonlin, True).view(-1, 32, 4, 4)
         h = F.pad(f(F.conv_transpose2d(h, p["decode.deconv1.weight"], p["decode.deconv1.bias"], stride=2, padding=2)), (0, 1, 0, 1))
@@ -341,7 +377,7 @@ def decode(c: ModelCfg, p, z):
 
 
 def recon_rows(c: ModelCfg, dist, target):
-    if c.kind in ("mnist", "conv", "auxmnist"):
+    if c.kind in ("mnist", "conv", "auxmnist", "auxconv"):
         (logit,) = dist
         return F.binary_cross_entropy_with_logits(logit, target, reduction="none").sum(1)
     mu, logvar = dist
@@ -455,7 +491,7 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
     The std=0 encodes consume a draw that is multiplied by 0, so they are skipped here
     (they only advance the reference's RNG stream)."""
     N = B * tc.nz_cdae
-    aux = mc.kind == "auxmnist"       # a second draw per sampler call: eps of z = mu + exp(lv/2) eps (ivae/auxmnist.py:113-114)
+    aux = mc.kind in ("auxmnist", "auxconv")       # a second draw per sampler call: eps of z = mu + exp(lv/2) eps (ivae/auxmnist.py:113-114)
     n = {"sampler": torch.randn(N, mc.noise_dim, generator=gen)}          # forward_hidden
     if aux:
         n["sampler_z"] = torch.randn(N, mc.z_dim, generator=gen)
@@ -469,7 +505,7 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
 
 def sampler_noise(mc: ModelCfg, noise, which):
     """The sampler's draws out of a step's noise dict: which = "sampler" (cDAE phase) | "vae"."""
-    return (noise[which], noise[which + "_z"]) if mc.kind == "auxmnist" else noise[which]
+    return (noise[which], noise[which + "_z"]) if mc.kind in ("auxmnist", "auxconv") else noise[which]
 
 
 # --------------------------------------------------------------------------- #
@@ -539,7 +575,7 @@ def iwae_logprob(mc: ModelCfg, pm, x, sample_size, enc_noise, prop_noise):
     B = x.size(0)
     x = x.reshape(B, mc.input_dim)
     with torch.no_grad():
-        if mc.kind == "auxmnist":      # enc_noise = (eps0 [B,k,noise_dim], eps [B,k,z]); ivae/auxmnist.py:306-326
+        if mc.kind in ("auxmnist", "auxconv"):      # enc_noise = (eps0 [B,k,noise_dim], eps [B,k,z]); ivae/auxmnist.py:306-326
             noise = (enc_noise[0].reshape(B * sample_size, mc.noise_dim), enc_noise[1].reshape(B * sample_size, mc.z_dim))
         else:
             noise = enc_noise.reshape(B * sample_size, mc.noise_dim)
@@ -547,7 +583,7 @@ def iwae_logprob(mc: ModelCfg, pm, x, sample_size, enc_noise, prop_noise):
         mu = z.mean(1)
         zc = z - mu.unsqueeze(1)
         cov = zc.transpose(1, 2) @ zc / (sample_size - 1)
-        if mc.kind == "auxmnist":
+        if mc.kind in ("auxmnist", "auxconv"):
             cov = cov + 1e-5 * torch.eye(mc.z_dim, dtype=cov.dtype)      # ivae/auxmnist.py:321
         Lc = torch.linalg.cholesky(cov)
         newz = mu.unsqueeze(1) + prop_noise @ Lc.transpose(1, 2)

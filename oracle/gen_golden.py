@@ -63,6 +63,8 @@ def build_reference(net, mc, cc, pm, pc, dtype):
     elif mc.kind == "auxmnist":   # ivae_ardae.py:455-466 with --model-clip-z0-logvar / --model-clip-z-logvar none
         model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
                                   nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
+    elif mc.kind == "auxconv":   # ivae_ardae.py:467-478
+        model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
                                num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
@@ -135,7 +137,7 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
 def replay_noise(mc, tc, B_c, B_v, seed, dtype):
     """Re-draw, with the same seed and call sizes, what ref_step consumed (SURVEY 8 a-R)."""
     torch.manual_seed(seed)
-    if mc.kind == "auxmnist":
+    if mc.kind in ("auxmnist", "auxconv"):
         # one Encoder._forward call (ivae/auxmnist.py:110-116) draws eps0 [R, noise_dim] and eps [R, 1, z]; the two reparam modules
         # it runs then draw samples nobody uses (AuxEncoder.forward: randn_like [B, noise_dim], vae/auxmnist.py:66;
         # SimpleEncoder._forward_all: randn_like [R, z], :189)
@@ -169,7 +171,7 @@ def rel_l2(a, b):
 
 def synth_x(mc, B, seed):
     g = torch.Generator().manual_seed(seed)
-    if mc.kind in ("mnist", "conv", "auxmnist"):
+    if mc.kind in ("mnist", "conv", "auxmnist", "auxconv"):
         p = (torch.rand(mc.input_dim, generator=g) < 0.2).float() * 0.6 + 0.03
         return torch.bernoulli(p.expand(B, -1), generator=g)
     mu = (torch.randint(0, 5, (B, mc.input_dim), generator=g).float() - 2) * 2
@@ -336,6 +338,10 @@ def main():
     run_case(net, rutils, "tiny_auxmnist_grad_f64", aux_m, aux_c, aux_t, B=4, steps=1, dtype=f64, store_full=True)
     run_case(net, rutils, "tiny_auxmnist_grad", aux_m, aux_c, aux_t, B=4, steps=2, dtype=f32, store_full=True)
     run_iwae_case(net, "iwae_tiny_auxmnist", aux_m, B=3, k=16, dtype=f64)
+    # hierarchical conv model (--model auxconv, run_vae_dbmnist.sh "hierarchical conv"): oracle pin (its HIP path is not built yet)
+    auxc_m = O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus")
+    auxc_c = O.CdaeCfg("grad", 32, 1600, 64, 2)
+    run_case(net, rutils, "auxconv_b4_nz8", auxc_m, auxc_c, O.TrainCfg(nz_cdae=8, ctx_type="hidden1a"), B=4, steps=2, dtype=f32, store_full=False)
 
 
 if __name__ == "__main__":

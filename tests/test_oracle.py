@@ -53,6 +53,41 @@ def test_oracle_step_matches_reference_fixture(golden_dir, name):
         pm = {n: torch.tensor(fx[pre + "model_params_after/" + n]) for n, _ in O.model_param_spec(mc)}
 
 
+@pytest.mark.parametrize("name,mc,cc,ctx", [
+    ("conv_b4_nz8", O.ModelCfg("conv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 32, 64, 2), "lt0"),
+    # hierarchical conv model (--model auxconv): oracle pinned against the reference's MNISTConvAuxIPVAE; its HIP path is not built yet
+    ("auxconv_b4_nz8", O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 1600, 64, 2), "hidden1a"),
+])
+def test_oracle_step_matches_reference_summaries(golden_dir, name, mc, cc, ctx):
+    """Fixtures that hold summaries only (parameters regenerated from the seed): losses, latent statistics and the norm / sum /
+    first elements of every gradient of step 0."""
+    fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    tc = O.TrainCfg(nz_cdae=8, ctx_type=ctx)
+    ps = int(fx["meta_pseed"])
+    pm = O.init_params(O.model_param_spec(mc), ps, O.model_init_special(mc))
+    pc = O.init_params(O.cdae_param_spec(cc), ps + 1)
+    pre = "s0/"
+    noise = {k[len(pre + "noise/"):]: torch.tensor(v) for k, v in fx.items() if k.startswith(pre + "noise/")}
+    xc, xv = torch.tensor(fx[pre + "x_cdae"]), torch.tensor(fx[pre + "x_vae"])
+    closs, gc, std = O.cdae_update_grads(mc, cc, tc, pm, pc, xc, noise)
+    assert abs(float(closs) - float(fx[pre + "cdae_loss"])) / float(fx[pre + "cdae_loss"]) < 2e-4
+    assert rel_l2(std, torch.tensor(fx[pre + "std"])) < 2e-4
+    for n, _ in O.cdae_param_spec(cc):
+        if pre + "cdae_grads/" + n + "/none" in fx:
+            assert gc[n] is None
+        else:
+            assert abs(float(gc[n].double().norm()) - float(fx[pre + "cdae_grads/" + n + "/norm"])) <= 4e-3 * float(fx[pre + "cdae_grads/" + n + "/norm"]), n
+    st_c = {}
+    with torch.no_grad():
+        O.rmsprop_step(pc, gc, st_c, tc.d_lr, tc.d_momentum)
+    mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, tc, pm, pc, xv, noise)
+    assert abs(float(mloss) - float(fx[pre + "model_loss"])) / float(fx[pre + "model_loss"]) < 2e-4
+    assert abs(float(rec) - float(fx[pre + "recon"])) / float(fx[pre + "recon"]) < 2e-4
+    for n, _ in O.model_param_spec(mc):
+        ref = float(fx[pre + "model_grads/" + n + "/norm"])
+        assert abs(float(gm[n].double().norm()) - ref) <= 4e-3 * ref, n
+
+
 def test_oracle_optimizers_match_reference_fixture(golden_dir):
     mc, cc, nz, _ = CASES["tiny_mnist_grad"]
     fx = dict(np.load(os.path.join(golden_dir, "tiny_mnist_grad.npz")))
