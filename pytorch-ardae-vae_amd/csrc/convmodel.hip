@@ -225,19 +225,43 @@ int transpose_hw_c(const float* in, int Bn, int HW, int C, float* out, bool to_n
   return 0;
 }
 
+// conv trunk 1 -> 16 -> 32 -> 32 (k5 s2 p2, 28 -> 14 -> 7 -> 4) on the rescaled images x2 [B, 784]: fills cols / hcv and the
+// NCHW-flattened output inp [B, 512] (shared by ConvIPVAE and the two trunks of the hierarchical conv model)
+int trunk_fwd(const Lin* conv, const size_t* conv_f, const float* params, const float* packed, const float* x2, float* const* cols,
+              float* const* hcv, float* inp, int B, int act, hipStream_t st) {
+  const float* cur = x2;
+  for (int i = 0; i < 3; ++i) {                                                 // conv_i = im2col + Linear([O, C*25]) + act
+    const int OH = EH[i + 1], Kc = ECH[i] * 25;
+    ARDAE_TRY(im2col(cur, B, EH[i], EH[i], ECH[i], OH, OH, cols[i], st));
+    LinArgs A{}; A.bias = params + conv[i].b; A.Y = hcv[i]; A.ldY = ECH[i + 1];
+    ARDAE_TRY(lin1(EPI_ACT, act, B * OH * OH, ECH[i + 1], cols[i], Kc, Kc, packed + conv_f[i], A, st));
+    cur = hcv[i];
+  }
+  return transpose_hw_c(hcv[2], B, 16, 32, inp, true, st);                      // h3.view(B,-1) of NCHW
+}
+
+// backward of the trunk from d(inp) [B, 512] (NCHW-flat): dh3 / dh2 / dh1 = d(pre-activation) of conv3 / conv2 / conv1 (NHWC rows)
+int trunk_bwd(const size_t* conv_b, const float* packed, const float* dinp, float* dinp_t, float* const* hcv, float* dh3, float* dcols3,
+              float* dh2, float* dcols2, float* dh1, int B, int act, hipStream_t st) {
+  ARDAE_TRY(transpose_hw_c(dinp, B, 16, 32, dinp_t, false, st));               // NCHW-flat -> NHWC rows
+  {
+    const int64_t n = (int64_t)B * 512;
+    hipLaunchKernelGGL(mul_dact_kernel, dim3(nblk(n)), dim3(256), 0, st, dinp_t, hcv[2], act, dh3, n);
+    ARDAE_LAUNCH_CHECK();
+  }
+  { LinArgs A{}; A.Y = dcols3; A.ldY = 800;                                     // conv3 backward-data: dcols = dpre . W3
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B * 16, 800, dh3, 32, 32, packed + conv_b[2], A, st)); }
+  ARDAE_TRY(col2im(dcols3, B, 4, 4, 32, 7, 7, 7, 7, nullptr, act, hcv[1], dh2, st));
+  { LinArgs A{}; A.Y = dcols2; A.ldY = 400;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B * 49, 400, dh2, 32, 32, packed + conv_b[1], A, st)); }
+  return col2im(dcols2, B, 7, 7, 16, 14, 14, 14, 14, nullptr, act, hcv[0], dh1, st);
+}
+
 int conv_encode_fwd(const ConvLayout& P, const ConvPacked& K, const float* params, const float* packed, const float* x, const float* noise,
                     int B, int nz, ConvWs& W, float* z_out, hipStream_t st) {
   const int R = B * nz, act = P.act;
   ARDAE_TRY(launch_affine(x, (int64_t)B * 784, 2.f, -1.f, W.x2, st));           // ivae/conv.py:81
-  const float* cur = W.x2;
-  for (int i = 0; i < 3; ++i) {                                                 // conv_i = im2col + Linear([O, C*25]) + act
-    const int OH = EH[i + 1], Kc = ECH[i] * 25;
-    ARDAE_TRY(im2col(cur, B, EH[i], EH[i], ECH[i], OH, OH, W.cols[i], st));
-    LinArgs A{}; A.bias = params + P.conv[i].b; A.Y = W.hcv[i]; A.ldY = ECH[i + 1];
-    ARDAE_TRY(lin1(EPI_ACT, act, B * OH * OH, ECH[i + 1], W.cols[i], Kc, Kc, packed + K.conv_f[i], A, st));
-    cur = W.hcv[i];
-  }
-  ARDAE_TRY(transpose_hw_c(W.hcv[2], B, 16, 32, W.inp, true, st));              // h3.view(B,-1) of NCHW
+  ARDAE_TRY(trunk_fwd(P.conv, K.conv_f, params, packed, W.x2, W.cols, W.hcv, W.inp, B, act, st));
   {
     LinArgs A{}; A.bias = params + P.fc4.b; A.Y = W.rb; A.ldY = 800;            // image half of fc4, once per image
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 800, W.inp, 512, 512, packed + K.fc4i_f, A, st));
@@ -270,6 +294,38 @@ int conv_decode_fwd(const ConvLayout& P, const ConvPacked& K, const float* param
   { LinArgs A{}; A.Y = W.c3; A.ldY = 25; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R * 225, 25, W.u2, 16, 16, packed + K.dcv_f[2], A, st)); }
   ARDAE_TRY(col2im(W.c3, R, 15, 15, 1, 28, 28, 28, 28, params + P.dcv[2].b, ACT_NONE, nullptr, W.logit, st));
   return 0;
+}
+
+// decoder backward from W.dlogit (and W.dzq = prior + seed part of dL/dz): fills dc3/dp2/dc2/dp1/dc1/dg0/dd2/dd1 and W.dz
+int conv_decoder_bwd(const ConvLayout& P, const ConvPacked& K, const float* packed, ConvWs& W, int R, hipStream_t st) {
+  const int act = P.act;
+  {
+    const int64_t n = (int64_t)R * 784;
+    hipLaunchKernelGGL(fill_kernel, dim3(nblk(n)), dim3(256), 0, st, W.ones, 1.0f, n);
+    ARDAE_LAUNCH_CHECK();
+  }
+  // ---- decoder backward.  d(cols) of a transposed conv = im2col of the output gradient over the deconv's INPUT grid.
+  ARDAE_TRY(im2col(W.dlogit, R, 28, 28, 1, 15, 15, W.dc3, st));                 // cropped row/col 28 has no gradient
+  { LinArgs A{}; A.S = W.u2; A.ldS = 16; A.Y = W.dp2; A.ldY = 16;               // dpre2 = (dc3 . W3^T) (.) act'(u2)
+    ARDAE_TRY(lin1(EPI_DACT, act, R * 225, 16, W.dc3, 25, 25, packed + K.dcv_b[2], A, st)); }
+  ARDAE_TRY(im2col(W.dp2, R, 15, 15, 16, 8, 8, W.dc2, st));
+  { LinArgs A{}; A.S = W.u1; A.ldS = 32; A.Y = W.dp1; A.ldY = 32;               // zero at the padded positions: act'(0) = 0
+    ARDAE_TRY(lin1(EPI_DACT, act, R * 64, 32, W.dc2, 400, 400, packed + K.dcv_b[1], A, st)); }
+  ARDAE_TRY(im2col(W.dp1, R, 8, 8, 32, 4, 4, W.dc1, st));
+  { LinArgs A{}; A.S = W.g0; A.ldS = 32; A.Y = W.dg0; A.ldY = 32;               // g0 is the (permuted) activated output of decode.fc
+    ARDAE_TRY(lin1(EPI_DACT, act, R * 16, 32, W.dc1, 800, 800, packed + K.dcv_b[0], A, st)); }
+  ARDAE_TRY(transpose_hw_c(W.dg0, R, 16, 32, W.dd2, true, st));                 // -> d(pre) of decode.fc.fc  [R,512]
+  { LinArgs A{}; A.S = W.d1; A.ldS = 300; A.Y = W.dd1; A.ldY = 300;
+    ARDAE_TRY(lin1(EPI_DACT, act, R, 300, W.dd2, 512, 512, packed + K.dfc_b[1], A, st)); }
+  { LinArgs A{}; A.S = W.dzq; A.ldS = P.zd; A.Q = W.dzq; A.ldQ = P.zd; A.Y = W.dz; A.ldY = P.zd;   // + prior + injected seed
+    ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, R, P.zd, W.dd1, 300, 300, packed + K.dfc_b[0], A, st)); }
+  return 0;
+}
+
+// the decoder's eight weight-gradient problems (order == wgrad_scratch)
+template <class PUSH>
+void conv_decoder_wgrads(const ConvLayout& P, ConvWs& W, int R, float* grads, PUSH&& push) {
+  conv_decoder_wgrads(P, W, R, grads, push);
 }
 
 }  // namespace
@@ -363,44 +419,14 @@ int conv_model_vae_backward(const ardae_model_desc& d, const float* params, cons
   const float gscale = dloss / (float)R;
   ARDAE_TRY(launch_vae_loss(0, W.logit, nullptr, x, W.z, R, nz, 784, P.zd, beta, 1, gscale, dz_extra, W.rec_row, W.pri_row, W.dlogit, nullptr,
                             W.dzq, st));
-  {
-    const int64_t n = (int64_t)R * 784;
-    hipLaunchKernelGGL(fill_kernel, dim3(nblk(n)), dim3(256), 0, st, W.ones, 1.0f, n);
-    ARDAE_LAUNCH_CHECK();
-  }
-  // ---- decoder backward.  d(cols) of a transposed conv = im2col of the output gradient over the deconv's INPUT grid.
-  ARDAE_TRY(im2col(W.dlogit, R, 28, 28, 1, 15, 15, W.dc3, st));                 // cropped row/col 28 has no gradient
-  { LinArgs A{}; A.S = W.u2; A.ldS = 16; A.Y = W.dp2; A.ldY = 16;               // dpre2 = (dc3 . W3^T) (.) act'(u2)
-    ARDAE_TRY(lin1(EPI_DACT, act, R * 225, 16, W.dc3, 25, 25, packed + K.dcv_b[2], A, st)); }
-  ARDAE_TRY(im2col(W.dp2, R, 15, 15, 16, 8, 8, W.dc2, st));
-  { LinArgs A{}; A.S = W.u1; A.ldS = 32; A.Y = W.dp1; A.ldY = 32;               // zero at the padded positions: act'(0) = 0
-    ARDAE_TRY(lin1(EPI_DACT, act, R * 64, 32, W.dc2, 400, 400, packed + K.dcv_b[1], A, st)); }
-  ARDAE_TRY(im2col(W.dp1, R, 8, 8, 32, 4, 4, W.dc1, st));
-  { LinArgs A{}; A.S = W.g0; A.ldS = 32; A.Y = W.dg0; A.ldY = 32;               // g0 is the (permuted) activated output of decode.fc
-    ARDAE_TRY(lin1(EPI_DACT, act, R * 16, 32, W.dc1, 800, 800, packed + K.dcv_b[0], A, st)); }
-  ARDAE_TRY(transpose_hw_c(W.dg0, R, 16, 32, W.dd2, true, st));                 // -> d(pre) of decode.fc.fc  [R,512]
-  { LinArgs A{}; A.S = W.d1; A.ldS = 300; A.Y = W.dd1; A.ldY = 300;
-    ARDAE_TRY(lin1(EPI_DACT, act, R, 300, W.dd2, 512, 512, packed + K.dfc_b[1], A, st)); }
-  { LinArgs A{}; A.S = W.dzq; A.ldS = P.zd; A.Q = W.dzq; A.ldQ = P.zd; A.Y = W.dz; A.ldY = P.zd;   // + prior + injected seed
-    ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, R, P.zd, W.dd1, 300, 300, packed + K.dfc_b[0], A, st)); }
+  ARDAE_TRY(conv_decoder_bwd(P, K, packed, W, R, st));
   // ---- sampler backward
   { LinArgs A{}; A.S = W.t1; A.ldS = 800; A.Y = W.dt1; A.ldY = 800;
     ARDAE_TRY(lin1(EPI_DACT, act, R, 800, W.dz, P.zd, P.zd, packed + K.fc5_b, A, st)); }
   ARDAE_TRY(launch_segment_sum(W.dt1, 800, B, nz, 800, 1.0f, W.drb, 800, st));
   { LinArgs A{}; A.Y = W.dinp; A.ldY = 512;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 512, W.drb, 800, 800, packed + K.fc4i_b, A, st)); }
-  ARDAE_TRY(transpose_hw_c(W.dinp, B, 16, 32, W.dinp_t, false, st));           // NCHW-flat -> NHWC rows
-  {
-    const int64_t n = (int64_t)B * 512;
-    hipLaunchKernelGGL(mul_dact_kernel, dim3(nblk(n)), dim3(256), 0, st, W.dinp_t, W.hcv[2], act, W.dh3, n);
-    ARDAE_LAUNCH_CHECK();
-  }
-  { LinArgs A{}; A.Y = W.dcols3; A.ldY = 800;                                   // conv3 backward-data: dcols = dpre . W3
-    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B * 16, 800, W.dh3, 32, 32, packed + K.conv_b[2], A, st)); }
-  ARDAE_TRY(col2im(W.dcols3, B, 4, 4, 32, 7, 7, 7, 7, nullptr, act, W.hcv[1], W.dh2, st));
-  { LinArgs A{}; A.Y = W.dcols2; A.ldY = 400;
-    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B * 49, 400, W.dh2, 32, 32, packed + K.conv_b[1], A, st)); }
-  ARDAE_TRY(col2im(W.dcols2, B, 7, 7, 16, 14, 14, 14, 14, nullptr, act, W.hcv[0], W.dh1, st));
+  ARDAE_TRY(trunk_bwd(K.conv_b, packed, W.dinp, W.dinp_t, W.hcv, W.dh3, W.dcols3, W.dh2, W.dcols2, W.dh1, B, act, st));
   // ---- weight gradients (order must match wgrad_scratch)
   std::vector<int> splits;
   wgrad_scratch(P, B, R, &splits);
