@@ -18,4 +18,10 @@ int aux_model_vae_forward(const ardae_model_desc& d, const float* params, const 
 int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,
                            float beta, float dloss, const float* dz_extra, float* workspace, size_t wsf, float* grads, float grads_beta,
                            hipStream_t st);
+// the two reparameterisation steps shared with the hierarchical conv model (csrc/convmodel.hip)
+//   out[r][c] = mu[g][c] + exp(lv[g][c] / 2) * eps[r * ld_eps + c],  g = r / rows_per_group   (mu, lv: [rows / rpg, cols])
+int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int ld_eps, int64_t rows, int cols, int rows_per_group, float* out,
+                       hipStream_t st);
+//   dlv[r][c] = dz[r][c] * (z[r][c] - mu[g][c]) / 2
+int launch_reparam_bwd(const float* dz, const float* z, const float* mu, int64_t rows, int cols, int rows_per_group, float* dlv, hipStream_t st);
 }  // namespace ardae

@@ -172,6 +172,7 @@ int grid_of(int64_t n) {
   const int64_t g = (n + 255) / 256;
   return (int)(g < 4096 ? g : 4096);
 }
+}  // namespace
 int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int ld_eps, int64_t rows, int cols, int rpg, float* out, hipStream_t st) {
   ARDAE_TRY(flush_active_chain());
   hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, mu, lv, cols, eps, ld_eps, rows, cols, rpg, out);
@@ -185,6 +186,7 @@ int launch_reparam_bwd(const float* dz, const float* z, const float* mu, int64_t
   return 0;
 }
 
+namespace {
 int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
   a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
   a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;

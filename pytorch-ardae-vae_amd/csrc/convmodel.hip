@@ -9,6 +9,7 @@
 
 #include "ardae_hip.h"
 #include "common.h"
+#include "auxmodel.h"
 #include "convmodel.h"
 #include "elementwise.h"
 #include "linear.h"
@@ -102,6 +103,7 @@ struct ConvLayout {
   int nd, zd, act;
   Lin conv[3], fc4, fc5, dfc[2], dcv[3];
   size_t total;
+  ConvLayout() : nd(0), zd(0), act(0), total(0) {}     // decoder-only view filled by AuxConvLayout
   explicit ConvLayout(const ardae_model_desc& d) : nd(d.noise_dim), zd(d.z_dim), act(d.act) {
     size_t off = 0;
     auto add = [&](Lin& l, int out, int in, int nbias) { l.out = out; l.in = in; l.w = off; off += (size_t)out * in; l.b = off; off += nbias; };
@@ -117,6 +119,7 @@ size_t al64(size_t n) { return (n + 63) & ~size_t(63); }
 
 struct ConvPacked {
   size_t conv_f[3], conv_b[3], fc4i_f, fc4i_b, fc4n_f, fc5_f, fc5_b, dfc_f[2], dfc_b[2], dcv_f[3], dcv_b[3], total;
+  ConvPacked() : total(0) {}
   explicit ConvPacked(const ConvLayout& P) {
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += al64(n); return o; };
@@ -325,7 +328,15 @@ int conv_decoder_bwd(const ConvLayout& P, const ConvPacked& K, const float* pack
 // the decoder's eight weight-gradient problems (order == wgrad_scratch)
 template <class PUSH>
 void conv_decoder_wgrads(const ConvLayout& P, ConvWs& W, int R, float* grads, PUSH&& push) {
-  conv_decoder_wgrads(P, W, R, grads, push);
+  // ConvTranspose2d: dW[in][out*25] = sum_rows input[row][in] * dcols[row][out*25]; its bias = sum of the output gradient
+  push(R * 225, 16, 25, W.u2, W.dc3, grads + P.dcv[2].w, 25, nullptr);
+  push(R * 784, 1, 1, W.dlogit, W.ones, grads + P.dcv[2].b, 1, nullptr);
+  push(R * 64, 32, 400, W.u1, W.dc2, grads + P.dcv[1].w, 400, nullptr);
+  push(R * 225, 16, 1, W.dp2, W.ones, grads + P.dcv[1].b, 1, nullptr);
+  push(R * 16, 32, 800, W.g0, W.dc1, grads + P.dcv[0].w, 800, nullptr);
+  push(R * 64, 32, 1, W.dp1, W.ones, grads + P.dcv[0].b, 1, nullptr);
+  push(R, 512, 300, W.dd2, W.d1, grads + P.dfc[1].w, 300, grads + P.dfc[1].b);
+  push(R, 300, P.zd, W.dd1, W.z, grads + P.dfc[0].w, P.zd, grads + P.dfc[0].b);
 }
 
 }  // namespace
@@ -443,15 +454,7 @@ int conv_model_vae_backward(const ardae_model_desc& d, const float* params, cons
     p.out = out; p.ldout = ldout; p.out_bias = out_bias; p.beta = grads_beta;
     probs.push_back(p);
   };
-  // ConvTranspose2d: dW[in][out*25] = sum_rows input[row][in] * dcols[row][out*25]; its bias = sum of the output gradient
-  push(R * 225, 16, 25, W.u2, W.dc3, grads + P.dcv[2].w, 25, nullptr);
-  push(R * 784, 1, 1, W.dlogit, W.ones, grads + P.dcv[2].b, 1, nullptr);
-  push(R * 64, 32, 400, W.u1, W.dc2, grads + P.dcv[1].w, 400, nullptr);
-  push(R * 225, 16, 1, W.dp2, W.ones, grads + P.dcv[1].b, 1, nullptr);
-  push(R * 16, 32, 800, W.g0, W.dc1, grads + P.dcv[0].w, 800, nullptr);
-  push(R * 64, 32, 1, W.dp1, W.ones, grads + P.dcv[0].b, 1, nullptr);
-  push(R, 512, 300, W.dd2, W.d1, grads + P.dfc[1].w, 300, grads + P.dfc[1].b);
-  push(R, 300, P.zd, W.dd1, W.z, grads + P.dfc[0].w, P.zd, grads + P.dfc[0].b);
+  conv_decoder_wgrads(P, W, R, grads, push);
   push(R, P.zd, 800, W.dz, W.t1, grads + P.fc5.w, 800, grads + P.fc5.b);
   push(R, 800, P.nd, W.dt1, noise, grads + P.fc4.w + 512, 512 + P.nd, grads + P.fc4.b);
   push(B, 800, 512, W.drb, W.inp, grads + P.fc4.w, 512 + P.nd, nullptr);
@@ -460,6 +463,305 @@ int conv_model_vae_backward(const ardae_model_desc& d, const float* params, cons
   push(B * 196, 16, 25, W.dh1, W.cols[0], grads + P.conv[0].w, 25, grads + P.conv[0].b);
   ARDAE_CHECK_ARG(ws.ok, "conv_model_vae_backward: workspace too small");
   return launch_wgrad_batch(probs.data(), (int)probs.size(), st);
+}
+
+
+// =====================================================================================================================
+// MNISTConvAuxIPVAE (`--model auxconv`, kind == 4): models/ivae/auxconv.py:48-126 - the hierarchical sampler of csrc/auxmodel.hip with
+// conv trunks in place of the MLPs (models/vae/auxconv.py:32-140) and ConvIPVAE's decoder (models/vae/conv.py:79-136):
+//   per image:   h3a = trunk_a(2x-1); h4a = act(Fa h3a + fa); mu0 = M0 h4a + m0; lv0 = L0 h4a + l0;  h3 = trunk_e(2x-1); rb = Fi h3 + f
+//   per sample:  z0 = mu0[b] + exp(lv0[b]/2) eps0;  h4 = act(Fn z0 + rb[b]);  mu = M h4 + m; lv = L h4 + l;  z = mu + exp(lv/2) eps
+// Noise layout as for kind 3: one [R, noise_dim + z_dim] tensor per sampler call.  hidden1a context = cat(h4a, h4) [B, 1600].
+// =====================================================================================================================
+namespace {
+
+struct AuxConvLayout {
+  int nd, zd, act;
+  Lin aconv[3], afc, mean0, logvar0, econv[3], efc, mean, logvar;
+  ConvLayout dec;      // dfc / dcv only
+  size_t total;
+  explicit AuxConvLayout(const ardae_model_desc& d) : nd(d.noise_dim), zd(d.z_dim), act(d.act) {
+    size_t off = 0;
+    auto add = [&](Lin& l, int out, int in, int nbias) { l.out = out; l.in = in; l.w = off; off += (size_t)out * in; l.b = off; off += nbias; };
+    add(aconv[0], 16, 25, 16); add(aconv[1], 32, 400, 32); add(aconv[2], 32, 800, 32);
+    add(afc, 800, 512, 800); add(mean0, nd, 800, nd); add(logvar0, nd, 800, nd);
+    add(econv[0], 16, 25, 16); add(econv[1], 32, 400, 32); add(econv[2], 32, 800, 32);
+    add(efc, 800, 512 + nd, 800); add(mean, zd, 800, zd); add(logvar, zd, 800, zd);
+    dec.nd = nd; dec.zd = zd; dec.act = act;
+    add(dec.dfc[0], 300, zd, 300); add(dec.dfc[1], 512, 300, 512);
+    add(dec.dcv[0], 32, 32 * 25, 32); add(dec.dcv[1], 32, 16 * 25, 16); add(dec.dcv[2], 16, 25, 1);
+    total = off;
+  }
+};
+
+struct AuxConvPacked {
+  size_t aconv_f[3], aconv_b[3], afc_f, afc_b, mean0_f, mean0_b, logvar0_f, logvar0_b, econv_f[3], econv_b[3], efci_f, efci_b, efcn_f, efcn_b,
+      mean_f, mean_b, logvar_f, logvar_b, total;
+  ConvPacked dec;
+  explicit AuxConvPacked(const AuxConvLayout& P) {
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += al64(n); return o; };
+    for (int i = 0; i < 3; ++i) { aconv_f[i] = take(packed_floats(P.aconv[i].out, P.aconv[i].in)); aconv_b[i] = take(packed_floats(P.aconv[i].in, P.aconv[i].out)); }
+    afc_f = take(packed_floats(800, 512)); afc_b = take(packed_floats(512, 800));
+    mean0_f = take(packed_floats(P.nd, 800)); mean0_b = take(packed_floats(800, P.nd));
+    logvar0_f = take(packed_floats(P.nd, 800)); logvar0_b = take(packed_floats(800, P.nd));
+    for (int i = 0; i < 3; ++i) { econv_f[i] = take(packed_floats(P.econv[i].out, P.econv[i].in)); econv_b[i] = take(packed_floats(P.econv[i].in, P.econv[i].out)); }
+    efci_f = take(packed_floats(800, 512)); efci_b = take(packed_floats(512, 800));
+    efcn_f = take(packed_floats(800, P.nd)); efcn_b = take(packed_floats(P.nd, 800));
+    mean_f = take(packed_floats(P.zd, 800)); mean_b = take(packed_floats(800, P.zd));
+    logvar_f = take(packed_floats(P.zd, 800)); logvar_b = take(packed_floats(800, P.zd));
+    for (int i = 0; i < 2; ++i) { dec.dfc_f[i] = take(packed_floats(P.dec.dfc[i].out, P.dec.dfc[i].in)); dec.dfc_b[i] = take(packed_floats(P.dec.dfc[i].in, P.dec.dfc[i].out)); }
+    for (int i = 0; i < 3; ++i) { dec.dcv_f[i] = take(packed_floats(P.dec.dcv[i].in, P.dec.dcv[i].out)); dec.dcv_b[i] = take(packed_floats(P.dec.dcv[i].out, P.dec.dcv[i].in)); }
+    total = off;
+  }
+};
+
+struct AuxConvWs {
+  ConvWs D;    // x2, decoder buffers, z, t1 (= h4), dzq / dz, ones, rec_row / pri_row and the decoder's backward buffers
+  float *acols[3], *ahcv[3], *ainp, *h4a, *mu0, *lv0, *z0, *ecols[3], *ehcv[3], *einp, *rb, *mu, *lv, *zero;
+  // backward
+  float *dlv, *dt1, *dz0, *dlv0r, *drb, *dmu0, *dlv0, *dh4a, *dinp_a, *dinp_e, *dinp_t;
+  float *dh3[2], *dcols3[2], *dh2[2], *dcols2[2], *dh1[2];    // [0] = aux trunk, [1] = encoder trunk
+};
+
+void aux_carve(const AuxConvLayout& P, Bump& ws, int B, int nz, int mode, AuxConvWs& W) {
+  const size_t R = (size_t)B * nz;
+  ConvWs& D = W.D;
+  D.x2 = ws.take((size_t)B * 784);
+  for (int i = 0; i < 3; ++i) {
+    W.acols[i] = ws.take((size_t)B * EH[i + 1] * EH[i + 1] * ECH[i] * 25); W.ahcv[i] = ws.take((size_t)B * EH[i + 1] * EH[i + 1] * ECH[i + 1]);
+    W.ecols[i] = ws.take((size_t)B * EH[i + 1] * EH[i + 1] * ECH[i] * 25); W.ehcv[i] = ws.take((size_t)B * EH[i + 1] * EH[i + 1] * ECH[i + 1]);
+  }
+  W.ainp = ws.take((size_t)B * 512); W.h4a = ws.take((size_t)B * 800); W.mu0 = ws.take((size_t)B * P.nd); W.lv0 = ws.take((size_t)B * P.nd);
+  W.einp = ws.take((size_t)B * 512); W.rb = ws.take((size_t)B * 800);
+  W.z0 = ws.take(R * P.nd); D.t1 = ws.take(R * 800); W.mu = ws.take(R * P.zd); W.lv = ws.take(R * P.zd); D.z = ws.take(R * P.zd);
+  W.zero = ws.take(R * (P.nd + P.zd));
+  if (mode == 0) return;
+  D.d1 = ws.take(R * 300); D.d2 = ws.take(R * 512); D.g0 = ws.take(R * 512);
+  D.c1 = ws.take(R * 16 * 800); D.u1 = ws.take(R * 64 * 32);
+  D.c2 = ws.take(R * 64 * 400); D.u2 = ws.take(R * 225 * 16);
+  D.c3 = ws.take(R * 225 * 25); D.logit = ws.take(R * 784);
+  D.rec_row = ws.take(R); D.pri_row = ws.take(R);
+  if (mode == 2) return;
+  D.dlogit = ws.take(R * 784); D.dc3 = ws.take(R * 225 * 25); D.dp2 = ws.take(R * 225 * 16);
+  D.dc2 = ws.take(R * 64 * 400); D.dp1 = ws.take(R * 64 * 32); D.dc1 = ws.take(R * 16 * 800);
+  D.dg0 = ws.take(R * 512); D.dd2 = ws.take(R * 512); D.dd1 = ws.take(R * 300);
+  D.dzq = ws.take(R * P.zd); D.dz = ws.take(R * P.zd); D.ones = ws.take(R * 784);
+  W.dlv = ws.take(R * P.zd); W.dt1 = ws.take(R * 800); W.dz0 = ws.take(R * P.nd); W.dlv0r = ws.take(R * P.nd);
+  W.drb = ws.take((size_t)B * 800); W.dmu0 = ws.take((size_t)B * P.nd); W.dlv0 = ws.take((size_t)B * P.nd); W.dh4a = ws.take((size_t)B * 800);
+  W.dinp_a = ws.take((size_t)B * 512); W.dinp_e = ws.take((size_t)B * 512); W.dinp_t = ws.take((size_t)B * 512);
+  for (int k = 0; k < 2; ++k) {
+    W.dh3[k] = ws.take((size_t)B * 512); W.dcols3[k] = ws.take((size_t)B * 16 * 800); W.dh2[k] = ws.take((size_t)B * 49 * 32);
+    W.dcols2[k] = ws.take((size_t)B * 49 * 400); W.dh1[k] = ws.take((size_t)B * 196 * 16);
+  }
+}
+
+constexpr int AUX_N_WGRAD = 21;   // 8 decoder + 13 sampler problems, launched as two batches (20 per batch at most)
+
+size_t aux_wgrad_scratch(const AuxConvLayout& P, int B, int R, std::vector<int>* out) {
+  std::vector<int> sp; size_t tot = 0;
+  auto one = [&](int M, int O, int I) { const int s = wgrad_splits(M, O, I, AUX_N_WGRAD / 2); sp.push_back(s); tot += al64((size_t)s * O * I) + al64((size_t)s * 2 * O); };
+  one(R * 225, 16, 25); one(R * 784, 1, 1); one(R * 64, 32, 400); one(R * 225, 16, 1); one(R * 16, 32, 800); one(R * 64, 32, 1);
+  one(R, 512, 300); one(R, 300, P.zd);                                              // decoder (as ConvIPVAE)
+  one(R, P.zd, 800); one(R, P.zd, 800); one(R, 800, P.nd); one(B, 800, 512);       // mean, logvar, fc z0 half (+bias), fc image half
+  one(B * 16, 32, 800); one(B * 49, 32, 400); one(B * 196, 16, 25);                // encoder trunk
+  one(B, P.nd, 800); one(B, P.nd, 800); one(B, 800, 512);                          // mean0, logvar0, aux fc
+  one(B * 16, 32, 800); one(B * 49, 32, 400); one(B * 196, 16, 25);                // aux trunk
+  if (out) *out = sp;
+  return tot;
+}
+
+size_t aux_workspace(const AuxConvLayout& P, int B, int nz, int mode) {
+  Bump b(nullptr, ~size_t(0));
+  AuxConvWs W;
+  aux_carve(P, b, B, nz, mode, W);
+  size_t t = b.off;
+  if (mode == 1) t += aux_wgrad_scratch(P, B, B * nz, nullptr);
+  return t;
+}
+
+int aux_sampler_fwd(const AuxConvLayout& P, const AuxConvPacked& K, const float* params, const float* packed, const float* x, const float* noise,
+                    int B, int nz, AuxConvWs& W, hipStream_t st) {
+  const int R = B * nz, act = P.act, ldn = P.nd + P.zd;
+  ARDAE_TRY(launch_affine(x, (int64_t)B * 784, 2.f, -1.f, W.D.x2, st));
+  ARDAE_TRY(trunk_fwd(P.aconv, K.aconv_f, params, packed, W.D.x2, W.acols, W.ahcv, W.ainp, B, act, st));
+  { LinArgs A{}; A.bias = params + P.afc.b; A.Y = W.h4a; A.ldY = 800;
+    ARDAE_TRY(lin1(EPI_ACT, act, B, 800, W.ainp, 512, 512, packed + K.afc_f, A, st)); }
+  { LinArgs A{}; A.bias = params + P.mean0.b; A.Y = W.mu0; A.ldY = P.nd;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.nd, W.h4a, 800, 800, packed + K.mean0_f, A, st)); }
+  { LinArgs A{}; A.bias = params + P.logvar0.b; A.Y = W.lv0; A.ldY = P.nd;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.nd, W.h4a, 800, 800, packed + K.logvar0_f, A, st)); }
+  ARDAE_TRY(launch_reparam_fwd(W.mu0, W.lv0, noise, ldn, R, P.nd, nz, W.z0, st));
+  ARDAE_TRY(trunk_fwd(P.econv, K.econv_f, params, packed, W.D.x2, W.ecols, W.ehcv, W.einp, B, act, st));
+  { LinArgs A{}; A.bias = params + P.efc.b; A.Y = W.rb; A.ldY = 800;               // image half of the encoder's fc, once per image
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 800, W.einp, 512, 512, packed + K.efci_f, A, st)); }
+  { LinArgs A{}; A.rowbias = W.rb; A.rowbias_ld = 800; A.rows_per_group = nz; A.Y = W.D.t1; A.ldY = 800;
+    ARDAE_TRY(lin1(EPI_ACT, act, R, 800, W.z0, P.nd, P.nd, packed + K.efcn_f, A, st)); }
+  { LinArgs A{}; A.bias = params + P.mean.b; A.Y = W.mu; A.ldY = P.zd;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.D.t1, 800, 800, packed + K.mean_f, A, st)); }
+  { LinArgs A{}; A.bias = params + P.logvar.b; A.Y = W.lv; A.ldY = P.zd;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.D.t1, 800, 800, packed + K.logvar_f, A, st)); }
+  return launch_reparam_fwd(W.mu, W.lv, noise + P.nd, ldn, R, P.zd, 1, W.D.z, st);
+}
+
+}  // namespace
+
+size_t auxconv_model_param_floats(const ardae_model_desc& d) { return AuxConvLayout(d).total; }
+size_t auxconv_model_packed_floats(const ardae_model_desc& d) { return AuxConvPacked(AuxConvLayout(d)).total; }
+size_t auxconv_model_workspace_floats(const ardae_model_desc& d, int B, int nz, int mode) { return aux_workspace(AuxConvLayout(d), B, nz, mode == 3 ? 0 : mode); }
+
+int auxconv_model_pack(const ardae_model_desc& d, const float* params, float* packed, hipStream_t st) {
+  std::vector<PackItem> pack_items__;
+  const AuxConvLayout P(d);
+  const AuxConvPacked K(P);
+  auto both = [&](const Lin& l, size_t f, size_t b) {
+    PACK_PUSH(params + l.w, l.in, l.out, l.in, false, packed + f);
+    PACK_PUSH(params + l.w, l.in, l.in, l.out, true, packed + b);
+  };
+  for (int i = 0; i < 3; ++i) { both(P.aconv[i], K.aconv_f[i], K.aconv_b[i]); both(P.econv[i], K.econv_f[i], K.econv_b[i]); }
+  both(P.afc, K.afc_f, K.afc_b); both(P.mean0, K.mean0_f, K.mean0_b); both(P.logvar0, K.logvar0_f, K.logvar0_b);
+  const int lde = 512 + P.nd;
+  PACK_PUSH(params + P.efc.w, lde, 800, 512, false, packed + K.efci_f);
+  PACK_PUSH(params + P.efc.w, lde, 512, 800, true, packed + K.efci_b);
+  PACK_PUSH(params + P.efc.w + 512, lde, 800, P.nd, false, packed + K.efcn_f);
+  PACK_PUSH(params + P.efc.w + 512, lde, P.nd, 800, true, packed + K.efcn_b);
+  both(P.mean, K.mean_f, K.mean_b); both(P.logvar, K.logvar_f, K.logvar_b);
+  for (int i = 0; i < 2; ++i) both(P.dec.dfc[i], K.dec.dfc_f[i], K.dec.dfc_b[i]);
+  for (int i = 0; i < 3; ++i) {   // ConvTranspose2d weight [in, out*25] (see conv_model_pack)
+    PACK_PUSH(params + P.dec.dcv[i].w, P.dec.dcv[i].in, P.dec.dcv[i].in, P.dec.dcv[i].out, true, packed + K.dec.dcv_f[i]);
+    PACK_PUSH(params + P.dec.dcv[i].w, P.dec.dcv[i].in, P.dec.dcv[i].out, P.dec.dcv[i].in, false, packed + K.dec.dcv_b[i]);
+  }
+  PACK_FLUSH(st);
+  return 0;
+}
+
+int auxconv_model_encode(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,
+                         float* workspace, size_t wsf, float* z_out, float* hidden_out, hipStream_t st) {
+  const AuxConvLayout P(d);
+  const AuxConvPacked K(P);
+  Bump ws(workspace, wsf);
+  AuxConvWs W;
+  aux_carve(P, ws, B, nz, 0, W);
+  ARDAE_CHECK_ARG(ws.ok, "auxconv_model_encode: workspace too small");
+  const float* nptr = noise;
+  if (!noise) {
+    ARDAE_HIP(hipMemsetAsync(W.zero, 0, (size_t)B * nz * (P.nd + P.zd) * sizeof(float), st));
+    nptr = W.zero;
+  }
+  ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, nptr, B, nz, W, st));
+  if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.D.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (hidden_out) {
+    ARDAE_CHECK_ARG(nz == 1, "auxconv_model_encode: the hidden context is defined for nz == 1");
+    ARDAE_HIP(hipMemcpy2DAsync(hidden_out, 1600 * sizeof(float), W.h4a, 800 * sizeof(float), 800 * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+    ARDAE_HIP(hipMemcpy2DAsync(hidden_out + 800, 1600 * sizeof(float), W.D.t1, 800 * sizeof(float), 800 * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+int auxconv_model_decode(const ardae_model_desc& d, const float* params, const float* packed, const float* z, int R, float* workspace, size_t wsf,
+                         float* out0, hipStream_t st) {
+  const AuxConvLayout P(d);
+  const AuxConvPacked K(P);
+  Bump ws(workspace, wsf);
+  AuxConvWs W;
+  aux_carve(P, ws, R, 1, 2, W);
+  ARDAE_CHECK_ARG(ws.ok, "auxconv_model_decode: workspace too small");
+  ARDAE_TRY(conv_decode_fwd(P.dec, K.dec, params, packed, z, R, W.D, st));
+  ARDAE_HIP(hipMemcpyAsync(out0, W.D.logit, (size_t)R * 784 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int auxconv_model_vae_forward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B,
+                              int nz, float beta, float* workspace, size_t wsf, float* z_out, float* losses, hipStream_t st) {
+  const AuxConvLayout P(d);
+  const AuxConvPacked K(P);
+  Bump ws(workspace, wsf);
+  AuxConvWs W;
+  aux_carve(P, ws, B, nz, 1, W);
+  ARDAE_CHECK_ARG(ws.ok, "auxconv_model_vae_forward: workspace too small");
+  const int R = B * nz;
+  ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, noise, B, nz, W, st));
+  ARDAE_HIP(hipMemcpyAsync(z_out, W.D.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  ARDAE_TRY(conv_decode_fwd(P.dec, K.dec, params, packed, W.D.z, R, W.D, st));
+  ARDAE_TRY(launch_vae_loss(0, W.D.logit, nullptr, x, W.D.z, R, nz, 784, P.zd, beta, 0, 0.f, nullptr, W.D.rec_row, W.D.pri_row, nullptr, nullptr, nullptr, st));
+  return launch_vae_loss_finalize(W.D.rec_row, W.D.pri_row, R, beta, losses, st);
+}
+
+int auxconv_model_vae_backward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B,
+                               int nz, float beta, float dloss, const float* dz_extra, float* workspace, size_t wsf, float* grads,
+                               float grads_beta, hipStream_t st) {
+  (void)noise;
+  const AuxConvLayout P(d);
+  const AuxConvPacked K(P);
+  Bump ws(workspace, wsf);
+  AuxConvWs W;
+  aux_carve(P, ws, B, nz, 1, W);
+  ConvWs& D = W.D;
+  const int R = B * nz, act = P.act;
+  const float gscale = dloss / (float)R;
+  ARDAE_TRY(launch_vae_loss(0, D.logit, nullptr, x, D.z, R, nz, 784, P.zd, beta, 1, gscale, dz_extra, D.rec_row, D.pri_row, D.dlogit, nullptr, D.dzq, st));
+  ARDAE_TRY(conv_decoder_bwd(P.dec, K.dec, packed, D, R, st));
+  // second reparameterisation and the encoder's fc
+  ARDAE_TRY(launch_reparam_bwd(D.dz, D.z, W.mu, R, P.zd, 1, W.dlv, st));
+  {
+    LinArgs A{}; A.M = R; A.Nout = 800; A.nsrc = 2; A.act = act; A.S = D.t1; A.ldS = 800; A.Y = W.dt1; A.ldY = 800;
+    A.src[0].x = D.dz; A.src[0].ld = P.zd; A.src[0].K = P.zd; A.src[0].wp = packed + K.mean_b;
+    A.src[1].x = W.dlv; A.src[1].ld = P.zd; A.src[1].K = P.zd; A.src[1].wp = packed + K.logvar_b;
+    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
+  }
+  { LinArgs A{}; A.Y = W.dz0; A.ldY = P.nd;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.nd, W.dt1, 800, 800, packed + K.efcn_b, A, st)); }
+  ARDAE_TRY(launch_segment_sum(W.dt1, 800, B, nz, 800, 1.0f, W.drb, 800, st));
+  { LinArgs A{}; A.Y = W.dinp_e; A.ldY = 512;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 512, W.drb, 800, 800, packed + K.efci_b, A, st)); }
+  ARDAE_TRY(trunk_bwd(K.econv_b, packed, W.dinp_e, W.dinp_t, W.ehcv, W.dh3[1], W.dcols3[1], W.dh2[1], W.dcols2[1], W.dh1[1], B, act, st));
+  // first reparameterisation, reduced over the nz samples of each image, and the aux encoder
+  ARDAE_TRY(launch_reparam_bwd(W.dz0, W.z0, W.mu0, R, P.nd, nz, W.dlv0r, st));
+  ARDAE_TRY(launch_segment_sum(W.dz0, P.nd, B, nz, P.nd, 1.0f, W.dmu0, P.nd, st));
+  ARDAE_TRY(launch_segment_sum(W.dlv0r, P.nd, B, nz, P.nd, 1.0f, W.dlv0, P.nd, st));
+  {
+    LinArgs A{}; A.M = B; A.Nout = 800; A.nsrc = 2; A.act = act; A.S = W.h4a; A.ldS = 800; A.Y = W.dh4a; A.ldY = 800;
+    A.src[0].x = W.dmu0; A.src[0].ld = P.nd; A.src[0].K = P.nd; A.src[0].wp = packed + K.mean0_b;
+    A.src[1].x = W.dlv0; A.src[1].ld = P.nd; A.src[1].K = P.nd; A.src[1].wp = packed + K.logvar0_b;
+    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
+  }
+  { LinArgs A{}; A.Y = W.dinp_a; A.ldY = 512;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 512, W.dh4a, 800, 800, packed + K.afc_b, A, st)); }
+  ARDAE_TRY(trunk_bwd(K.aconv_b, packed, W.dinp_a, W.dinp_t, W.ahcv, W.dh3[0], W.dcols3[0], W.dh2[0], W.dcols2[0], W.dh1[0], B, act, st));
+  // ---- weight gradients: 8 decoder + 14 sampler problems in two batches (order == aux_wgrad_scratch)
+  std::vector<int> splits;
+  aux_wgrad_scratch(P, B, R, &splits);
+  std::vector<WgradProblem> probs;
+  auto push = [&](int M, int O, int I, const float* G, const float* X, float* out, int ldout, float* out_bias) {
+    WgradProblem p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.O = O; p.I = I; p.npairs = 1;
+    p.G[0] = G; p.ldG[0] = O; p.X[0] = X; p.ldX[0] = I;
+    p.bias_pair = out_bias ? 0 : -1;
+    p.splits = splits[probs.size()];
+    p.partial = ws.take((size_t)p.splits * O * I);
+    p.partial_vec = ws.take((size_t)p.splits * 2 * O);
+    p.out = out; p.ldout = ldout; p.out_bias = out_bias; p.beta = grads_beta;
+    probs.push_back(p);
+  };
+  conv_decoder_wgrads(P.dec, D, R, grads, push);
+  push(R, P.zd, 800, D.dz, D.t1, grads + P.mean.w, 800, grads + P.mean.b);
+  push(R, P.zd, 800, W.dlv, D.t1, grads + P.logvar.w, 800, grads + P.logvar.b);
+  push(R, 800, P.nd, W.dt1, W.z0, grads + P.efc.w + 512, 512 + P.nd, grads + P.efc.b);
+  push(B, 800, 512, W.drb, W.einp, grads + P.efc.w, 512 + P.nd, nullptr);
+  push(B * 16, 32, 800, W.dh3[1], W.ecols[2], grads + P.econv[2].w, 800, grads + P.econv[2].b);
+  push(B * 49, 32, 400, W.dh2[1], W.ecols[1], grads + P.econv[1].w, 400, grads + P.econv[1].b);
+  push(B * 196, 16, 25, W.dh1[1], W.ecols[0], grads + P.econv[0].w, 25, grads + P.econv[0].b);
+  push(B, P.nd, 800, W.dmu0, W.h4a, grads + P.mean0.w, 800, grads + P.mean0.b);
+  push(B, P.nd, 800, W.dlv0, W.h4a, grads + P.logvar0.w, 800, grads + P.logvar0.b);
+  push(B, 800, 512, W.dh4a, W.ainp, grads + P.afc.w, 512, grads + P.afc.b);
+  push(B * 16, 32, 800, W.dh3[0], W.acols[2], grads + P.aconv[2].w, 800, grads + P.aconv[2].b);
+  push(B * 49, 32, 400, W.dh2[0], W.acols[1], grads + P.aconv[1].w, 400, grads + P.aconv[1].b);
+  push(B * 196, 16, 25, W.dh1[0], W.acols[0], grads + P.aconv[0].w, 25, grads + P.aconv[0].b);
+  ARDAE_CHECK_ARG(ws.ok, "auxconv_model_vae_backward: workspace too small (%zu floats needed so far, %zu given, %zu problems)", ws.off, wsf, probs.size());
+  ARDAE_CHECK_ARG((int)probs.size() == AUX_N_WGRAD, "auxconv_model_vae_backward: internal problem count");
+  ARDAE_TRY(launch_wgrad_batch(probs.data(), AUX_N_WGRAD / 2, st));
+  return launch_wgrad_batch(probs.data() + AUX_N_WGRAD / 2, AUX_N_WGRAD - AUX_N_WGRAD / 2, st);
 }
 
 }  // namespace ardae

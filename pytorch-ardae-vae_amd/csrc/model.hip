@@ -89,8 +89,9 @@ struct Bump {
 
 int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d != nullptr, "model: desc is NULL");
-  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 3, "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE) or 3 (MNISTAuxIPVAE)");
-  if (d->kind == 2) {
+  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 4,
+                  "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE), 3 (MNISTAuxIPVAE) or 4 (MNISTConvAuxIPVAE)");
+  if (d->kind == 2 || d->kind == 4) {
     ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1, "model: ConvIPVAE is hard-wired to 28x28x1 inputs (input_dim 784)");
     ARDAE_CHECK_ARG(d->act == ACT_SOFTPLUS || d->act == ACT_RELU, "model: activation must be softplus or relu");
     return 0;
@@ -248,16 +249,19 @@ extern "C" {
 
 size_t ardae_model_param_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
+  if (d->kind == 4) return auxconv_model_param_floats(*d);
   if (d->kind == 3) return aux_model_param_floats(*d);
   return d->kind == 2 ? conv_model_param_floats(*d) : ModelLayout(*d).total;
 }
 size_t ardae_model_packed_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
+  if (d->kind == 4) return auxconv_model_packed_floats(*d);
   if (d->kind == 3) return aux_model_packed_floats(*d);
   return d->kind == 2 ? conv_model_packed_floats(*d) : ModelPacked(ModelLayout(*d)).total;
 }
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
   if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
+  if (d->kind == 4) return auxconv_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 3) return aux_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 2) return conv_model_workspace_floats(*d, B, nz, mode == 3 ? 0 : mode);
   const ModelLayout P(*d);
@@ -271,6 +275,7 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
   ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
+  if (d->kind == 4) return auxconv_model_pack(*d, params, packed, st);
   if (d->kind == 3) return aux_model_pack(*d, params, packed, st);
   if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
   std::vector<PackItem> pack_items__;
@@ -318,6 +323,7 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
     ARDAE_TRY(aux_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st));
     return chain_scope.finish();
   }
+  if (d->kind == 4) return auxconv_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st);
   if (d->kind == 2) return conv_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
@@ -344,7 +350,7 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
   ARDAE_CHECK_ARG(params && packed && x && (noise || phase == 1) && workspace && z0_out && z_out, "model_encode_pair: null pointer argument");
   ARDAE_CHECK_ARG(B > 0 && nz > 0 && (int64_t)B * nz < (int64_t)1 << 30, "model_encode_pair: bad batch (B=%d nz=%d)", B, nz);
   ARDAE_CHECK_ARG(workspace_floats_ >= ardae_model_workspace_floats(d, B, nz, 3), "model_encode_pair: workspace too small");
-  if (d->kind == 2 || d->kind == 3) {   // conv / aux samplers: two passes over the same workspace
+  if (d->kind >= 2) {   // conv / aux samplers: two passes over the same workspace
     if (phase != 2) ARDAE_TRY(ardae_model_encode(d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, stream));
     if (phase == 1) return 0;
     return ardae_model_encode(d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, stream);
@@ -372,11 +378,12 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
 int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B, float* workspace,
                               size_t workspace_floats_, float* z0_out, float* hidden_out, void* stream) {
   ARDAE_TRY(model_common(d, params, packed, x, B, 1, workspace, workspace_floats_, 0));
-  ARDAE_CHECK_ARG(d->kind == 3, "model_encode_hidden: the hidden1a context exists for the aux models only (kind 3)");
+  ARDAE_CHECK_ARG(d->kind == 3 || d->kind == 4, "model_encode_hidden: the hidden1a context exists for the aux models only (kinds 3, 4)");
   ARDAE_CHECK_ARG(hidden_out, "model_encode_hidden: hidden_out is NULL");
   hipStream_t st = (hipStream_t)stream;
   ChainScope chain_scope(st);
-  ARDAE_TRY(aux_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
+  if (d->kind == 4) ARDAE_TRY(auxconv_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
+  else ARDAE_TRY(aux_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
   return chain_scope.finish();
 }
 
@@ -387,6 +394,10 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
   if (d->kind == 2) {
     ARDAE_CHECK_ARG(workspace_floats_ >= conv_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
     return conv_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
+  }
+  if (d->kind == 4) {
+    ARDAE_CHECK_ARG(workspace_floats_ >= auxconv_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
+    return auxconv_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
   }
   if (d->kind == 3) {
     ARDAE_CHECK_ARG(workspace_floats_ >= aux_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
@@ -434,6 +445,7 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
     ARDAE_TRY(aux_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st));
     return chain_scope.finish();
   }
+  if (d->kind == 4) return auxconv_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
   if (d->kind == 2) return conv_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
@@ -551,6 +563,10 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   if (d->kind == 2) {
     ChainScope chain_scope(st);
     return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
+  }
+  if (d->kind == 4) {
+    ChainScope chain_scope(st);
+    return auxconv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
   if (d->kind == 3) {
     ChainScope chain_scope(st);

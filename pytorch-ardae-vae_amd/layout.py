@@ -47,6 +47,21 @@ def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers):
               ("encode.encode.reparam.logvar_fn.weight", (z_dim, h_dim)), ("encode.encode.reparam.logvar_fn.bias", (z_dim,))]
         s += _mlp("decode.main.", z_dim, h_dim, h_dim, n_layers - 1)
         s += [("decode.reparam.logit_fn.weight", (input_dim, h_dim)), ("decode.reparam.logit_fn.bias", (input_dim,))]
+    elif kind == "auxconv":    # models/ivae/auxconv.py:48-126 (AuxEncoder + Encoder of models/vae/auxconv.py) + models/vae/conv.py Decoder
+        def trunk(prefix, fc_in):
+            return [(prefix + "conv1.weight", (16, 1, 5, 5)), (prefix + "conv1.bias", (16,)),
+                    (prefix + "conv2.weight", (32, 16, 5, 5)), (prefix + "conv2.bias", (32,)),
+                    (prefix + "conv3.weight", (32, 32, 5, 5)), (prefix + "conv3.bias", (32,)),
+                    (prefix + "fc.weight", (800, fc_in)), (prefix + "fc.bias", (800,))]
+        def heads(prefix, out):
+            return [(prefix + "reparam.mean_fn.weight", (out, 800)), (prefix + "reparam.mean_fn.bias", (out,)),
+                    (prefix + "reparam.logvar_fn.weight", (out, 800)), (prefix + "reparam.logvar_fn.bias", (out,))]
+        s = trunk("encode.aux_encode.", 512) + heads("encode.aux_encode.", noise_dim)
+        s += trunk("encode.encode.", 512 + noise_dim) + heads("encode.encode.", z_dim)
+        s += _mlp("decode.fc.", z_dim, 300, 512, 1)
+        s += [("decode.deconv1.weight", (32, 32, 5, 5)), ("decode.deconv1.bias", (32,)),
+              ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
+              ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
     else:
         raise NotImplementedError(kind)
     return s

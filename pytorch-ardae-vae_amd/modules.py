@@ -268,10 +268,10 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self.input_dim, self.noise_dim, self.h_dim, self.z_dim = input_dim, noise_dim, h_dim, z_dim
         self.latent_dim = z_dim
         self.nonlinearity, self.num_hidden_layers, self.init, self.enc_type = nonlinearity, num_hidden_layers, init, enc_type
-        self._desc = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3}[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers,
+        self._desc = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4}[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers,
                                  L.ACT[nonlinearity])
         # floats per row of a sampler draw: the aux models take two draws per call, laid out side by side [eps0 | eps]
-        self._noise_width = noise_dim + z_dim if self._kind == "auxmnist" else noise_dim
+        self._noise_width = noise_dim + z_dim if self._kind in ("auxmnist", "auxconv") else noise_dim
         self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers), {"encode": _EncodeBox})
         object.__setattr__(self.encode, "_owner_ref", weakref.ref(self))   # `model.encode(x, std=0)` (ivae_ardae.py:735)
         self.reset_parameters()
@@ -285,7 +285,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
                     for t in p.values():
                         nn.init.xavier_uniform_(t) if t.dim() == 2 else t.zero_()
                 return
-            if self._kind == "conv":                      # self.apply(weight_init): xavier-uniform on Conv2d / Linear, zero biases;
+            if self._kind in ("conv", "auxconv"):         # self.apply(weight_init): xavier-uniform on Conv2d / Linear, zero biases;
                 if self.do_xavier:                        # ConvTranspose2d keeps torch's default init (vae/auxconv.py:18-23)
                     for name, t in p.items():
                         if "deconv" in name or "logit_fn" in name:
@@ -345,7 +345,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
 
     def _hidden(self, input):
         """cat(h0, h) [B, 2 h] of the std = 0 pass (aux models; the `hidden1a` cDAE context)."""
-        if self._kind != "auxmnist":
+        if self._kind not in ("auxmnist", "auxconv"):
             raise NotImplementedError("hidden contexts exist for the aux models only")
         x = self._x(input)
         B, lib = x.size(0), L.lib()
@@ -407,8 +407,8 @@ class ImplicitPosteriorVAE(FlatParamModule):
             mu = zs.mean(1)
             zc = zs - mu.unsqueeze(1)
             cov = zc.transpose(1, 2) @ zc / (k - 1)           # utils/stat.py:127-158
-            if self._kind == "auxmnist":
-                cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321
+            if self._kind in ("auxmnist", "auxconv"):
+                cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321, ivae/auxconv.py
             try:
                 Lc = torch.linalg.cholesky(cov)
             except RuntimeError:                              # no device solver in this build: 32x32 factorisations on the host
@@ -461,6 +461,19 @@ class MNISTAuxIPVAE(ImplicitPosteriorVAE):
             raise NotImplementedError                     # ivae/auxmnist.py:72-73
         self.do_xavier, self.clip_z0_logvar, self.clip_z_logvar = do_xavier, None, None
         super().__init__(energy_func, input_dim, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, "none", enc_type)
+
+
+class MNISTConvAuxIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/auxconv.py::ImplicitPosteriorVAE (`--model auxconv`, the shipped "hierarchical conv" recipe): the hierarchical
+    sampler with two conv trunks and ConvIPVAE's decoder; 28x28x1 only; the hidden1a context is [B, 1600]."""
+    _kind = "auxconv"
+
+    def __init__(self, energy_func=normal_energy_func, input_height=28, input_channels=1, z0_dim=100, h_dim=300, z_dim=32,
+                 nonlinearity="softplus", do_xavier=True):
+        if input_height != 28 or input_channels != 1:
+            raise NotImplementedError("MNISTConvAuxIPVAE: the reference decoder (models/vae/conv.py:79-136) is hard-wired to 28x28x1")
+        self.input_height, self.input_channels, self.z0_dim, self.do_xavier = input_height, input_channels, z0_dim, do_xavier
+        super().__init__(energy_func, 784, z0_dim, 800, z_dim, nonlinearity, 1, "none", "concat")
 
 
 class ToyIPVAE(ImplicitPosteriorVAE):

@@ -39,11 +39,11 @@ def test_abi_version_and_error_channel():
 
 
 @pytest.mark.parametrize("kind,args", [("mnist", (784, 100, 256, 32, 2)), ("toy", (2, 10, 256, 2, 2)), ("mnist", (24, 10, 64, 8, 2)),
-                                       ("conv", (784, 100, 800, 32, 1)), ("auxmnist", (784, 100, 300, 32, 2)), ("auxmnist", (24, 10, 48, 8, 3))])
+                                       ("conv", (784, 100, 800, 32, 1)), ("auxmnist", (784, 100, 300, 32, 2)), ("auxmnist", (24, 10, 48, 8, 3)), ("auxconv", (784, 100, 800, 32, 1))])
 def test_model_layout_matches_c_side(kind, args):
     spec = layout.model_spec(kind, *args)
     _, total = layout.offsets(spec)
-    d = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3}[kind], *args, 2)
+    d = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4}[kind], *args, 2)
     assert L.lib().ardae_model_param_floats(ctypes.byref(d)) == total
     assert L.lib().ardae_model_packed_floats(ctypes.byref(d)) > total
     assert L.lib().ardae_model_workspace_floats(ctypes.byref(d), 8, 16, 1) > 0

@@ -23,11 +23,15 @@ CASES = {
     "conv_b4_nz8": (O.ModelCfg("conv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 32, 64, 2), 8, False),   # cfg #4 model
     # the shipped "hierarchical mlp" recipe's model family: aux sampler + hidden1a context (run_vae_dbmnist.sh --model auxmnist)
     "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, True),
+    # the shipped "hierarchical conv" recipe's model family (run_vae_dbmnist.sh --model auxconv, hidden1a context of 1600 columns)
+    "auxconv_b4_nz8": (O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 1600, 64, 2), 8, False),
 }
 
 
 def build(mc, cc):
-    if mc.kind == "auxmnist":
+    if mc.kind == "auxconv":
+        model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
+    elif mc.kind == "auxmnist":
         model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
                                   nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
     elif mc.kind == "conv":
@@ -83,7 +87,7 @@ def noise_of(fx, t, dev):
 
 
 def train_config(mc, nz, **kw):
-    return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a" if mc.kind == "auxmnist" else "lt0", **kw)
+    return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a" if mc.kind in ("auxmnist", "auxconv") else "lt0", **kw)
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -582,3 +586,34 @@ def test_iwae_logprob_golden_aux(golden_dir):
     assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
     _, mean, z = model.generate(5)
     assert mean.shape == (5, 24) and z.shape == (5, 8)
+
+
+def test_auxconv_vae_phase_grads_vs_oracle(golden_dir):
+    """MNISTConvAuxIPVAE (the shipped "hierarchical conv" recipe's model): every conv / fc / reparameterisation-head / transposed-conv
+    gradient of the VAE phase, the hidden1a context and the sampler against the oracle (itself pinned to the reference's
+    MNISTConvAuxIPVAE at 2e-6) on the fixture's inputs."""
+    mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, "auxconv_b4_nz8")
+    model, cdae = build(mc, cc)
+    assert [k for k in model.state_dict()] == [n for n, _ in O.model_param_spec(mc)]
+    model.load_state_dict(pm); cdae.load_state_dict(pc)
+    model, cdae = model.to("cuda"), cdae.to("cuda")
+    B = int(fx["meta_B"])
+    tc = O.TrainCfg(nz_cdae=nz, ctx_type="hidden1a")
+    eng = net.ArdaeEngine(model, cdae, train_config(mc, nz), batch_size=B)
+    noise = noise_of(fx, 0, "cuda")
+    xv = torch.tensor(fx["s0/x_vae"])
+    hid = model.encode.forward_hidden(xv.cuda(), std=0)
+    assert hid.shape == (B, 1600) and rel_l2(hid, O.cdae_context(mc, tc, pm, xv)) < 1e-5
+    eng.vae_phase(xv.cuda(), noise=noise, apply_update=False)
+    cpu_noise = {k[len("s0/noise/"):]: torch.tensor(v) for k, v in fx.items() if k.startswith("s0/noise/")}
+    mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, tc, pm, pc, xv, cpu_noise)
+    s = eng.stats()
+    assert rel(s["model_loss"], mloss) < 1e-4 and rel(s["recon"], rec) < 2e-5 and rel(s["prior"], pri) < 2e-5
+    off = 0
+    for n, shp in O.model_param_spec(mc):
+        k = int(np.prod(shp))
+        assert rel_l2(eng.grads_m[off:off + k].cpu(), gm[n].reshape(-1)) < 2e-3, n
+        off += k
+    z = torch.randn(6, mc.z_dim)
+    (logit,) = model.decode_params(z.cuda())
+    assert rel_l2(logit, O.decode(mc, pm, z)[0]) < 1e-5
