@@ -175,7 +175,10 @@ int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float*
  *   kind 3 (MNISTAuxIPVAE, models/ivae/auxmnist.py): encode.aux_encode.{main.*, reparam.{mean_fn, logvar_fn}},
  *                        encode.encode.{fc.*, reparam.{mean_fn, logvar_fn}}, decode.main.*, decode.reparam.logit_fn.  Its sampler takes TWO
  *                        draws per call: every `noise` argument of this kind is ONE [rows, noise_dim + z_dim] tensor, row = [eps0 | eps]
- *                        (z0 = mu0 + exp(lv0/2) eps0,  z = mu + exp(lv/2) eps) */
+ *                        (z0 = mu0 + exp(lv0/2) eps0,  z = mu + exp(lv/2) eps)
+ *   kind 4 (MNISTConvAuxIPVAE, models/ivae/auxconv.py): the same hierarchical sampler with two conv trunks
+ *                        (encode.aux_encode.{conv1-3, fc, reparam.*}, encode.encode.{conv1-3, fc, reparam.*}) and ConvIPVAE's decoder;
+ *                        noise_dim = z0_dim, h_dim = 800 (the fc width), 28 x 28 x 1 only; same noise layout as kind 3 */
 typedef struct ardae_model_desc {
   int kind;
   int input_dim, noise_dim, h_dim, z_dim;
@@ -205,7 +208,7 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
 int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, const float* packed, const float* x,
                             const float* noise, int B, int nz, float beta, float* workspace, size_t workspace_floats,
                             float* z_out, float* losses, void* stream);
-/* Aux models (kind 3): the std = 0 pass of the sampler, returning the latent mean z0 [B, z] (may be NULL) AND the encoder hiddens
+/* Aux models (kinds 3 and 4): the std = 0 pass of the sampler, returning the latent mean z0 [B, z] (may be NULL) AND the encoder hiddens
  * cat(h0, h) [B, 2 h] that --cdae-ctx-type hidden1a uses as the cDAE context (ivae_ardae.py:737-739, ivae/auxmnist.py:125-132).
  * Workspace: mode 0 with nz = 1. */
 int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B,

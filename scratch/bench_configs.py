@@ -39,6 +39,11 @@ def cfg(i):
         c = net.MLPGradCARDAE(input_dim=32, context_dim=600, std=1., h_dim=256, num_hidden_layers=5, nonlinearity="softplus",
                               noise_type="gaussian", enc_ctx=True, enc_input=True)
         return m, c, 128, 625, lambda B, dev: (torch.rand(B, 784, device=dev) < 0.13).float(), dict(z=32, h=256, L=5, kind="grad", ctx="hidden1a")
+    if i == 8:   # the shipped "hierarchical conv" recipe (run_vae_dbmnist.sh: --model auxconv, hidden1a context of 1600 columns, nz_cdae 625, L 5)
+        m = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=100, z_dim=32, nonlinearity="softplus")
+        c = net.MLPGradCARDAE(input_dim=32, context_dim=1600, std=1., h_dim=256, num_hidden_layers=5, nonlinearity="softplus",
+                              noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 128, 625, lambda B, dev: (torch.rand(B, 1, 28, 28, device=dev) < 0.13).float(), dict(z=32, h=256, L=5, kind="grad", ctx="hidden1a")
     raise SystemExit(f"no config {i}")
 
 def cdae_flops(B, nz, z, h, L, kind):
