@@ -261,10 +261,10 @@ def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0
           f"({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
-def run_iwae_case(net, name, mc, B, k, dtype):
+def run_iwae_case(net, name, mc, B, k, dtype, store_params=True):
     """models/ivae/mnist.py:378-437 with the per-image draws captured by replaying the seed."""
     pm = O.init_params(O.model_param_spec(mc), 7, O.model_init_special(mc), dtype)
-    cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=2 * mc.h_dim if mc.kind == "auxmnist" else mc.z_dim, h_dim=32, n_layers=2)
+    cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=2 * mc.h_dim if mc.kind in ("auxmnist", "auxconv") else mc.z_dim, h_dim=32, n_layers=2)
     pc = O.init_params(O.cdae_param_spec(cc), 8, None, dtype)
     model, _ = build_reference(net, mc, cc, pm, pc, dtype)
     x = synth_x(mc, B, 55).to(dtype)
@@ -273,7 +273,7 @@ def run_iwae_case(net, name, mc, B, k, dtype):
     with torch.no_grad():
         ref = model.logprob(x, sample_size=k)
     torch.manual_seed(99)
-    if mc.kind == "auxmnist":   # ONE Encoder._forward(nz=k) call for all images (ivae/auxmnist.py:314), then the per-image proposals
+    if mc.kind in ("auxmnist", "auxconv"):   # ONE Encoder._forward(nz=k) call for all images (ivae/auxmnist.py:314), then the per-image proposals
         e0 = torch.randn(B * k, mc.noise_dim)
         e = torch.randn(B * k, 1, mc.z_dim)
         torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * k, mc.z_dim, dtype=dtype)     # the two unused reparam samples
@@ -286,12 +286,15 @@ def run_iwae_case(net, name, mc, B, k, dtype):
     err = abs(float(mine) - float(ref)) / abs(float(ref))
     assert err < (1e-4 if dtype == torch.float32 else 1e-9), (float(mine), float(ref))
     fx = {"x": x.numpy(), "prop_noise": prop.numpy(), "logprob": ref.numpy(), "meta_k": np.int64(k)}
-    if mc.kind == "auxmnist":
+    if mc.kind in ("auxmnist", "auxconv"):
         fx["enc_noise"], fx["enc_noise_z"] = enc[0].numpy(), enc[1].numpy()
     else:
         fx["enc_noise"] = enc.numpy()
-    for kk, v in pm.items():
-        fx["pm/" + kk] = v.numpy()
+    if store_params:
+        for kk, v in pm.items():
+            fx["pm/" + kk] = v.numpy()
+    else:
+        fx["meta_pseed"] = np.int64(7)       # parameters: O.init_params(spec, 7, special) (large model: regenerated, not stored)
     path = os.path.join(GOLDEN, name + ".npz")
     np.savez_compressed(path, **fx)
     print(f"[golden] {name}: IWAE-{k} ref {float(ref):.6f} oracle {float(mine):.6f} rel err {err:.2e}")
@@ -342,6 +345,7 @@ def main():
     auxc_m = O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus")
     auxc_c = O.CdaeCfg("grad", 32, 1600, 64, 2)
     run_case(net, rutils, "auxconv_b4_nz8", auxc_m, auxc_c, O.TrainCfg(nz_cdae=8, ctx_type="hidden1a"), B=4, steps=2, dtype=f32, store_full=False)
+    run_iwae_case(net, "iwae_auxconv", auxc_m, B=2, k=64, dtype=f64, store_params=False)
 
 
 if __name__ == "__main__":

@@ -617,3 +617,19 @@ def test_auxconv_vae_phase_grads_vs_oracle(golden_dir):
     z = torch.randn(6, mc.z_dim)
     (logit,) = model.decode_params(z.cuda())
     assert rel_l2(logit, O.decode(mc, pm, z)[0]) < 1e-5
+
+
+def test_iwae_logprob_golden_auxconv(golden_dir):
+    """MNISTConvAuxIPVAE.logprob (ivae/auxconv.py:289-350) against the reference's value with injected draws."""
+    fx = dict(np.load(os.path.join(golden_dir, "iwae_auxconv.npz")))
+    mc = O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus")
+    pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc))
+    model, _ = build(mc, O.CdaeCfg("grad", 32, 1600, 32, 2))
+    model.load_state_dict(pm)
+    model = model.to("cuda")
+    k = int(fx["meta_k"])
+    got = model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=k,
+                        enc_noise=(torch.tensor(fx["enc_noise"]).float().cuda(), torch.tensor(fx["enc_noise_z"]).float().cuda()),
+                        prop_noise=torch.tensor(fx["prop_noise"]).float().cuda())
+    ref = float(fx["logprob"])
+    assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32

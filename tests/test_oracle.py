@@ -126,6 +126,15 @@ def test_oracle_iwae_matches_reference_fixture_aux(golden_dir):
     assert abs(float(got) - float(fx["logprob"])) / abs(float(fx["logprob"])) < 1e-9
 
 
+def test_oracle_iwae_matches_reference_fixture_auxconv(golden_dir):
+    fx = dict(np.load(os.path.join(golden_dir, "iwae_auxconv.npz")))
+    mc = O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus")
+    pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc), torch.float64)
+    got = O.iwae_logprob(mc, pm, torch.tensor(fx["x"]), int(fx["meta_k"]), (torch.tensor(fx["enc_noise"]), torch.tensor(fx["enc_noise_z"])),
+                         torch.tensor(fx["prop_noise"]))
+    assert abs(float(got) - float(fx["logprob"])) / abs(float(fx["logprob"])) < 1e-9
+
+
 def test_closed_form_known_answer_one_layer_score():
     """Analytic score of a 1-layer softplus energy (known-answer test): with L=1 the cDAE is
     E = w . sp(W1a sp(A1 x + b1) + ...), whose input-gradient is checked against autograd in float64."""
