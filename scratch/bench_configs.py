@@ -60,7 +60,7 @@ for i in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5]:
     m, c = m.to(dev), c.to(dev)
     eng = net.ArdaeEngine(m, c, net.TrainConfig(nz_cdae=nz, cdae_ctx_type=shp.pop("ctx", "lt0")), batch_size=B)
     x1, x2 = data(B, dev), data(B, dev)
-    steps = 20 if i < 4 else 5
+    steps = int(os.environ.get("CFG_STEPS", "20" if i < 4 else "5"))
     for _ in range(3):
         eng.step(x1, x2)
     torch.cuda.synchronize()
