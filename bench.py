@@ -42,8 +42,9 @@ def algorithmic_flops_per_step(B, nz, z=32, h=256, L=3, D=784, nd=100):
     return cdae + sampler + 2 * B * 3 * F_vae
 
 
-def cpu_baseline(steps=2, warm=1):
-    """The oracle (a restatement of the reference's op sequence, pinned against it) on this box's host cores."""
+def cpu_baseline(steps=5, warm=2):
+    """The oracle (a restatement of the reference's op sequence, pinned against it) on this box's host cores.
+    Protocol of BASELINE.md section 3: 2 warm-up steps, then 5 timed steps, median."""
     from oracle import ardae_oracle as O
     # a one-GPU box grants 16 host cores (the driver's CPU share); more threads than that only oversubscribe
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
@@ -63,10 +64,59 @@ def cpu_baseline(steps=2, warm=1):
         t0 = time.perf_counter()
         O.train_step(mc, cc, tc, pm, pc, st_m, st_c, xc, xv, noise)
         times.append(time.perf_counter() - t0)
-    dt = sum(times[warm:]) / steps
+    timed = sorted(times[warm:])
+    dt = timed[len(timed) // 2]
     return {"value": 1.0 / dt, "unit": "train-steps/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} full steps (B=512, nz_cdae=256) after {warm} warm-up, oracle/ardae_oracle.py (PyTorch CPU autograd)",
-            "s_per_step": dt}
+            "sample": f"median of {steps} full steps (B=512, nz_cdae=256) after {warm} warm-up, oracle/ardae_oracle.py (PyTorch CPU autograd)",
+            "s_per_step": dt, "s_per_step_all": [round(t, 3) for t in times[warm:]]}
+
+
+def kernel_family(name):
+    """Template instantiations of one kernel are ONE family: `linear_wide_kernel<8, 4, 2, 2, 0, 0>` -> `linear_wide_kernel`."""
+    return name.split("<", 1)[0].strip()
+
+
+def roofline_of(rep, prof_steps):
+    """The `roofline` object of the bench line, from the live HIP-event log of the instrumented steps.
+
+    The dominant kernel is the kernel FAMILY (template arguments stripped) with the largest share of the step; `achieved`
+    is that family's algorithmic FLOPs / its summed launch durations.  The time-weighted figure over every MFMA kernel
+    family and the single best instantiation are reported beside it, so the headline cannot be one well-tuned kernel that
+    is a small share of the step."""
+    fam = {}
+    for e in rep:
+        f = fam.setdefault(kernel_family(e["name"]), {"name": kernel_family(e["name"]), "calls": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for k in ("calls", "total_ms", "flops", "bytes"):
+            f[k] += e[k]
+    fams = sorted(fam.values(), key=lambda e: -e["total_ms"])
+    top = fams[0]
+    tf = lambda e: e["flops"] / (e["total_ms"] * 1e-3) / 1e12 if e["total_ms"] > 0 else 0.0
+    ach = tf(top)
+    tot_ms = sum(e["total_ms"] for e in fams)
+    tot_fl = sum(e["flops"] for e in fams)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (a STORED profile value, not measured in this run)
+        with open(pmc) as f:
+            doc = json.load(f)
+        per = [(doc[n]["hbm_bytes_per_launch"], e["calls"]) for e in rep for n in [e["name"]]
+               if kernel_family(n) == top["name"] and n in doc and doc[n].get("hbm_bytes_per_launch")]
+        if per:
+            traffic = sum(b * c for b, c in per) / sum(c for _, c in per)
+            traffic_src = "profiles/pmc_summary.json (stored rocprofv3 --pmc passes; launch-weighted mean over the family's instantiations)"
+    single = max((e for e in rep if e["flops"] > 0 and e["total_ms"] > 0.02 * tot_ms), key=tf, default=None)
+    return {"bound": "mfma", "kernel": top["name"], "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "share_of_step_kernel_time": top["total_ms"] / tot_ms,
+            "avg_launch_us": 1e3 * top["total_ms"] / top["calls"], "launches_per_step": top["calls"] / prof_steps,
+            "algorithmic_gflop_per_launch": top["flops"] / top["calls"] / 1e9,
+            "algorithmic_mbytes_per_launch": top["bytes"] / top["calls"] / 1e6,
+            "all_kernels_time_weighted": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                          "kernel_ms_per_step": tot_ms / prof_steps},
+            "best_single_kernel": None if single is None else {"name": single["name"], "achieved": tf(single), "frac": tf(single) / FP32_MFMA_PEAK_TFLOPS,
+                                                                "share_of_step_kernel_time": single["total_ms"] / tot_ms},
+            "families": [{"name": e["name"], "calls_per_step": e["calls"] / prof_steps, "ms_per_step": e["total_ms"] / prof_steps,
+                          "tflops": tf(e)} for e in fams[:int(os.environ.get("BENCH_TOPK", "8"))]]}
 
 
 def main():
@@ -154,22 +204,7 @@ def main():
         lib.ardae_profile_enable(0)
         eng.use_graph = graph_was
     if rank == 0 and rep:
-        rep.sort(key=lambda e: -e["total_ms"])
-        top = rep[0]
-        ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get(top["name"], {}).get("hbm_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": top["name"], "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                    "avg_launch_us": 1e3 * top["total_ms"] / top["calls"], "launches_per_step": top["calls"] / args.prof_steps,
-                    "algorithmic_gflop_per_launch": top["flops"] / top["calls"] / 1e9,
-                    "algorithmic_mbytes_per_launch": top["bytes"] / top["calls"] / 1e6,
-                    "kernels": [{"name": e["name"], "calls_per_step": e["calls"] / args.prof_steps,
-                                 "ms_per_step": e["total_ms"] / args.prof_steps,
-                                 "tflops": e["flops"] / (e["total_ms"] * 1e-3) / 1e12 if e["total_ms"] > 0 else 0.0} for e in rep[:int(os.environ.get("BENCH_TOPK", "8"))]]}
+        roofline = roofline_of(rep, args.prof_steps)
     barrier()
 
     if rank == 0:

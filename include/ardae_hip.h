@@ -238,6 +238,35 @@ int ardae_model_vae_backward_sampler(const ardae_model_desc* d, const float* par
                                      float* workspace, size_t workspace_floats, float* grads, float grads_beta, void* stream);
 
 
+/* ---- evaluation / visualisation side of the model surface (csrc/eval_kernels.hip) ----------------------------
+ * Decoder samples that ImplicitPosteriorVAE.forward / .generate return next to the losses (ivae/mnist.py:188-199,300,316):
+ * relaxed Bernoulli (models/reparam.py:111-158, BernoulliDistribution.sample_logistic_sigmoid):
+ *   sample = sigmoid((logit + log(u/(1-u) + 1e-20)) / temperature), mean = sigmoid(logit); u ~ U[0,1) from the caller
+ *   (ardae_philox_uniform); sample or mean may be NULL. */
+int ardae_relaxed_bernoulli(const float* logit, const float* u, int64_t n, float temperature, float* sample, float* mean,
+                            void* stream);
+/* models/reparam.py:42-51 (sample_gaussian; Gaussian decoder of ivae/toy.py:725-737): sample = mu + exp(logvar/2) * eps */
+int ardae_gaussian_sample(const float* mu, const float* logvar, const float* eps, int64_t n, float* sample, void* stream);
+/* Lower Cholesky factors of `batch` symmetric n x n matrices (n <= 64), one launch: the factorisation inside
+ * MultivariateNormal(mu, cov) of the IWAE proposal (ivae/mnist.py:397-406).  Not positive definite -> NaNs in that factor. */
+int ardae_cholesky_batched(const float* A, int batch, int n, float* L, void* stream);
+
+
+/* ---- scalar log channel + static-binarised batches ------------------------------------------------
+ * The scalars the reference logs per --log-interval (ivae_ardae.py:850-906; five .item() synchronisations per step there,
+ * :756-758,774,837-841) leave the step through a device ring buffer instead: one record per step, written by ONE kernel at
+ * the end of the step (graph-replayable: the slot comes from the device step state, iter = Adam's t), read in bulk by the host.
+ * Record (ARDAE_LOG_RECORD_FLOATS floats): [0] iter (low 31 bits, int bit pattern), [1] model loss, [2] recon, [3] prior,
+ * [4] beta, [5] cDAE loss, [6..8] mean / max / min over the B images of std (ivae_ardae.py:756-758), [9] cDAE lr,
+ * [10] iter >> 31.  ring: [capacity, ARDAE_LOG_RECORD_FLOATS]. */
+#define ARDAE_LOG_RECORD_FLOATS 16
+int ardae_log_scalars(const float* cdae_loss, const float* model_losses, const float* std_b, int B, float beta, float d_lr,
+                      const void* state, float* ring, int capacity, void* stream);
+/* out[b, :] = table[idx[b], :]: a batch of a statically binarised set (fixed pre-drawn rows, datasets/sbmnist.py:34-60) by
+ * int64 row indices, all on the device */
+int ardae_gather_rows(const float* table, const int64_t* idx, int B, int D, float* out, void* stream);
+
+
 /* ---- live per-kernel timing (bench.py roofline): HIP events around every launch on the launch stream ---------- */
 typedef struct ardae_profile_entry {
   char name[96];   /* kernel name as rocprofv3 prints it (template arguments included)                         */

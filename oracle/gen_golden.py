@@ -300,6 +300,66 @@ def run_iwae_case(net, name, mc, B, k, dtype, store_params=True):
     print(f"[golden] {name}: IWAE-{k} ref {float(ref):.6f} oracle {float(mine):.6f} rel err {err:.2e}")
 
 
+def run_ckpt_case(net, rutils, name, mc, cc, tc, B, k_steps, dtype=torch.float32):
+    """what the reference's own objects put in a checkpoint (ivae_ardae.py:1117-1139: `model.state_dict()`,
+    `model_optimizer.state_dict()` of utils.Adam, `cdae.state_dict()`, `cdae_optimizer.state_dict()` of torch.optim.RMSprop)
+    after k_steps steps, as plain arrays + the exact key layout, and the reference's parameters after step k_steps + 1 run
+    from that state.  The test rebuilds the dicts, loads them into the fused engine (ArdaeEngine.load_checkpoints) and must
+    land on the same step k_steps + 1."""
+    import json
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc), dtype)
+    pc = O.init_params(O.cdae_param_spec(cc), 1, None, dtype)
+    model, cdae = build_reference(net, mc, cc, pm, pc, dtype)
+    m_opt = rutils.Adam(model.parameters(), lr=tc.m_lr, betas=(tc.m_beta1, 0.999))
+    c_opt = torch.optim.RMSprop(cdae.parameters(), lr=tc.d_lr, momentum=tc.d_momentum)
+    for t in range(k_steps):
+        ref_step(rutils, model, cdae, m_opt, c_opt, tc, synth_x(mc, B, 1000 + 2 * t).to(dtype), synth_x(mc, B, 1001 + 2 * t).to(dtype), 4242 + t)
+    fx = {"meta_B": np.int64(B), "meta_k": np.int64(k_steps)}
+    layout = {}
+    for tag, sd in (("model", model.state_dict()), ("cdae", cdae.state_dict())):
+        layout[tag + "_state_dict"] = list(sd.keys())
+        for k_, v in sd.items():
+            fx[f"{tag}_sd/{k_}"] = v.detach().numpy().copy()
+    for tag, osd in (("m_opt", m_opt.state_dict()), ("c_opt", c_opt.state_dict())):
+        groups = []
+        for g in osd["param_groups"]:
+            groups.append({k_: (list(v) if isinstance(v, (tuple, list)) else v) for k_, v in g.items()})
+        layout[tag + "_param_groups"] = groups
+        layout[tag + "_state_keys"] = {str(i): sorted(st.keys()) for i, st in osd["state"].items()}
+        for i, st in osd["state"].items():
+            for k_, v in st.items():
+                if torch.is_tensor(v):
+                    fx[f"{tag}/{i}/{k_}"] = v.detach().numpy().copy()
+                    layout.setdefault(tag + "_tensor_fields", {}).setdefault(str(i), []).append(k_)
+                elif v is not None:
+                    fx[f"{tag}/{i}/{k_}"] = np.float64(v)
+    fx["layout_json"] = np.array(json.dumps(layout))
+    t = k_steps
+    xc, xv = synth_x(mc, B, 1000 + 2 * t).to(dtype), synth_x(mc, B, 1001 + 2 * t).to(dtype)
+    seed = 4242 + t
+    ref = ref_step(rutils, model, cdae, m_opt, c_opt, tc, xc, xv, seed)
+    noise = replay_noise(mc, tc, B, B, seed, dtype)
+    fx["x_cdae"], fx["x_vae"] = xc.numpy(), xv.numpy()
+    for k_, v in noise.items():
+        fx["noise/" + k_] = v.numpy()
+    for k_ in ("cdae_loss", "model_loss", "recon", "prior"):
+        fx[k_] = ref[k_].numpy()
+    for grp in ("cdae_params_after", "model_params_after"):
+        for k_, v in ref[grp].items():
+            fx[grp + "/" + k_] = v.numpy()
+    # the optimiser states after step k + 1 as well (what the engine must write back)
+    for tag, osd in (("m_opt_after", m_opt.state_dict()), ("c_opt_after", c_opt.state_dict())):
+        for i, st in osd["state"].items():
+            for k_, v in st.items():
+                if torch.is_tensor(v):
+                    fx[f"{tag}/{i}/{k_}"] = v.detach().numpy().copy()
+                elif v is not None:
+                    fx[f"{tag}/{i}/{k_}"] = np.float64(v)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[golden] {name}: reference checkpoint after {k_steps} steps + step {k_steps + 1} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
     torch.set_num_threads(8)
     net, rutils = import_reference()
@@ -310,6 +370,8 @@ def main():
         real_run_case, real_iwae = run_case, run_iwae_case
         globals()["run_case"] = lambda net_, ru_, name, *a, **k: real_run_case(net_, ru_, name, *a, **k) if name in only else None
         globals()["run_iwae_case"] = lambda net_, name, *a, **k: real_iwae(net_, name, *a, **k) if name in only else None
+        real_ckpt = run_ckpt_case
+        globals()["run_ckpt_case"] = lambda net_, ru_, name, *a, **k: real_ckpt(net_, ru_, name, *a, **k) if name in only else None
     tiny_m = O.ModelCfg("mnist", input_dim=24, noise_dim=10, h_dim=64, z_dim=8, n_layers=2, nonlin="softplus")
     tiny_c = O.CdaeCfg("grad", input_dim=8, context_dim=8, h_dim=64, n_layers=3)
     tc = O.TrainCfg(nz_cdae=8)
@@ -346,6 +408,8 @@ def main():
     auxc_c = O.CdaeCfg("grad", 32, 1600, 64, 2)
     run_case(net, rutils, "auxconv_b4_nz8", auxc_m, auxc_c, O.TrainCfg(nz_cdae=8, ctx_type="hidden1a"), B=4, steps=2, dtype=f32, store_full=False)
     run_iwae_case(net, "iwae_auxconv", auxc_m, B=2, k=64, dtype=f64, store_params=False)
+    # reference-written checkpoint (model / cDAE state_dict + utils.Adam / torch.optim.RMSprop state_dict) and the step after it
+    run_ckpt_case(net, rutils, "ckpt_tiny_mnist_grad", tiny_m, tiny_c, tc, B=4, k_steps=2)
 
 
 if __name__ == "__main__":

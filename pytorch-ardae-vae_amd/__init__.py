@@ -4,6 +4,7 @@ Drop-in surface (same names as the reference's `models` / `utils` re-exports use
     MNISTIPVAE, ToyIPVAE, ConvIPVAE, MNISTAuxIPVAE, MNISTConvAuxIPVAE, MLPGradCARDAE, MLPResCARDAE, Adam, RMSprop, normal_energy_func, annealing_func
 Fused path:
     ArdaeEngine, TrainConfig  -- one train step as a straight line of C-ABI calls (what bench.py times)
+    ScalarLog                 -- the reference's per-step scalars through a device ring buffer (no host sync in the step)
 The compute is libardae_hip.so (hand-written HIP for gfx950, C ABI in include/ardae_hip.h); there is no fallback.
 """
 from . import _lib  # noqa: F401
@@ -14,3 +15,4 @@ from .modules import (MNISTIPVAE, ToyIPVAE, ConvIPVAE, MNISTAuxIPVAE, MNISTConvA
                       normal_energy_func)
 from .optim import Adam, RMSprop  # noqa: F401
 from .engine import ArdaeEngine, TrainConfig, annealing_func  # noqa: F401
+from .scalar_log import ScalarLog  # noqa: F401

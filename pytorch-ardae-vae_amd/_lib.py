@@ -71,6 +71,7 @@ class ModelDesc(ctypes.Structure):
 
 
 ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2}
+LOG_RECORD_FLOATS = 16
 EPI_ACT, EPI_DACT, EPI_CHAIN, EPI_DAE_LOSS = 0, 1, 2, 3
 
 # every symbol include/ardae_hip.h declares (checked by tests/test_abi.py)
@@ -129,6 +130,13 @@ EXPORTS = {
     "ardae_model_vae_backward_sampler": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,
                                                          ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                                          ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]),
+    "ardae_relaxed_bernoulli": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "ardae_gaussian_sample": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "ardae_cholesky_batched": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "ardae_log_scalars": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int, ctypes.c_void_p]),
+    "ardae_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "ardae_profile_report": (ctypes.c_int, [ctypes.POINTER(ProfileEntry), ctypes.c_int]),
     "ardae_cdae_score": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int,
@@ -170,6 +178,8 @@ def ptr(t):
     import torch
     if not (t.is_cuda and t.dtype == torch.float32):
         raise TypeError(f"expected a float32 tensor on the GPU, got {t.dtype} on {t.device}")
+    if not t.is_contiguous():
+        raise ValueError(f"expected a contiguous tensor, got strides {tuple(t.stride())} for shape {tuple(t.shape)}")
     return ctypes.c_void_p(t.data_ptr())
 
 

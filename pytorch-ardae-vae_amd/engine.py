@@ -107,7 +107,12 @@ class ArdaeEngine:
         # MLP models: the decoder half of the VAE backward (down to dL/dz) joins the forward half on the side stream
         self.split_backward = int(md.kind) < 2 and os.environ.get("ARDAE_SPLIT_BACKWARD", "1") != "0"
         self._side = torch.cuda.Stream(device=self.dev) if self.overlap else None
+        self._log = None                                # scalar log channel (scalar_log.ScalarLog), one more launch at the end of the step
         self.repack()
+
+    def attach_log(self, log):
+        """Append `log.record(beta)` to every step (a new launch: a captured step graph is rebuilt)."""
+        self._log, self._graph = log, None
 
     # ------------------------------------------------------------------------------------------------------------
     def repack(self):
@@ -122,14 +127,29 @@ class ArdaeEngine:
     def _pack_cdae(self):
         L.check(self.lib.ardae_cdae_pack(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.stream_ptr()))
 
+    def _check_batch(self, x, what):
+        """The kernels read exactly B * input_dim contiguous floats from each batch pointer: anything else (a ragged last batch
+        of a loader without drop_last, a strided view, a host tensor) must be refused here, not read out of bounds."""
+        if not torch.is_tensor(x):
+            raise TypeError(f"{what}: expected a tensor, got {type(x).__name__}")
+        if x.dtype != torch.float32:
+            raise ValueError(f"{what}: expected a float32 tensor, got {x.dtype}")
+        if x.dim() < 2 or x.size(0) != self.B or x.numel() != self.B * self.model.input_dim:
+            raise ValueError(f"{what}: expected {self.B} images of {self.model.input_dim} values (the engine was built with batch_size={self.B}; "
+                             f"use drop_last or pad the last batch), got shape {tuple(x.shape)}")
+        if not x.is_contiguous():
+            raise ValueError(f"{what}: the batch must be contiguous (got strides {tuple(x.stride())}); call .contiguous()")
+        if not x.is_cuda or x.device != self.dev:
+            raise ValueError(f"{what}: expected a tensor on {self.dev}, got one on {x.device}")
+
     def _encode(self, x, noise, nz, out, ws):
         L.check(self.lib.ardae_model_encode(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x),
-                                            L.ptr(noise) if noise is not None else None, x.size(0), nz, L.ptr(ws), ws.numel(),
+                                            L.ptr(noise) if noise is not None else None, self.B, nz, L.ptr(ws), ws.numel(),
                                             L.ptr(out), L.stream_ptr()), "ardae_model_encode")
 
     def _hidden(self, x, z0_out, out, ws):
         """The std = 0 pass of an aux sampler: latent mean z0 AND the hidden1a context in one go."""
-        L.check(self.lib.ardae_model_encode_hidden(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), x.size(0),
+        L.check(self.lib.ardae_model_encode_hidden(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), self.B,
                                                    L.ptr(ws), ws.numel(), L.ptr(z0_out), L.ptr(out), L.stream_ptr()), "ardae_model_encode_hidden")
 
     def _allreduce_mean(self, t):
@@ -158,6 +178,7 @@ class ArdaeEngine:
         """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z]).
         drawn: event after which the engine's own three draws (sampler, sigma, eps) are in their buffers - step() issues them
         on the side stream, next to the per-image trunk this method starts with."""
+        self._check_batch(x, "cdae_phase")
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         B, nz, z = self.B, cfg.nz_cdae, self.model.z_dim
         if noise:
@@ -202,6 +223,7 @@ class ArdaeEngine:
 
     def vae_forward_part(self, x, noise=None, beta=None, draw=None):
         """ivae_ardae.py:781-827: everything of the VAE update that does not involve the cDAE (forward, ELBO pieces, z0, u)."""
+        self._check_batch(x, "vae_forward_part")
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         beta = cfg.beta if beta is None else beta
         B, nz, md = self.B, cfg.nz_model, self.model._desc
@@ -223,6 +245,7 @@ class ArdaeEngine:
 
     def vae_backward_part(self, x, nv, beta=None, apply_update=True):
         """ivae_ardae.py:829-846: entropy gradient through the (updated) cDAE, backward, Adam."""
+        self._check_batch(x, "vae_backward_part")
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         beta = cfg.beta if beta is None else beta
         B, nz, md = self.B, cfg.nz_model, self.model._desc
@@ -293,6 +316,8 @@ class ArdaeEngine:
                     self.cdae_phase(xc, nlist[i])
                 nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
             self.vae_backward_part(x_vae, nv, beta)
+            if self._log is not None:
+                self._log.record(cfg.beta if beta is None else beta)
         finally:
             self._in_step = False
 
@@ -301,6 +326,9 @@ class ArdaeEngine:
         caller passes a list of batches when num_cdae_updates > 1) followed by one VAE update."""
         many = isinstance(x_cdae, (list, tuple))
         xs = list(x_cdae) if many else [x_cdae] * self.cfg.num_cdae_updates
+        for x in xs:
+            self._check_batch(x, "step(x_cdae)")
+        self._check_batch(x_vae, "step(x_vae)")
         if 3 * len(xs) >= self.RNG_STRIDE:
             raise ValueError("at most %d cDAE updates per step (Philox offsets reserved per step)" % ((self.RNG_STRIDE - 1) // 3))
         if self.use_graph and noise is None:
@@ -367,7 +395,8 @@ class ArdaeEngine:
                 "optimizer": {"state": state,
                               "param_groups": [{"lr": cfg.m_lr, "betas": (cfg.m_beta1, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
                                                 "params": list(range(len(m)))}]},
-                "engine": {"step_count": self.step_count, "rng_seed": rng.get_state()["seed"], "step_state": self.state.cpu().clone()}}
+                "engine": {"step_count": self.step_count, "rng_seed": rng.get_state()["seed"], "rng_host_offset": rng.get_state()["offset"],
+                           "step_state": self.state.cpu().clone()}}
 
     def cdae_checkpoint(self):
         cfg = self.cfg
@@ -407,7 +436,7 @@ class ArdaeEngine:
         self.step_count = steps.pop() if steps else 0
         eng = model_ckpt.get("engine")
         if eng is not None:     # written by this engine: continue the same noise stream
-            rng.manual_seed(eng["rng_seed"], rng.get_state()["offset"])
+            rng.manual_seed(eng["rng_seed"], eng.get("rng_host_offset", rng.get_state()["offset"]))
             self.state.copy_(eng["step_state"].to(self.dev))
         else:                   # written by the reference / the module path: only Adam's t matters
             self.state.zero_()

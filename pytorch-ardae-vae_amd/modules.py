@@ -56,7 +56,6 @@ class FlatParamModule(nn.Module):
                 mod = mod._modules[p]
             mod.register_parameter(parts[-1], nn.Parameter(self._flat[off:off + n].view(shape)))
         self._packed = None
-        self._packed_version = -1
 
     # keep the parameters views of the flat buffer across .to()/.cuda()/.float()
     def _apply(self, fn, recurse=True):
@@ -70,7 +69,6 @@ class FlatParamModule(nn.Module):
             off, n, shape = self._offs[name]
             p.data = flat[off:off + n].view(shape)
         self._packed = None
-        self._packed_version = -1
 
     def flat_params(self):
         return self._flat
@@ -91,10 +89,6 @@ class FlatParamModule(nn.Module):
         for t in tensors:
             if t is not None and not t.is_cuda:
                 raise RuntimeError(f"{type(self).__name__}: got a {t.device} tensor; inputs must be on the GPU")
-
-    def _version(self):
-        # in-place updates through a parameter bump that parameter's own counter (p.data views do not share the base's)
-        return self._flat._version + sum(p._version for p in self.parameters())
 
     def _ws(self, nfloats):
         return torch.empty(nfloats, device=self._flat.device, dtype=torch.float32)
@@ -157,12 +151,14 @@ class ConditionalARDAE(FlatParamModule):
         self._default_init()
 
     def _packed_weights(self):
-        if self._packed is None or self._packed_version != self._version():
-            lib = L.lib()
-            if self._packed is None:
-                self._packed = self._ws(lib.ardae_cdae_packed_floats(ctypes.byref(self._desc)))
-            L.check(lib.ardae_cdae_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_cdae_pack")
-            self._packed_version = self._version()
+        """MFMA-lane-linear image of the current weights.  Re-packed at EVERY call (one launch over ~2-12 MB): tensor version
+        counters cannot be trusted to see an update - `p.data.add_(...)`, which is how the reference's vendored Adam writes
+        (utils/optim.py:106), bumps none - so any optimiser, the reference's included, may be used with these modules.
+        (The fused engine keeps its own image and re-packs right after its own optimiser kernels.)"""
+        lib = L.lib()
+        if self._packed is None:
+            self._packed = self._ws(lib.ardae_cdae_packed_floats(ctypes.byref(self._desc)))
+        L.check(lib.ardae_cdae_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_cdae_pack")
         return self._packed
 
     def _prep(self, input, context, std):
@@ -255,6 +251,7 @@ class _VaeFn(torch.autograd.Function):
 class ImplicitPosteriorVAE(FlatParamModule):
     _kind = None
     _enc_types = ("concat",)
+    return_samples = True        # forward() also returns the decoder sample / mean the reference's visualisation code reads
 
     def __init__(self, energy_func=normal_energy_func, input_dim=784, noise_dim=100, h_dim=300, z_dim=32, nonlinearity="softplus",
                  num_hidden_layers=1, init="gaussian", enc_type="concat"):
@@ -303,12 +300,11 @@ class ImplicitPosteriorVAE(FlatParamModule):
                 p["encode.fc.fc.weight"].normal_()
 
     def _packed_weights(self):
-        if self._packed is None or self._packed_version != self._version():
-            lib = L.lib()
-            if self._packed is None:
-                self._packed = self._ws(lib.ardae_model_packed_floats(ctypes.byref(self._desc)))
-            L.check(lib.ardae_model_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_model_pack")
-            self._packed_version = self._version()
+        """See ConditionalARDAE._packed_weights: re-packed at every call, whatever wrote the parameters."""
+        lib = L.lib()
+        if self._packed is None:
+            self._packed = self._ws(lib.ardae_model_packed_floats(ctypes.byref(self._desc)))
+        L.check(lib.ardae_model_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_model_pack")
         return self._packed
 
     def _x(self, input):
@@ -355,9 +351,29 @@ class ImplicitPosteriorVAE(FlatParamModule):
                                               ws.numel(), None, L.ptr(hid), L.stream_ptr()), "ardae_model_encode_hidden")
         return hid
 
-    def forward(self, input, beta=1.0, eta=0.0, lmbd=0.0, std=None, nz=1, noise=None):
-        """-> (None, None, z, loss, recon.detach(), prior.detach()).  The first two entries (a decoder sample and its mean,
-        used only by the reference's visualisation code) are not produced by the training engine."""
+    def _decoder_sample(self, z_rows, dec_noise=None):
+        """(x_sample, decoder mean) of the reference's Decoder.forward for z_rows [R, z]: Bernoulli decoders return the relaxed
+        (logistic-sigmoid, T = 1) sample and sigmoid(logit) (reparam.py:111-158, ivae/mnist.py:188-199,300); the toy model's
+        Gaussian decoder returns mu + exp(logvar/2) eps and mu (reparam.py:42-51, ivae/toy.py:725-737,858).  dec_noise injects
+        the draw (uniform [R, D] resp. normal [R, D]); default: the library's Philox stream."""
+        out = self.decode_params(z_rows)
+        R, lib = out[0].size(0), L.lib()
+        sample = torch.empty_like(out[0])
+        if self._kind == "toy":
+            e = _f32c(dec_noise).view(R, self.input_dim) if dec_noise is not None else rng.normal((R, self.input_dim), out[0].device)
+            L.check(lib.ardae_gaussian_sample(L.ptr(out[0]), L.ptr(out[1]), L.ptr(e), out[0].numel(), L.ptr(sample), L.stream_ptr()),
+                    "ardae_gaussian_sample")
+            return sample, out[0]
+        u = _f32c(dec_noise).view(R, self.input_dim) if dec_noise is not None else rng.uniform((R, self.input_dim), out[0].device)
+        mean = torch.empty_like(out[0])
+        L.check(lib.ardae_relaxed_bernoulli(L.ptr(out[0]), L.ptr(u), out[0].numel(), 1.0, L.ptr(sample), L.ptr(mean), L.stream_ptr()),
+                "ardae_relaxed_bernoulli")
+        return sample, mean
+
+    def forward(self, input, beta=1.0, eta=0.0, lmbd=0.0, std=None, nz=1, noise=None, dec_noise=None):
+        """-> (x_sample, decoder mean, z, loss, recon.detach(), prior.detach()) like the reference (ivae/mnist.py:267-301).
+        The first two entries feed only the reference's visualisation code; they cost one extra decoder pass on the B*nz rows
+        and are skipped (None, None) when `self.return_samples` is False - the fused engine never produces them."""
         if lmbd > 0:
             raise NotImplementedError                     # ivae/mnist.py:288-290
         x = self._x(input)
@@ -368,7 +384,11 @@ class ImplicitPosteriorVAE(FlatParamModule):
                 noise = noise * float(std)
         noise = self._noise_rows(noise, B * nz)
         z, loss, losses = _VaeFn.apply(self, x, noise, beta, nz, *self.parameters())
-        return None, None, z, loss, losses[1].detach(), losses[2].detach()
+        xs, xm = (None, None)
+        if self.return_samples:
+            with torch.no_grad():
+                xs, xm = self._decoder_sample(z.detach().reshape(B * nz, self.z_dim), dec_noise)
+        return xs, xm, z, loss, losses[1].detach(), losses[2].detach()
 
 
     # ---- evaluation --------------------------------------------------------------------------------
@@ -384,11 +404,12 @@ class ImplicitPosteriorVAE(FlatParamModule):
                                        ws.numel(), L.ptr(o0), L.ptr(o1), L.stream_ptr()), "ardae_model_decode")
         return (o0,) if o1 is None else (o0, o1)
 
-    def generate(self, batch_size=1):
-        """-> (None, decoder mean, z) with z ~ N(0, I) (ivae/mnist.py:303-316; the relaxed sample is not produced)."""
-        z = rng.normal((batch_size, self.z_dim), self._flat.device)
-        out = self.decode_params(z)
-        return None, (torch.sigmoid(out[0]) if self._kind == "mnist" else out[0]), z
+    def generate(self, batch_size=1, z=None, dec_noise=None):
+        """-> (x_sample, decoder mean, z) with z ~ N(0, I) (ivae/mnist.py:303-316, ivae/toy.py:862-873).  z / dec_noise inject the draws."""
+        with torch.no_grad():
+            z = rng.normal((batch_size, self.z_dim), self._flat.device) if z is None else _f32c(z).view(batch_size, self.z_dim)
+            xs, xm = self._decoder_sample(z, dec_noise)
+        return xs, xm, z
 
     def logprob(self, input, sample_size=128, z=None, std=None, enc_noise=None, prop_noise=None):
         """IWAE-k bound with a full-covariance Gaussian fitted to the encoder samples as proposal
@@ -409,10 +430,11 @@ class ImplicitPosteriorVAE(FlatParamModule):
             cov = zc.transpose(1, 2) @ zc / (k - 1)           # utils/stat.py:127-158
             if self._kind in ("auxmnist", "auxconv"):
                 cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321, ivae/auxconv.py
-            try:
-                Lc = torch.linalg.cholesky(cov)
-            except RuntimeError:                              # no device solver in this build: 32x32 factorisations on the host
-                Lc = torch.linalg.cholesky(cov.cpu()).to(cov.device)
+            cov = cov.contiguous()
+            Lc = torch.empty_like(cov)                        # all B factorisations in one launch (MultivariateNormal's, ivae/mnist.py:397)
+            L.check(L.lib().ardae_cholesky_batched(L.ptr(cov), B, zd, L.ptr(Lc), L.stream_ptr()), "ardae_cholesky_batched")
+            if not bool(torch.isfinite(Lc).all()):
+                raise ValueError("logprob: a sample covariance is not positive definite (torch.distributions would raise here too)")
             if prop_noise is None:
                 prop_noise = rng.normal((B, k, zd), x.device)
             e = _f32c(prop_noise).view(B, k, zd)

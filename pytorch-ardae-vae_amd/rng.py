@@ -4,12 +4,19 @@ Replaces the `torch.randn` calls of the reference hot path (models/ivae/mnist.py
 models/graddae/mlp.py:22).  GPU Philox cannot reproduce torch-CPU draws, so parity tests inject noise tensors instead;
 this stream is what training and the benchmark use.  Every draw consumes one `offset`; element i of a draw depends
 only on (seed, offset, i), so results do not depend on how rows are partitioned over ranks.
+
+Two consumers share one seed and must never share a Philox word: the fused engine's in-step draws use offsets
+`RNG_STRIDE * step + k` (device-resident step state, engine.py), host-side draws (this module: `normal`, `uniform`,
+`data.dynamic_binarize`, `model.generate/logprob`, the drop-in modules' noise) use `HOST_STREAM | n` with the top bit of
+the 64-bit offset set.  The host counter `n` is part of the engine checkpoint (engine.py::model_checkpoint).
 """
 import ctypes
 
 import torch
 
 from . import _lib as L
+
+HOST_STREAM = 1 << 63          # offset space of host-side draws; the engine's in-step offsets stay below it
 
 _state = {"seed": 0x5EED, "offset": 0}
 
@@ -23,9 +30,12 @@ def get_state():
 
 
 def _next_offset():
+    """Philox offset of the next host-side draw (disjoint from every in-step offset of the engine)."""
     o = _state["offset"]
+    if o >= HOST_STREAM:
+        raise OverflowError("host Philox stream exhausted")
     _state["offset"] = o + 1
-    return o
+    return HOST_STREAM | o
 
 
 def normal(shape, device, out=None, first_element=0):

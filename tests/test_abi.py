@@ -135,3 +135,48 @@ def test_argument_validation_of_the_step_entry_points():
     probs = (L.WgradProblem * 1)()
     fails(lib.ardae_wgrad_batch(probs, 0, None), "problems per batch")
     fails(lib.ardae_wgrad_batch(probs, 1, None), "empty problem")
+
+
+def test_engine_batch_validation_rules():
+    """what ArdaeEngine.step / the phase entry points accept as a batch (checked before any pointer reaches a kernel).
+    The rules are host logic, so they are exercised here on CPU tensors against a stand-in for the engine's fields."""
+    import types
+    import torch
+    from ardae_amd.engine import ArdaeEngine
+    eng = types.SimpleNamespace(B=4, dev=torch.device("cuda", 0), model=types.SimpleNamespace(input_dim=24))
+    check = lambda x: ArdaeEngine._check_batch(eng, x, "step")
+    good = torch.zeros(4, 24)
+    with pytest.raises(ValueError, match="on cuda:0"):
+        check(good)                                               # everything right but the device
+    with pytest.raises(ValueError, match="batch_size=4"):
+        check(torch.zeros(3, 24))                                 # ragged last batch of a loader without drop_last
+    with pytest.raises(ValueError, match="batch_size=4"):
+        check(torch.zeros(4, 25))
+    with pytest.raises(ValueError, match="batch_size=4"):
+        check(torch.zeros(1, 24).expand(4, 24)[:1])
+    with pytest.raises(ValueError, match="contiguous"):
+        check(torch.zeros(4, 48)[:, ::2])                         # strided view
+    with pytest.raises(ValueError, match="contiguous"):
+        check(torch.zeros(24, 4).t())
+    with pytest.raises(ValueError, match="float32"):
+        check(good.double())
+    with pytest.raises(TypeError):
+        check([[0.0] * 24] * 4)
+    with pytest.raises(ValueError, match="on cuda:0"):
+        check(torch.zeros(4, 1, 4, 6))                            # image-shaped batches pass the shape rule
+
+
+def test_host_and_in_step_philox_offsets_are_disjoint():
+    """host-side draws (rng.normal / uniform, data.*, model.generate / logprob) and the engine's in-step draws share one
+    seed; their Philox offsets must never coincide.  In-step offsets are RNG_STRIDE * step + k < 2^63, host offsets have bit 63 set."""
+    from ardae_amd import rng
+    from ardae_amd.engine import ArdaeEngine
+    rng.manual_seed(7, 0)
+    host = [rng._next_offset() for _ in range(40)]
+    assert all(o & rng.HOST_STREAM for o in host) and len(set(host)) == 40
+    assert [o & ~rng.HOST_STREAM for o in host] == list(range(40))
+    in_step = {ArdaeEngine.RNG_STRIDE * step + k for step in range(1, 10_000, 97) for k in range(ArdaeEngine.RNG_STRIDE)}
+    assert max(in_step) < rng.HOST_STREAM and not (in_step & set(host))
+    assert rng.get_state() == {"seed": 7, "offset": 40}           # the host counter itself (what the engine checkpoint stores)
+    rng.manual_seed(7, 40)
+    assert rng._next_offset() == rng.HOST_STREAM | 40
