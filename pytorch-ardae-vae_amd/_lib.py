@@ -172,14 +172,13 @@ def check(rc, what="ardae call"):
 
 
 def ptr(t):
-    """Device pointer of a contiguous fp32 CUDA(HIP) tensor (or None)."""
+    """Device pointer of an fp32 CUDA(HIP) tensor (or None).  Layout is the caller's business (strided views are passed with their
+    leading dimension); the engine validates its batches in ArdaeEngine._check_batch."""
     if t is None:
         return None
     import torch
     if not (t.is_cuda and t.dtype == torch.float32):
         raise TypeError(f"expected a float32 tensor on the GPU, got {t.dtype} on {t.device}")
-    if not t.is_contiguous():
-        raise ValueError(f"expected a contiguous tensor, got strides {tuple(t.stride())} for shape {tuple(t.shape)}")
     return ctypes.c_void_p(t.data_ptr())
 
 

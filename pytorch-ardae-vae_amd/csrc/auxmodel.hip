@@ -174,13 +174,11 @@ int grid_of(int64_t n) {
 }
 }  // namespace
 int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int ld_eps, int64_t rows, int cols, int rpg, float* out, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, mu, lv, cols, eps, ld_eps, rows, cols, rpg, out);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
 int launch_reparam_bwd(const float* dz, const float* z, const float* mu, int64_t rows, int cols, int rpg, float* dlv, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, dz, z, mu, rows, cols, rpg, dlv);
   ARDAE_LAUNCH_CHECK();
   return 0;
@@ -190,7 +188,7 @@ namespace {
 int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
   a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
   a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;
-  return linear_or_chain(a, epi, st);
+  return launch_linear(a, epi, st);
 }
 
 // the sampler on R = B nz rows; noise [R, nd + zd] (never null here); fills every forward field of W
@@ -229,8 +227,7 @@ int sampler_fwd(const AuxLayout& P, const AuxPacked& K, const float* params, con
 const float* noise_or_zero(const AuxLayout& P, const float* noise, int R, AuxWs& W, hipStream_t st, int& rc) {
   rc = 0;
   if (noise) return noise;
-  rc = flush_active_chain();
-  if (rc == 0 && hipMemsetAsync(W.zero, 0, (size_t)R * (P.nd + P.zd) * sizeof(float), st) != hipSuccess) rc = (int)hipErrorUnknown;
+  if (hipMemsetAsync(W.zero, 0, (size_t)R * (P.nd + P.zd) * sizeof(float), st) != hipSuccess) rc = (int)hipErrorUnknown;
   return W.zero;
 }
 
@@ -277,7 +274,6 @@ int aux_model_encode(const ardae_model_desc& d, const float* params, const float
   const float* nz_ptr = noise_or_zero(P, noise, B * nz, W, st, rc);
   ARDAE_TRY(rc);
   ARDAE_TRY(sampler_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, st));
-  ARDAE_TRY(flush_active_chain());
   if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (hidden_out) {   // forward_hidden of the ENCODER (ivae/auxmnist.py:125-132, nz == 1): cat(h0, h)
     ARDAE_CHECK_ARG(nz == 1, "aux_model_encode: the hidden context is defined for nz == 1");
@@ -316,7 +312,6 @@ int aux_model_vae_forward(const ardae_model_desc& d, const float* params, const 
   ARDAE_CHECK_ARG(ws.ok, "aux_model_vae_forward: workspace too small");
   const int R = B * nz, h = P.h;
   ARDAE_TRY(sampler_fwd(P, K, params, packed, x, noise, B, nz, W, st));
-  ARDAE_TRY(flush_active_chain());
   ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
   for (int l = 1; l <= P.nl; ++l) {
     LinArgs A{}; A.bias = params + P.dec[l - 1].b; A.Y = W.dcd[l]; A.ldY = h;
@@ -361,7 +356,7 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
     LinArgs A{}; A.M = R; A.Nout = h; A.nsrc = 2; A.act = act; A.S = W.t[nl]; A.ldS = h; A.Y = W.dt[nl]; A.ldY = h;
     A.src[0].x = W.dz; A.src[0].ld = P.zd; A.src[0].K = P.zd; A.src[0].wp = packed + K.mean_b;
     A.src[1].x = W.dlv; A.src[1].ld = P.zd; A.src[1].K = P.zd; A.src[1].wp = packed + K.logvar_b;
-    ARDAE_TRY(linear_or_chain(A, EPI_DACT, st));
+    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
   }
   for (int l = nl; l >= 2; --l) {
     LinArgs A{}; A.S = W.t[l - 1]; A.ldS = h; A.Y = W.dt[l - 1]; A.ldY = h;
@@ -380,7 +375,7 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
     LinArgs A{}; A.M = B; A.Nout = h; A.nsrc = 2; A.act = act; A.S = W.e[nl]; A.ldS = h; A.Y = W.de[nl]; A.ldY = h;
     A.src[0].x = W.dmu0; A.src[0].ld = P.nd; A.src[0].K = P.nd; A.src[0].wp = packed + K.mean0_b;
     A.src[1].x = W.dlv0; A.src[1].ld = P.nd; A.src[1].K = P.nd; A.src[1].wp = packed + K.logvar0_b;
-    ARDAE_TRY(linear_or_chain(A, EPI_DACT, st));
+    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
   }
   for (int l = nl; l >= 2; --l) {
     LinArgs A{}; A.S = W.e[l - 1]; A.ldS = h; A.Y = W.de[l - 1]; A.ldY = h;

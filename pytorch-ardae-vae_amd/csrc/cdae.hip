@@ -180,14 +180,13 @@ int cdae_pack_impl(const CdaeLayout& P, const PackedLayout& K, const float* para
 int lin(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
   a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
   a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;
-  return linear_or_chain(a, epi, st);
+  return launch_linear(a, epi, st);
 }
 
 int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed, const float* xbar, const float* sigma,
               const float* eps, const float* ctx, int B, int S, float* workspace, size_t ws_floats, float* loss, float* grads,
               float* score_out, bool need_grads, hipStream_t st) {
   ARDAE_TRY(desc_ok(d));
-  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   ARDAE_CHECK_ARG(params && packed && xbar && sigma && ctx && workspace, "cdae: null pointer argument");
   ARDAE_CHECK_ARG(B > 0 && S > 0 && (int64_t)B * S < (int64_t)1 << 30, "cdae: bad batch (B=%d, S=%d)", B, S);
   ARDAE_CHECK_ARG(!need_grads || (eps && loss && grads), "cdae: loss/grads/eps must be given");

@@ -418,7 +418,6 @@ inline int grid_for(int64_t n, int cap = 4096) {
 
 int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int zd,
                           float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(latent && z0 && xi && eps && xbar && sigma && std_b, "latent_perturb: null pointer");
   ARDAE_CHECK_ARG(B > 0 && nz >= 2 && zd >= 1 && zd <= 256, "latent_perturb: need B>0, nz>=2 (unbiased std), 1<=z<=256 (B=%d nz=%d z=%d)", B, nz, zd);
   int zp = 1;
@@ -442,7 +441,6 @@ int launch_latent_perturb(const float* latent, const float* z0, const float* xi,
 }
 
 int launch_center_scale(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float* u, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(latent && z0 && u && B > 0 && nz > 0 && zd > 0, "center_scale: bad arguments");
   const int64_t n = (int64_t)B * nz * zd;
   hipLaunchKernelGGL(center_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, latent, z0, n, nz, zd, std_scale, u);
@@ -452,7 +450,6 @@ int launch_center_scale(const float* latent, const float* z0, int B, int nz, int
 
 int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, int cols, float scale, float* out, int ldout,
                        hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(in && out && groups > 0 && rows_per_group > 0 && cols > 0 && ld >= cols && ldout >= cols, "segment_sum: bad arguments");
   if ((int64_t)groups * ceil_div(cols, 64) < 256 && rows_per_group >= 128)
     hipLaunchKernelGGL(segment_sum_kernel<1024>, dim3(groups, ceil_div(cols, 64)), dim3(1024), 0, st, in, ld, rows_per_group, cols, scale, out, ldout);
@@ -463,7 +460,6 @@ int launch_segment_sum(const float* in, int ld, int groups, int rows_per_group, 
 }
 
 int launch_sum_scale(const float* in, int n, float scale, float* out, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(in && out && n > 0, "sum_scale: bad arguments");
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, in, n, scale, out);
   ARDAE_LAUNCH_CHECK();
@@ -471,7 +467,6 @@ int launch_sum_scale(const float* in, int n, float scale, float* out, hipStream_
 }
 
 int launch_gather_strided(const float* src, int stride, int n, float* dst, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(src && dst && n > 0 && stride > 0, "gather_strided: bad arguments");
   hipLaunchKernelGGL(gather_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, stride, n, dst);
   ARDAE_LAUNCH_CHECK();
@@ -479,7 +474,6 @@ int launch_gather_strided(const float* src, int stride, int n, float* dst, hipSt
 }
 
 int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(out && n > 0, "philox_normal: bad arguments");
   const int64_t q = (n + 3) / 4;
   hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset,
@@ -489,7 +483,6 @@ int launch_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, 
 }
 
 int launch_philox_normal_at(float* out, int64_t n, uint64_t seed, uint64_t offset, const void* state, uint64_t first_element, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(out && n > 0, "philox_normal_at: bad arguments");
   ARDAE_CHECK_ARG((first_element & 3) == 0, "philox_normal_at: first_element must be a multiple of 4 (one Philox counter = 4 normals)");
   const int64_t q = (n + 3) / 4;
@@ -505,7 +498,6 @@ int launch_philox_normal_dev(float* out, int64_t n, uint64_t seed, const void* s
 }
 
 int launch_step_state_advance(void* state, uint64_t rng_inc, double lr, double beta1, double beta2, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(state, "step_state_advance: null state");
   hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, st, (StepState*)state, rng_inc, lr, beta1, beta2);
   ARDAE_LAUNCH_CHECK();
@@ -513,7 +505,6 @@ int launch_step_state_advance(void* state, uint64_t rng_inc, double lr, double b
 }
 
 int launch_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(out && n > 0, "philox_uniform: bad arguments");
   const int64_t q = (n + 3) / 4;
   hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, out, n, seed, offset);
@@ -522,7 +513,6 @@ int launch_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset,
 }
 
 int launch_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_t seed, uint64_t offset, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(p && out && rows > 0 && cols > 0, "bernoulli: bad arguments");
   const int64_t q = (rows * cols + 3) / 4;
   hipLaunchKernelGGL(bernoulli_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, p, rows, cols, out, seed, offset);
@@ -532,7 +522,6 @@ int launch_bernoulli(const float* p, int64_t rows, int cols, float* out, uint64_
 
 int launch_adam_ref(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1, double beta2,
                     double eps, int step, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_ref: bad arguments");
   const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   hipLaunchKernelGGL(adam_ref_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, vmax, n, (float)beta1, (float)beta2,
@@ -543,7 +532,6 @@ int launch_adam_ref(float* p, const float* g, float* m, float* v, float* vmax, i
 
 int launch_adam_ref_dev(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double beta1, double beta2, double eps,
                         const void* state, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(p && g && m && v && n > 0 && state, "adam_ref_dev: bad arguments");
   hipLaunchKernelGGL(adam_ref_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, vmax, n, (float)beta1, (float)beta2,
                      (float)eps, 0.f, 1.f, (const StepState*)state);
@@ -553,7 +541,6 @@ int launch_adam_ref_dev(float* p, const float* g, float* m, float* v, float* vma
 
 int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, double lr, double alpha, double eps, double momentum,
                    hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(p && g && sq && n > 0 && (momentum <= 0.0 || buf), "rmsprop: bad arguments");
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, sq, buf, n, (float)lr, (float)alpha, (float)eps,
                      (float)momentum);
@@ -562,7 +549,6 @@ int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, d
 }
 
 int launch_axpy(const float* x, int64_t n, float alpha, float* y, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(x && y && n > 0, "axpy: bad arguments");
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, alpha, y);
   ARDAE_LAUNCH_CHECK();
@@ -570,7 +556,6 @@ int launch_axpy(const float* x, int64_t n, float alpha, float* y, hipStream_t st
 }
 
 int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(x && y && n > 0, "affine: bad arguments");
   hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, alpha, beta, y);
   ARDAE_LAUNCH_CHECK();
@@ -580,7 +565,6 @@ int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, 
 int launch_vae_loss(int kind, const float* o0, const float* o1, const float* x, const float* z, int rows, int nz, int D, int zd,
                     float beta, int write_grads, float gscale, const float* dz_extra, float* rec_row, float* pri_row, float* do0,
                     float* do1, float* dzq, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(o0 && x && z && rec_row && pri_row && rows > 0 && nz > 0 && D > 0 && zd > 0, "vae_loss: bad arguments");
   ARDAE_CHECK_ARG(kind == 0 || (kind == 1 && o1), "vae_loss: kind 1 needs the logvar head");
   ARDAE_CHECK_ARG(!write_grads || (do0 && dzq && (kind == 0 || do1)), "vae_loss: gradient outputs missing");
@@ -595,7 +579,6 @@ int launch_vae_loss(int kind, const float* o0, const float* o1, const float* x, 
 }
 
 int launch_vae_loss_finalize(const float* rec_row, const float* pri_row, int rows, float beta, float* losses, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(rec_row && pri_row && losses && rows > 0, "vae_loss_finalize: bad arguments");
   hipLaunchKernelGGL(vae_loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_row, pri_row, rows, beta, losses);
   ARDAE_LAUNCH_CHECK();

@@ -29,33 +29,6 @@ int linear_col_panels(int M, int nout);
 // M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]
 int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose, float* out, hipStream_t st);
 int launch_linear(const LinArgs& a, int epi, hipStream_t st);
-// Chain of ROW-LOCAL layers on a few hundred rows: consecutive chain_add() calls whose layer l+1 reads, at row r, only
-// what earlier layers of the chain wrote at row r (plus tensors from outside the chain) run in ONE launch, one workgroup
-// per 32 rows.  The caller flushes before anything else touches the chain's outputs.  Ineligible layers (large M, the
-// DAE-loss epilogue) flush the chain and launch on their own, so call sites can route every linear through chain_add.
-constexpr int LIN_CHAIN_MAX = 8;
-struct LinChain {
-  explicit LinChain(hipStream_t s) : st(s) {}
-  int n = 0, M = 0;
-  bool wide = false;   // a chain of N-row layers for linear_fchain_kernel (else: per-image layers for linear_chain_kernel)
-  LinArgs a[LIN_CHAIN_MAX];
-  int epi[LIN_CHAIN_MAX];
-  hipStream_t st;
-};
-int chain_add(LinChain& c, const LinArgs& a, int epi);
-int chain_flush(LinChain& c);
-// Scope within which linear_or_chain() collects consecutive row-local layers into chains.  Every other launcher of the
-// library (elementwise, wgrad, direct launch_linear, copies in model.hip / cdae.hip) calls flush_active_chain() first, so
-// a chain can never be overtaken by a consumer of its outputs.  finish() flushes and reports the error code.
-struct ChainScope {
-  explicit ChainScope(hipStream_t st);
-  ~ChainScope();
-  int finish();
-  LinChain chain;
-  LinChain* prev;
-};
-int flush_active_chain();
-int linear_or_chain(const LinArgs& a, int epi, hipStream_t st);   // chain_add on the active scope, else launch_linear
 // pack many matrices with one launch (the per-step refresh of a network's weight images)
 struct PackItem { const float* W; int ldw, nout, k, transpose; float* out; };
 constexpr int PACK_BATCH_MAX = 48;
@@ -72,9 +45,5 @@ int launch_linear_shortk(const LinArgs& a, int epi, hipStream_t st);
 // software-pipelined 64 x 256 kernel (linear_wide.hip): full tiles, K % 32 == 0
 bool linear_wide_eligible(const LinArgs& a, int epi);
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);
-// fused chain of N-row 256 -> 256 layers in one persistent launch (linear_fchain_kernel.h)
-bool linear_fchain_layer_ok(const LinArgs& a, int epi);
-int linear_fchain_length();
-int launch_linear_fchain(const LinArgs* layers, int nl, int epi, hipStream_t st);
 
 }  // namespace ardae

@@ -107,7 +107,7 @@ __device__ __forceinline__ void epilogue_tr(const LinArgs& a, const f32x16& acc,
 }
 
 // One output tile (bx = row tile, by = column panel of a grid that has nby column panels).  `lds` holds
-// Geo::LDS_FLOATS floats, `red` four.  linear_kernel runs one tile per workgroup; linear_chain_kernel walks the tiles of
+// Geo::LDS_FLOATS floats, `red` four.  linear_kernel runs one tile per workgroup (
 // consecutive layers for a fixed set of rows.
 template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, bool TR>
 __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, int nby, float* lds, float* red) {
@@ -412,49 +412,6 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
   linear_tile<TM, TN, WM, WN, KPANEL, EPI, ACT, TR>(a, blockIdx.x, blockIdx.y, gridDim.y, lds, red);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Chain of row-local layers on a few hundred rows (the per-image MLPs: encoder trunk, context encoder, decoder, and
-// their backward chains).  One workgroup owns 32 rows and runs every layer of the chain for them, column panel by
-// column panel; layer l+1 reads what the same workgroup wrote for layer l (workgroup-scope visibility: one CU, one L1).
-// These layers are a few microseconds of work each, so a launch per layer is mostly launch latency.
-// ---------------------------------------------------------------------------------------------------------------------
-struct LinChainDev {
-  int n;
-  int epi[LIN_CHAIN_MAX];
-  LinArgs a[LIN_CHAIN_MAX];
-};
-static_assert(sizeof(LinChainDev) <= 4000, "kernel argument block too large");
-
-template <int EPI, int ACT>
-__device__ __forceinline__ void chain_layer(const LinArgs& a, int bx, float* lds, float* red) {
-  const int nby = (a.Nout + 127) >> 7;
-  for (int by = 0; by < nby; ++by) {
-    linear_tile<1, 1, 1, 4, SMALLM_KPANEL, EPI, ACT, false>(a, bx, by, nby, lds, red);
-    __syncthreads();   // the next tile restages the LDS panels
-  }
-}
-
-__global__ __launch_bounds__(256, SMALLM_MINB) void linear_chain_kernel(const LinChainDev c) {
-  __shared__ float lds[Geo<1, 1, 1, 4, SMALLM_KPANEL>::LDS_FLOATS];
-  __shared__ float red[4];
-  const int bx = blockIdx.x;
-  for (int li = 0; li < c.n; ++li) {
-    const LinArgs& a = c.a[li];
-    switch (c.epi[li] * 4 + a.act) {
-      case EPI_ACT * 4 + ACT_NONE: chain_layer<EPI_ACT, ACT_NONE>(a, bx, lds, red); break;
-      case EPI_ACT * 4 + ACT_RELU: chain_layer<EPI_ACT, ACT_RELU>(a, bx, lds, red); break;
-      case EPI_ACT * 4 + ACT_SOFTPLUS: chain_layer<EPI_ACT, ACT_SOFTPLUS>(a, bx, lds, red); break;
-      case EPI_DACT * 4 + ACT_NONE: chain_layer<EPI_DACT, ACT_NONE>(a, bx, lds, red); break;
-      case EPI_DACT * 4 + ACT_RELU: chain_layer<EPI_DACT, ACT_RELU>(a, bx, lds, red); break;
-      case EPI_DACT * 4 + ACT_SOFTPLUS: chain_layer<EPI_DACT, ACT_SOFTPLUS>(a, bx, lds, red); break;
-      case EPI_CHAIN * 4 + ACT_SOFTPLUS: chain_layer<EPI_CHAIN, ACT_SOFTPLUS>(a, bx, lds, red); break;
-      default: break;
-    }
-    __threadfence_block();   // this workgroup's stores are visible to its own later loads
-    __syncthreads();
-  }
-}
-
 // M[n][k] -> packed[nb][kc][lane][j], n = nb*32 + (lane&31), k = kc*8 + 4*(lane>>5) + j
 __global__ void pack_weight_kernel(const float* __restrict__ W, int ldw, int nout, int K, int transpose,
                                    float* __restrict__ out, int kchunks, size_t total4) {
@@ -593,7 +550,6 @@ int launch_pack_weight(const float* W, int ldw, int nout, int k, bool transpose,
 }
 
 int launch_pack_batch(const PackItem* items, int n, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   for (int start = 0; start < n; start += PACK_BATCH_MAX) {
     PackBatchDev b;
     b.n = n - start < PACK_BATCH_MAX ? n - start : PACK_BATCH_MAX;
@@ -612,7 +568,7 @@ int launch_pack_batch(const PackItem* items, int n, hipStream_t st) {
   return 0;
 }
 
-// argument validation shared by launch_linear and the chain builder
+// argument validation of launch_linear
 int validate_linear(const LinArgs& a, int epi) {
   ARDAE_CHECK_ARG(a.M > 0 && a.Nout > 0, "linear: empty problem (M=%d, Nout=%d)", a.M, a.Nout);
   ARDAE_CHECK_ARG(a.nsrc >= 1 && a.nsrc <= 2, "linear: nsrc must be 1 or 2");
@@ -642,109 +598,7 @@ int validate_linear(const LinArgs& a, int epi) {
   return 0;
 }
 
-bool chain_eligible(const LinArgs& a, int epi) {
-  // Opt-in (ARDAE_CHAIN=1).  Measured on config #2 (512 images): a 7-layer chain takes 247 us against ~12 us per layer
-  // for separate launches - sixteen workgroups walking column panels and layers serially lose more to exposed staging
-  // latency than the launches cost.  Kept for the small-batch regime; results are identical (tests run both ways).
-  static const bool on = getenv("ARDAE_CHAIN") && atoi(getenv("ARDAE_CHAIN")) == 1;
-  if (!on || epi == EPI_DAE_LOSS || a.M > 4096) return false;
-  const int g = pick_geometry(a.M, a.Nout);
-  if (g == 2) return false;
-  if (g == 0 && a.colsum != nullptr) return false;   // narrow layers run on the 32 x 128 tile inside a chain: no column sums there
-  return true;
-}
-
-int chain_flush(LinChain& c) {
-  const int n = c.n;
-  c.n = 0;
-  if (n == 0) return 0;
-  if (c.wide) {
-    c.wide = false;
-    if (n == linear_fchain_length()) return launch_linear_fchain(c.a, n, c.epi[0], c.st);
-    for (int i = 0; i < n; ++i) ARDAE_TRY(launch_linear(c.a[i], c.epi[i], c.st));   // not a full chain: layer by layer
-    return 0;
-  }
-  if (n == 1) return launch_linear(c.a[0], c.epi[0], c.st);
-  LinChainDev d;
-  d.n = n;
-  double fl = 0, by = 0;
-  for (int i = 0; i < n; ++i) {
-    d.a[i] = c.a[i];
-    d.epi[i] = c.epi[i];
-    double ksum = 0;
-    for (int s = 0; s < c.a[i].nsrc; ++s) ksum += c.a[i].src[s].K;
-    fl += 2.0 * c.a[i].M * (double)c.a[i].Nout * ksum;
-    by += 4.0 * ((double)c.a[i].M * ksum + 2.0 * c.a[i].M * (double)c.a[i].Nout + ksum * c.a[i].Nout);
-  }
-  for (int i = n; i < LIN_CHAIN_MAX; ++i) d.epi[i] = 0;
-  if (g_prof_enabled) {
-    char name[64];
-    snprintf(name, sizeof(name), "linear_chain_kernel<%d layers>", n);
-    prof_begin(c.st, name, fl, by);
-  }
-  hipLaunchKernelGGL(linear_chain_kernel, dim3(ceil_div(c.M, 32)), dim3(256), 0, c.st, d);
-  prof_end(c.st);
-  ARDAE_LAUNCH_CHECK();
-  return 0;
-}
-
-int chain_add(LinChain& c, const LinArgs& a, int epi) {
-  ARDAE_TRY(validate_linear(a, epi));
-  if (linear_fchain_layer_ok(a, epi)) {
-    // an N-row layer joins the pending chain only if it provably consumes the previous layer's output row by row
-    if (c.n > 0) {
-      const LinArgs& p = c.a[c.n - 1];
-      const bool joins = c.wide && c.n < linear_fchain_length() && a.M == c.M && epi == c.epi[0] && a.src[0].x == p.Y && a.src[0].ld == p.ldY &&
-                         (epi != EPI_DACT || ((a.Q != nullptr) == (c.a[0].Q != nullptr)));
-      if (!joins) ARDAE_TRY(chain_flush(c));
-    }
-    c.wide = true;
-    c.M = a.M;
-    c.a[c.n] = a;
-    c.epi[c.n] = epi;
-    ++c.n;
-    if (c.n == linear_fchain_length()) return chain_flush(c);
-    return 0;
-  }
-  if (c.wide) ARDAE_TRY(chain_flush(c));
-  if (!chain_eligible(a, epi)) {
-    ARDAE_TRY(chain_flush(c));
-    return launch_linear(a, epi, c.st);
-  }
-  if (c.n > 0 && (a.M != c.M || c.n == LIN_CHAIN_MAX)) ARDAE_TRY(chain_flush(c));
-  c.M = a.M;
-  c.a[c.n] = a;
-  c.epi[c.n] = epi;
-  ++c.n;
-  return 0;
-}
-
-namespace {
-thread_local LinChain* g_active_chain = nullptr;
-}
-
-ChainScope::ChainScope(hipStream_t st) : chain(st), prev(g_active_chain) { g_active_chain = &chain; }
-ChainScope::~ChainScope() {
-  (void)chain_flush(chain);
-  g_active_chain = prev;
-}
-int ChainScope::finish() { return chain_flush(chain); }
-
-int flush_active_chain() { return g_active_chain ? chain_flush(*g_active_chain) : 0; }
-
-int linear_or_chain(const LinArgs& a, int epi, hipStream_t st) {
-  if (g_active_chain && g_active_chain->st == st) return chain_add(*g_active_chain, a, epi);
-  return launch_linear(a, epi, st);
-}
-
 int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
-  if (g_active_chain && g_active_chain->n > 0) {   // a direct launch must not overtake pending chain layers
-    LinChain* c = g_active_chain;
-    g_active_chain = nullptr;                      // chain_flush of a single layer re-enters launch_linear
-    const int rc = chain_flush(*c);
-    g_active_chain = c;
-    if (rc != 0) return rc;
-  }
   ARDAE_CHECK_ARG(a.M > 0 && a.Nout > 0, "linear: empty problem (M=%d, Nout=%d)", a.M, a.Nout);
   ARDAE_CHECK_ARG(a.nsrc >= 1 && a.nsrc <= 2, "linear: nsrc must be 1 or 2");
   for (int s = 0; s < a.nsrc; ++s)

@@ -1,6 +1,6 @@
 // Dispatcher of the software-pipelined wide linear kernel (template code: linear_wide_kernel.h; the kernels are
 // instantiated per epilogue / activation in linear_wide_inst_*.hip so that the build parallelises).
-#include "linear_fchain_kernel.h"
+#include "linear_wide_kernel.h"
 
 namespace ardae {
 namespace wide {
@@ -72,32 +72,6 @@ bool linear_wide_eligible(const LinArgs& a, int epi) {
   const int64_t ldmax = std::max<int64_t>({a.ldY, a.ldY2, a.ldS, a.ldR, a.ldQ});
   if (ldmax * 8 * 4 >= (int64_t)1 << 31) return false;
   return true;
-}
-
-// One layer of a fused chain (linear_fchain_kernel.h): an N-row 256 -> 256 softplus layer that the single-layer wide
-// kernel would take
-bool linear_fchain_layer_ok(const LinArgs& a, int epi) {
-  // Opt-in (ARDAE_FCHAIN=1) until the fused kernels fit the register budget: tools/check_kernel_registers.py reports
-  // accum_offset 256 for them, i.e. the compiler spills, and a spill of an in-flight register is a wrong result.
-  static const bool on = getenv("ARDAE_FCHAIN") && atoi(getenv("ARDAE_FCHAIN")) == 1;
-  if (!on || !linear_wide_eligible(a, epi)) return false;
-  if (a.nsrc != 1 || a.src[0].K != 256 || a.Nout != 256 || a.act != ACT_SOFTPLUS) return false;
-  return epi == EPI_ACT || epi == EPI_DACT || epi == EPI_CHAIN;
-}
-
-int linear_fchain_length() { return wide::FC_NL; }
-
-// layers[i+1].src[0].x == layers[i].Y (checked by the caller), same M, same epilogue kind, DACT: all with or all without Q
-int launch_linear_fchain(const LinArgs* layers, int nl, int epi, hipStream_t st) {
-  switch (epi) {
-    case EPI_ACT: return wide::launch_fchain<EPI_ACT, ACT_SOFTPLUS, true, true>(layers, nl, st);
-    case EPI_DACT:
-      return layers[0].Q ? wide::launch_fchain<EPI_DACT, ACT_SOFTPLUS, true, false>(layers, nl, st)
-                         : wide::launch_fchain<EPI_DACT, ACT_SOFTPLUS, false, false>(layers, nl, st);
-    case EPI_CHAIN: return wide::launch_fchain<EPI_CHAIN, ACT_SOFTPLUS, false, false>(layers, nl, st);
-  }
-  ARDAE_CHECK_ARG(false, "fchain: unsupported epilogue %d", epi);
-  return -1;
 }
 
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st) {

@@ -178,7 +178,7 @@ void carve(const ModelLayout& P, Bump& ws, int B, int nz, int mode, ModelWs& W) 
 int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
   a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
   a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;
-  return linear_or_chain(a, epi, st);
+  return launch_linear(a, epi, st);
 }
 
 // sampler trunk (once per image): inp_encode on B rows, then rb = inp . S_1[:, :h]^T + b_S1.  Fills W.e, W.rb.
@@ -218,7 +218,7 @@ int encode_stack(const ModelLayout& P, const ModelPacked& K, const float* params
       A.src[n].x = noise; A.src[n].ld = P.nd; A.src[n].K = P.nd; A.src[n].wp = packed + K.sn_f[i]; ++n;
     }
     A.nsrc = n;
-    ARDAE_TRY(linear_or_chain(A, EPI_ACT, st));
+    ARDAE_TRY(launch_linear(A, EPI_ACT, st));
   }
   return 0;
 }
@@ -229,7 +229,6 @@ int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, 
   ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
   ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, W.z, st));
   if (z_out) {
-    ARDAE_TRY(flush_active_chain());
     ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   return 0;
@@ -274,7 +273,6 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   if (d->kind == 4) return auxconv_model_pack(*d, params, packed, st);
   if (d->kind == 3) return aux_model_pack(*d, params, packed, st);
   if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
@@ -318,10 +316,9 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 0));
   ARDAE_CHECK_ARG(z_out, "model_encode: z_out is NULL");
   hipStream_t st = (hipStream_t)stream;
-  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   if (d->kind == 3) {
     ARDAE_TRY(aux_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st));
-    return chain_scope.finish();
+    return 0;
   }
   if (d->kind == 4) return auxconv_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st);
   if (d->kind == 2) return conv_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, st);
@@ -333,13 +330,12 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   const float* nz_ptr = noise;
   if (!noise) {   // encode(x, std=0): the reference multiplies its draw by 0
     float* zero = ws.take((size_t)B * nz * P.nd);
-    ARDAE_TRY(flush_active_chain());
     ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * nz * P.nd * sizeof(float), st));
     nz_ptr = zero;
   }
   ARDAE_CHECK_ARG(ws.ok, "model_encode: internal workspace accounting error");
   ARDAE_TRY(encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, st));
-  return chain_scope.finish();
+  return 0;
 }
 
 int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
@@ -356,7 +352,6 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
     return ardae_model_encode(d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, stream);
   }
   hipStream_t st = (hipStream_t)stream;
-  ChainScope chain_scope(st);
   const ModelLayout P(*d);
   const ModelPacked K(P);
   Bump ws(workspace, workspace_floats_);
@@ -372,7 +367,7 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
     ARDAE_TRY(encode_stack(P, K, params, packed, zero, B, 1, W.rb, t0, z0_out, st));    // encode(x, std=0): the draw is multiplied by 0
   }
   if (phase != 1) ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, st));   // forward_hidden(x, nz); W.rb from phase 1
-  return chain_scope.finish();
+  return 0;
 }
 
 int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B, float* workspace,
@@ -381,10 +376,9 @@ int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, co
   ARDAE_CHECK_ARG(d->kind == 3 || d->kind == 4, "model_encode_hidden: the hidden1a context exists for the aux models only (kinds 3, 4)");
   ARDAE_CHECK_ARG(hidden_out, "model_encode_hidden: hidden_out is NULL");
   hipStream_t st = (hipStream_t)stream;
-  ChainScope chain_scope(st);
   if (d->kind == 4) ARDAE_TRY(auxconv_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
   else ARDAE_TRY(aux_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
-  return chain_scope.finish();
+  return 0;
 }
 
 int ardae_model_decode(const ardae_model_desc* d, const float* params, const float* packed, const float* z, int R, float* workspace,
@@ -401,16 +395,14 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
   }
   if (d->kind == 3) {
     ARDAE_CHECK_ARG(workspace_floats_ >= aux_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
-    ChainScope aux_scope((hipStream_t)stream);
     ARDAE_TRY(aux_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream));
-    return aux_scope.finish();
+    return 0;
   }
   const ModelLayout P(*d);
   const ModelPacked K(P);
   ARDAE_CHECK_ARG(P.kind == 0 || out1, "model_decode: the Gaussian decoder needs out1 (logvar)");
   ARDAE_CHECK_ARG(workspace_floats_ >= P.dec.size() * al64((size_t)R * P.h), "model_decode: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   Bump ws(workspace, workspace_floats_);
   const int h = P.h;
   const float* cur = z;
@@ -440,10 +432,9 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && z_out && losses, "model_vae_forward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
-  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   if (d->kind == 3) {
     ARDAE_TRY(aux_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st));
-    return chain_scope.finish();
+    return 0;
   }
   if (d->kind == 4) return auxconv_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
   if (d->kind == 2) return conv_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
@@ -474,7 +465,6 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
 static int vae_backward_impl(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* noise,
                              int B, int nz, float beta, float dloss, const float* dz_extra, float seed_scale, float* workspace,
                              size_t workspace_floats_, float* grads, float grads_beta, int phases, hipStream_t st) {
-  ChainScope chain_scope(st);   // consecutive per-image layers run as one launch (linear.h)
   const ModelLayout P(*d);
   const ModelPacked K(P);
   Bump ws(workspace, workspace_floats_);
@@ -490,7 +480,7 @@ static int vae_backward_impl(const ardae_model_desc* d, const float* params, con
   {
     LinArgs A{}; A.S = W.dcd[ndec]; A.ldS = h; A.Y = W.ddec[ndec]; A.ldY = h; A.M = R; A.Nout = h; A.act = act; A.nsrc = (int)nh;
     for (size_t k = 0; k < nh; ++k) { A.src[k].x = W.dox[k]; A.src[k].ld = P.D; A.src[k].K = P.D; A.src[k].wp = packed + K.head_b[k]; }
-    ARDAE_TRY(linear_or_chain(A, EPI_DACT, st));
+    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
   }
   for (size_t l = ndec; l >= 2; --l) {
     LinArgs A{}; A.S = W.dcd[l - 1]; A.ldS = h; A.Y = W.ddec[l - 1]; A.ldY = h;
@@ -501,7 +491,7 @@ static int vae_backward_impl(const ardae_model_desc* d, const float* params, con
     ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, R, P.zd, W.ddec[1], h, h, packed + K.dec_b[0], A, st));
   }
   }
-  if (!(phases & 2)) return chain_scope.finish();
+  if (!(phases & 2)) return 0;
   if (phases == 2 && dz_extra) ARDAE_TRY(launch_axpy(dz_extra, (int64_t)R * P.zd, seed_scale, W.dz, st));   // + the entropy seed
   // sampler backward
   for (size_t i = ns - 1; i >= 1; --i) {
@@ -561,15 +551,12 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
   if (d->kind == 2) {
-    ChainScope chain_scope(st);
     return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
   if (d->kind == 4) {
-    ChainScope chain_scope(st);
     return auxconv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
   if (d->kind == 3) {
-    ChainScope chain_scope(st);
     return aux_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
   return vae_backward_impl(d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, 1.f, workspace, workspace_floats_, grads, grads_beta, 3, st);

@@ -282,7 +282,6 @@ int wgrad_splits(int M, int O, int I, int nproblems_hint) {
 }
 
 int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
-  ARDAE_TRY(flush_active_chain());
   ARDAE_CHECK_ARG(probs && nprob >= 1 && nprob <= WGRAD_MAX_PROBLEMS, "wgrad: 1..%d problems per batch (got %d)",
                   WGRAD_MAX_PROBLEMS, nprob);
   // the big regular problems go to the software-pipelined kernel (which may lower their split count), the rest to

@@ -335,12 +335,13 @@ class ArdaeEngine:
             b = float(self.cfg.beta if beta is None else beta)
             # static copies of the batches (one per DISTINCT batch object: --num-cdae-updates k on one tensor shares its copy)
             if self._xc is None or len(self._xc) != len(xs):
-                self._xc, self._xv, self._graph = [torch.empty_like(x) for x in xs], torch.empty_like(x_vae), None
-            for buf, x in zip(self._xc, xs):
+                flat = lambda: torch.empty(self.B, self.model.input_dim, device=self.dev, dtype=torch.float32)
+                self._xc, self._xv, self._graph = [flat() for _ in xs], flat(), None
+            for buf, x in zip(self._xc, xs):      # batches were validated above: B x input_dim contiguous floats, whatever their view shape
                 if x is not buf:
-                    buf.copy_(x)
+                    buf.copy_(x.view(self.B, -1))
             if x_vae is not self._xv:
-                self._xv.copy_(x_vae)
+                self._xv.copy_(x_vae.view(self.B, -1))
             key = (b, tuple(tuple(x.shape) for x in self._xc), tuple(self._xv.shape))
             # beta annealing (utils/msc.py:53-55) changes a frozen kernel argument every step: capture only once beta has stood
             # still for two steps, run eagerly while it moves (a capture per step would cost far more than replay saves)

@@ -223,10 +223,11 @@ def test_cdae_loss_grads_shipped_recipe_shape():
     test_cdae_loss_grads_vs_oracle("grad", 16, 625, 32, 256, 5)
 
 
-@pytest.mark.parametrize("knob", ["ARDAE_FCHAIN", "ARDAE_CHAIN", "ARDAE_WIDE=0", "ARDAE_WGRAD_WIDE=0", "ARDAE_SMALL=0", "ARDAE_NARROW=0"])
+@pytest.mark.parametrize("knob", ["ARDAE_WIDE=0", "ARDAE_WGRAD_WIDE=0", "ARDAE_SMALL=0", "ARDAE_NARROW=0"])
 def test_cdae_nrow_kernels_opt_in_variants(knob):
-    """The opt-in / fallback code paths (fused N-row layer chains, per-image layer chains, generic linear and weight-gradient
-    kernels, the generic kernel in place of the per-image split-K and the narrow streaming kernels) must give the same answers as the defaults: the library reads its knobs once per process, so the 8192-row
+    """The generic kernels that ragged shapes fall back to (generic linear and weight-gradient kernels, the generic kernel in place of the
+    per-image split-K and the narrow streaming kernels) must give the same answers as the shape-specialised defaults at a shape both
+    can run: the library reads its debug knobs once per process, so the 8192-row
     oracle comparison is re-run in a child process with the knob set."""
     import subprocess
     import sys
