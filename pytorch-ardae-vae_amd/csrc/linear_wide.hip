@@ -20,21 +20,25 @@ using namespace wide;
 
 bool al16w(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// supported K layouts: one source of K = 256 (four 64-wide panels) or K = 32 (one 32-wide panel) - the shapes of the
-// N-row layers of the reference's MLP models (h_dim 256, z_dim 32); anything else runs on linear_kernel
-int wide_panels(const LinArgs& a, int& nch) {
+// supported K layouts (the wave's weight slab, 32 NJ columns x K, must fit its 256 AGPRs): one source of K = 256 (four 64-wide
+// panels) or K = 32 (one 32-wide panel) with two column blocks per wave (workgroup = 256 columns), or K = 512 (eight panels)
+// with one column block per wave (workgroup = 128 columns) - the N-row layers of the reference's MLP models at h_dim 256 / 512,
+// z_dim 32; anything else runs on linear_kernel
+int wide_panels(const LinArgs& a, int& nch, int& nj) {
   if (a.nsrc != 1) return 0;
-  if (a.src[0].K == 256) { nch = 8; return 4; }
-  if (a.src[0].K == 32) { nch = 4; return 1; }
+  if (a.src[0].K == 256) { nch = 8; nj = 2; return 4; }
+  if (a.src[0].K == 32) { nch = 4; nj = 2; return 1; }
+  if (a.src[0].K == 512) { nch = 8; nj = 1; return 8; }
   return 0;
 }
 
 template <int EPI, int ACT, bool F1, bool F2>
 int launch_wide_nch(const LinArgs& a, hipStream_t st) {
-  int nch = 0;
-  wide_panels(a, nch);
-  if (nch == 4) return launch_wide<4, 1, EPI, ACT, F1, F2>(a, st);
-  return launch_wide<8, 4, EPI, ACT, F1, F2>(a, st);
+  int nch = 0, nj = 0;
+  const int np = wide_panels(a, nch, nj);
+  if (np == 8) return launch_wide<8, 8, 1, EPI, ACT, F1, F2>(a, st);
+  if (nch == 4) return launch_wide<4, 1, 2, EPI, ACT, F1, F2>(a, st);
+  return launch_wide<8, 4, 2, EPI, ACT, F1, F2>(a, st);
 }
 
 template <int EPI, int ACT>
@@ -56,21 +60,22 @@ int launch_wide_flags(const LinArgs& a, hipStream_t st) {
 }  // namespace
 
 bool linear_wide_eligible(const LinArgs& a, int epi) {
-  if (a.M <= 0 || (a.M % WBM) || a.Nout <= 0 || (a.Nout % 256)) return false;
-  if ((int64_t)(a.M / WBM) * (a.Nout / 256) < 128) return false;   // small problems: the 32 x 128 tiling fills the chip better
+  int nch = 0, nj = 0;
+  if (wide_panels(a, nch, nj) == 0) return false;
+  const int wgcols = 128 * nj;                                      // columns per workgroup
+  if (a.M <= 0 || (a.M % WBM) || a.Nout <= 0 || (a.Nout % wgcols)) return false;
+  if ((int64_t)(a.M / WBM) * (a.Nout / wgcols) < 128) return false;   // small problems: the 32 x 128 tiling fills the chip better
   for (int s = 0; s < a.nsrc; ++s) {
     if (a.src[s].K % 32 || (a.src[s].ld & 3) || !al16w(a.src[s].x)) return false;
-    if ((int64_t)a.src[s].ld * WBM * 4 >= (int64_t)1 << 31) return false;   // 32-bit lane offsets
+    if ((int64_t)a.src[s].ld * a.M * 4 >= (int64_t)1 << 32) return false;   // 32-bit buffer offsets
   }
   if (epi == EPI_DAE_LOSS) return false;   // Nout = z_dim there (narrow geometry)
-  int nch = 0;
-  if (wide_panels(a, nch) == 0) return false;
-  if (256 % (a.Nout / 256)) return false;   // a workgroup keeps its column panel
+  if (256 % (a.Nout / wgcols)) return false;   // a workgroup keeps its column panel
   if (epi == EPI_ACT && a.rowbias && (a.rows_per_group <= 0 || a.rows_per_group % WBM)) return false;   // group must be tile-uniform
   if (epi == EPI_ACT && a.rowscale && !a.rowscale_w) return false;
   // 32-bit per-lane byte offsets in the epilogue
   const int64_t ldmax = std::max<int64_t>({a.ldY, a.ldY2, a.ldS, a.ldR, a.ldQ});
-  if (ldmax * 8 * 4 >= (int64_t)1 << 31) return false;
+  if (ldmax * a.M * 4 >= (int64_t)1 << 32) return false;   // every epilogue tensor behind a 32-bit buffer offset
   return true;
 }
 

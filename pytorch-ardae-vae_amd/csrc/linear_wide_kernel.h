@@ -146,25 +146,31 @@ __device__ __forceinline__ void bload4(f32x4& dst, unsigned voff, const i32x4& r
 __device__ __forceinline__ void gload4_agpr(f32x4& dst, unsigned voff, const float* sbase) {
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
-// acc += A x B (one k-pair); FIRST: the tile's first MFMA of this accumulator (SrcC = 0, no zero-initialisation needed)
-template <bool FIRST>
+// acc += A x B (one k-pair); FIRST: the tile's first MFMA of this accumulator (SrcC = 0, no zero-initialisation needed);
+// LAST: the tile's very last MFMA.  The hazard recogniser does not see inline-asm MFMAs, and the compiler is free to put its own
+// instructions (register copies of the accumulators, seen in the K = 512 instantiation) right behind the asm statement, so the
+// 16-pass MFMA's 18 wait states before a vector-ALU read of its result are part of the SAME asm statement (the other
+// accumulators' last MFMAs are older by 64 cycles each).
+template <bool FIRST, bool LAST>
 __device__ __forceinline__ void mfma_vab(f32x16& acc, float a, float b) {
   if (FIRST) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
+  else if (LAST) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(acc) : "v"(a), "a"(b));
   else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
 }
 
 // The order in which chunk g = p * NCH + c of a tile issues its memory operations behind its 16 MFMAs:
 //   2 fragment reads A(g + 1) | c == 0: NX panel loads (next panel) | c == XW: NX panel LDS writes
-//   | deferred stores of the PREVIOUS tile | 2 row-bias loads | epilogue-operand loads of THIS tile
+//   | deferred stores of the PREVIOUS tile | NJ row-bias loads | epilogue-operand loads of THIS tile
+// (NJ = 32-column blocks per wave: 2 for K <= 256, 1 for K = 512 - the wave's slab is 32 NJ columns x K = at most 256 registers)
 // Stores come first (chunks [0, GS)), operand loads after them (chunks [GS, GE)), in half-block order, into the registers
 // the stores have just read; the last GE .. G chunks carry none, so that the last operand has landed when the K loop ends.
-template <int NCH, int NP, int NLT, int NST, bool HP>
+template <int NCH, int NP, int NJ, int NLT, int NST, bool HP>
 struct Sched {
   static constexpr int NX = PanelGeo<NCH>::NX;
   static constexpr int G = NP * NCH;
   static constexpr bool DEFER = NP >= 2;                       // with a single panel per tile the epilogue stores at once
-  static constexpr int NSTO = (DEFER && HP) ? 64 * NST : 0;    // HP: there is a previous tile whose results wait in registers
-  static constexpr int NLD = 64 * NLT;
+  static constexpr int NSTO = (DEFER && HP) ? 32 * NJ * NST : 0;    // HP: there is a previous tile whose results wait in registers
+  static constexpr int NLD = 32 * NJ * NLT;
   static constexpr int XW = NCH - 3, BAR = NCH - 2;
   static constexpr int GE = G >= 16 ? G - 5 : G - 1;
   static constexpr int GS = (NSTO + NLD) == 0 ? 0 : NLD == 0 ? GE : (GE * NSTO + (NSTO + NLD) / 2) / (NSTO + NLD);
@@ -174,7 +180,7 @@ struct Sched {
   static constexpr int st_hi(int g) { return g >= GS ? NSTO : NSTO * (g + 1) / DS; }
   static constexpr int ld_lo(int g) { return g < GS ? 0 : g >= GE ? NLD : NLD * (g - GS) / DL; }
   static constexpr int ld_hi(int g) { return g < GS ? 0 : g >= GE ? NLD : NLD * (g - GS + 1) / DL; }
-  static constexpr int n_rb(int g) { return g == GRB ? 2 : 0; }
+  static constexpr int n_rb(int g) { return g == GRB ? NJ : 0; }
   static constexpr int vmem(int g) { return (st_hi(g) - st_lo(g)) + n_rb(g) + (ld_hi(g) - ld_lo(g)); }   // without the panel loads
   // vector-memory operations younger than the panel loads of chunk (p, 0) when chunk (p, XW) moves them to LDS
   static constexpr int vm_panel(int p) {
@@ -190,8 +196,9 @@ struct Sched {
 // SGPRs, per-lane column offset in one VGPR per tensor): no vector-ALU work per access.
 // F1 / F2:  EPI_ACT: F1 = score seed Y2, F2 = per-row scale (sigma column);  EPI_DACT: F1 = additive Q;  EPI_CHAIN: unused
 // ---------------------------------------------------------------------------------------------------------------------
-template <int EPI, int ACT, bool F1, bool F2>
+template <int EPI, int ACT, bool F1, bool F2, int NJ_ = 2>
 struct WideEpi {
+  static constexpr int NJ = NJ_;                           // 32-column blocks per wave
   static constexpr int NLT = EPI == EPI_ACT ? (F2 ? 1 : 0) : EPI == EPI_DACT ? (F1 ? 2 : 1) : 2;   // tensors loaded per element
   static constexpr int NST = EPI == EPI_ACT ? (F1 ? 2 : 1) : EPI == EPI_DACT ? 1 : 2;              // tensors stored per element
   static constexpr bool SIGMA_OPERAND = EPI == EPI_ACT;   // its one loaded operand (F2) is the per-row sigma
@@ -234,7 +241,7 @@ struct WideEpi {
     colw_loaded = colw;
     const int l31 = lane & 31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int col = colw + 32 * j + l31;
       bcol[j] = a.bias ? a.bias[col] : 0.f;
       wsig[j] = (F2 && a.rowscale_w) ? a.rowscale_w[col] : 0.f;
@@ -306,32 +313,37 @@ struct WideEpi {
 
   __device__ __forceinline__ void store_all(const float* y, const float* y2, int row0, int colw) const {
     stores<0>(y + 0, y2 + 0, row0, colw); stores<1>(y + 8, y2 + 8, row0, colw); stores<2>(y + 16, y2 + 16, row0, colw);
-    stores<3>(y + 24, y2 + 24, row0, colw); stores<4>(y + 32, y2 + 32, row0, colw); stores<5>(y + 40, y2 + 40, row0, colw);
-    stores<6>(y + 48, y2 + 48, row0, colw); stores<7>(y + 56, y2 + 56, row0, colw);
+    stores<3>(y + 24, y2 + 24, row0, colw);
+    if constexpr (NJ == 2) {
+      stores<4>(y + 32, y2 + 32, row0, colw); stores<5>(y + 40, y2 + 40, row0, colw);
+      stores<6>(y + 48, y2 + 48, row0, colw); stores<7>(y + 56, y2 + 56, row0, colw);
+    }
   }
 
   template <int VM, bool STORE_NOW>
-  __device__ __forceinline__ void run(f32x16 (&acc)[2][2], float* l0, float* l1, float (&rb)[2], int lane, int row0, int colw, int tile_row) const {
+  __device__ __forceinline__ void run(f32x16 (&acc)[2][NJ], float* l0, float* l1, float (&rb)[NJ], int lane, int row0, int colw, int tile_row) const {
     // one wait for everything the epilogue reads (issued >= NCH/2 chunks ago)
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rb[0]), "+v"(rb[1]) : "n"(VM) : "memory");
-    if (NLT >= 1) { wait16<VM>(l0); wait16<VM>(l0 + 16); wait16<VM>(l0 + 32); wait16<VM>(l0 + 48); }
-    if (NLT == 2) { wait16<VM>(l1); wait16<VM>(l1 + 16); wait16<VM>(l1 + 32); wait16<VM>(l1 + 48); }
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rb[0]), "+v"(rb[NJ - 1]) : "n"(VM) : "memory");
+    if (NLT >= 1) { wait16<VM>(l0); wait16<VM>(l0 + 16); if (NJ == 2) { wait16<VM>(l0 + 32); wait16<VM>(l0 + 48); } }
+    if (NLT == 2) { wait16<VM>(l1); wait16<VM>(l1 + 16); if (NJ == 2) { wait16<VM>(l1 + 32); wait16<VM>(l1 + 48); } }
     const bool has_rb = EPI == EPI_ACT && a.rowbias != nullptr;
-    const float br0 = bcol[0] + (has_rb ? rb[0] : 0.f), br1 = bcol[1] + (has_rb ? rb[1] : 0.f);
+    const float br0 = bcol[0] + (has_rb ? rb[0] : 0.f), br1 = bcol[1] + (has_rb ? rb[NJ - 1] : 0.f);
     float csum[2] = {0.f, 0.f};
     // one half-block at a time (the scheduler would otherwise interleave all 64 elements and run out of registers)
     math<0>(acc[0][0], l0 + 0, l1 + 0, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
     math<1>(acc[0][0], l0 + 8, l1 + 8, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
     math<2>(acc[1][0], l0 + 16, l1 + 16, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
     math<3>(acc[1][0], l0 + 24, l1 + 24, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
-    math<4>(acc[0][1], l0 + 32, l1 + 32, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
-    math<5>(acc[0][1], l0 + 40, l1 + 40, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
-    math<6>(acc[1][1], l0 + 48, l1 + 48, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
-    math<7>(acc[1][1], l0 + 56, l1 + 56, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NJ == 2) {
+      math<4>(acc[0][1], l0 + 32, l1 + 32, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+      math<5>(acc[0][1], l0 + 40, l1 + 40, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+      math<6>(acc[1][1], l0 + 48, l1 + 48, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+      math<7>(acc[1][1], l0 + 56, l1 + 56, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+    }
     if (STORE_NOW) store_all(l0, l1, row0, colw);
     if (a.colsum != nullptr) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const float c2 = csum[j] + __shfl_xor(csum[j], 32);
         if (lane < 32) a.colsum[(size_t)tile_row * a.Nout + colw + 32 * j + lane] = c2;
       }
@@ -349,19 +361,19 @@ struct PanelCtx {
   int row0, colw, prev_row0;             // prev_row0 < 0: no previous tile (nothing to store yet)
 };
 
-// One chunk: wait for its A fragments (LDS), then 16 MFMAs with the chunk's memory instructions spread evenly behind them
+// One chunk: wait for its A fragments (LDS), then 8 NJ MFMAs with the chunk's memory instructions spread evenly behind them
 // (an MFMA keeps the pipe busy for 64 cycles while the wave is free to issue; with one wave per SIMD nobody else would fill
 // a gap, and more than a handful of instructions behind one MFMA is a gap).
 template <int C, int P, int NCH, int NP, bool HP, class EPI_T>
 struct ChunkOps {
-  using SC = Sched<NCH, NP, EPI_T::NLT, EPI_T::NST, HP>;
+  using SC = Sched<NCH, NP, EPI_T::NJ, EPI_T::NLT, EPI_T::NST, HP>;
   static constexpr int NX = PanelGeo<NCH>::NX;
-  static constexpr int NLT = EPI_T::NLT, NST = EPI_T::NST;
+  static constexpr int NLT = EPI_T::NLT, NST = EPI_T::NST, NJ = EPI_T::NJ, NMF = 8 * EPI_T::NJ;   // NMF: MFMAs per chunk
   static constexpr int GC = P * NCH + C;
   static constexpr int n_a = 2, n_x = C == 0 ? NX : 0, n_w = C == SC::XW ? NX : 0, n_st = SC::st_hi(GC) - SC::st_lo(GC), n_rb = SC::n_rb(GC),
                        n_op = SC::ld_hi(GC) - SC::ld_lo(GC);
   static constexpr int o_a = 0, o_x = o_a + n_a, o_w = o_x + n_x, o_st = o_w + n_w, o_rb = o_st + n_st, o_op = o_rb + n_rb, total = o_op + n_op;
-  static constexpr int PER = (total + 15) / 16;   // instructions behind each MFMA
+  static constexpr int PER = (total + NMF - 1) / NMF;   // instructions behind each MFMA
 
   // running scalar byte offsets of the store / operand streams (bumped by one row per instruction)
   struct Ptrs {
@@ -369,7 +381,7 @@ struct ChunkOps {
   };
 
   template <int K>
-  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&xv)[NX], float* l0, float* l1, float (&rb)[2], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
+  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&xv)[NX], float* l0, float* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     using PG = PanelGeo<NCH>;
     const EPI_T& ep = x.epi;
     if constexpr (K < o_x) {   // fragment read of the next chunk (chunk 0 of the next panel after the last one)
@@ -401,7 +413,7 @@ struct ChunkOps {
     } else if constexpr (K < o_op) {
       constexpr int k = K - o_rb;
       if constexpr (k == 0) ep.template issue_rowbias_one<0>(rb[0], x.row0, x.colw);
-      else ep.template issue_rowbias_one<1>(rb[1], x.row0, x.colw);
+      else ep.template issue_rowbias_one<1>(rb[NJ - 1], x.row0, x.colw);
     } else {
       constexpr int idx = SC::ld_lo(GC) + (K - o_op);                     // index in the tile's operand-load sequence
       constexpr int HB = idx / (8 * NLT), tns = (idx / 8) % NLT, e = idx % 8;
@@ -425,7 +437,7 @@ struct ChunkOps {
 
   // the instructions behind MFMA S
   template <int S, int R = 0>
-  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&xv)[NX], float* l0, float* l1, float (&rb)[2], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
+  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&xv)[NX], float* l0, float* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     if constexpr (R < PER && S * PER + R < total) {
       op<S * PER + R>(A, xv, l0, l1, rb, x, q);
       slot<S, R + 1>(A, xv, l0, l1, rb, x, q);
@@ -433,18 +445,18 @@ struct ChunkOps {
   }
 
   template <int S>
-  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][2], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][2], f32x4 (&xv)[NX], float* l0, float* l1,
-                                               float (&rb)[2], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
-    if constexpr (S < 16) {
-      constexpr int kq = S >> 2, i = (S >> 1) & 1, j = S & 1;
-      mfma_vab<GC == 0 && kq == 0>(acc[i][j], A[C & 1][i][kq], Bw[GC][j][kq]);
+  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], float* l0, float* l1,
+                                               float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
+    if constexpr (S < NMF) {
+      constexpr int kq = S / (2 * NJ), i = (S / NJ) & 1, j = S % NJ;
+      mfma_vab<GC == 0 && kq == 0, GC == NP * NCH - 1 && S == NMF - 1>(acc[i][j], A[C & 1][i][kq], Bw[GC][j][kq]);
       slot<S>(A, xv, l0, l1, rb, x, q);
       steps<S + 1>(acc, A, Bw, xv, l0, l1, rb, x, q);
     }
   }
 
-  static __device__ __forceinline__ void run(f32x16 (&acc)[2][2], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][2], f32x4 (&xv)[NX], float* l0, float* l1,
-                                             float (&rb)[2], const PanelCtx<NCH, EPI_T>& x) {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], float* l0, float* l1,
+                                             float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x) {
     // this chunk's fragments (and, at XW + 1, this wave's panel writes) have landed in / left for LDS
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[C & 1][0]), "+v"(A[C & 1][1]) : : "memory");
     if (C == SC::BAR) __builtin_amdgcn_s_barrier();
@@ -454,8 +466,8 @@ struct ChunkOps {
 };
 
 template <int P, int NCH, int NP, bool HP, class EPI_T>
-__device__ __forceinline__ void panel(f32x16 (&acc)[2][2], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][2], f32x4 (&xv)[PanelGeo<NCH>::NX], float* l0, float* l1,
-                                      float (&rb)[2], const PanelCtx<NCH, EPI_T>& x) {
+__device__ __forceinline__ void panel(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], float* l0, float* l1,
+                                      float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x) {
   ChunkOps<0, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
   ChunkOps<1, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
   ChunkOps<2, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
@@ -471,8 +483,8 @@ __device__ __forceinline__ void panel(f32x16 (&acc)[2][2], f32x4 (&A)[2][2], con
 // panels P .. NP-1 of one tile, straight-line: values defined by the asm loads must never meet at a control-flow join
 // (the compiler would reconcile them with register copies - of registers whose loads are still in flight)
 template <int P, int NCH, int NP, bool HP, class EPI_T, class PX>
-__device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][2], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][2], f32x4 (&xv)[PanelGeo<NCH>::NX], float* l0,
-                                            float* l1, float (&rb)[2], const EPI_T& epi, const i32x4& rX, unsigned xvoff, unsigned xstep, int& buf,
+__device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], float* l0,
+                                            float* l1, float (&rb)[EPI_T::NJ], const EPI_T& epi, const i32x4& rX, unsigned xvoff, unsigned xstep, int& buf,
                                             unsigned rlane, unsigned wlane, int row0, int colw, int prev_row0, int tile, int tnext, const PX& panel_x) {
   if constexpr (P < NP) {
     constexpr bool lastp = P + 1 == NP;
@@ -487,14 +499,14 @@ __device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][2], f32x4 (&A)[2][2
 
 // NP = K panels per tile (compile time: the tile body is one basic block).  grid % ncp == 0, so a workgroup keeps its
 // column panel: the weight slab and the column-only epilogue operands are loaded once.
-template <int NCH, int NP, int EPI, int ACT, bool F1, bool F2>
-__global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, int ntiles, int ncp) {
+template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
+__global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, int nrt, int ncp) {
   using PG = PanelGeo<NCH>;
-  using EPI_T = WideEpi<EPI, ACT, F1, F2>;
-  using SC = Sched<NCH, NP, EPI_T::NLT, EPI_T::NST, true>;
+  using EPI_T = WideEpi<EPI, ACT, F1, F2, NJ>;
+  using SC = Sched<NCH, NP, NJ, EPI_T::NLT, EPI_T::NST, true>;
   constexpr int NX = PG::NX, G = NP * NCH;
   static_assert(NCH % 2 == 0 && NCH >= 4, "fragment double buffer / XW, BAR chunks");
-  static_assert(2 * G * 4 <= 256, "the weight slab must fit the AGPR file");
+  static_assert(NJ * G * 4 <= 256, "the weight slab must fit the AGPR file");
   __shared__ float lds[NBUF * WBM * WLDW];
 
 #ifdef ARDAE_STAMPS
@@ -508,8 +520,15 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   const unsigned rlane = lds0 + (unsigned)((l31 * WLDW + hh * 4) * 4);                         // fragment reads
   const unsigned wlane = lds0 + (unsigned)(((tid / PG::C4) * WLDW + (tid % PG::C4) * 4) * 4);   // panel stores
 
-  const int cp = (int)blockIdx.x % ncp;
-  const int colw = (cp * 8 + wave * 2) * 32;
+  // Workgroup -> (column panel, row tiles).  With several column panels the workgroups that share a row tile (= read the same
+  // activation rows) are placed on ONE XCD (blocks b and b + 8 share an XCD: MI355X_MICROARCH.md), so that the rows are fetched
+  // from beyond the XCD's L2 once; speed only - any placement is correct.
+  const int b = (int)blockIdx.x, nwg = (int)gridDim.x;
+  const bool xcd_map = ncp > 1 && nwg % (8 * ncp) == 0;
+  const int cp = xcd_map ? (b >> 3) % ncp : b % ncp;
+  const int rt0 = xcd_map ? ((b >> 3) / ncp) * 8 + (b & 7) : b / ncp;
+  const int rts = nwg / ncp;                                // row tiles advance by this much per round
+  const int colw = (cp * 4 * NJ + wave * NJ) * 32;
   EPI_T epi(a, lane);
   epi.column_operands(colw, lane);
 
@@ -518,22 +537,22 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   const i32x4 rX = make_rsrc(a.src[0].x, (unsigned)a.M * ldx4);
   const unsigned xvoff = (unsigned)(tid / PG::C4) * ldx4 + (unsigned)(tid % PG::C4) * 16u;
   const unsigned xstep = (unsigned)PG::RPP * ldx4;
-  auto panel_x = [&](int tile, int p) -> unsigned { return (unsigned)((tile / ncp) * WBM) * ldx4 + (unsigned)(p * 8 * NCH) * 4u; };
+  auto panel_x = [&](int rt, int p) -> unsigned { return (unsigned)(rt * WBM) * ldx4 + (unsigned)(p * 8 * NCH) * 4u; };
 
-  f32x4 A[2][2], Bw[G][2], xv[NX];
-  float l0[64], l1[64], rb[2];
+  f32x4 A[2][2], Bw[G][NJ], xv[NX];
+  float l0[32 * NJ], l1[32 * NJ], rb[NJ];
 #pragma unroll
-  for (int i = 0; i < 64; ++i) l0[i] = l1[i] = 0.f;   // the slots' registers exist from here on (tied asm operands read them)
-  int tile = blockIdx.x;
+  for (int i = 0; i < 32 * NJ; ++i) l0[i] = l1[i] = 0.f;   // the slots' registers exist from here on (tied asm operands read them)
+  int tile = rt0;   // row tile
   // ---- prologue: the wave's weight slab into its AGPRs, first panel into LDS buffer 0, fragment set 0 in flight
   {
     const unsigned bvoff = (unsigned)lane * 16u;
     const int kch = a.src[0].K >> 3;
-    const float* wp = a.src[0].wp + (size_t)(cp * 8 + wave * 2) * kch * 256;
+    const float* wp = a.src[0].wp + (size_t)(cp * 4 * NJ + wave * NJ) * kch * 256;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       gload4_agpr(Bw[g][0], bvoff, wp + (size_t)g * 256);
-      gload4_agpr(Bw[g][1], bvoff, wp + ((size_t)kch + g) * 256);
+      if constexpr (NJ == 2) gload4_agpr(Bw[g][1], bvoff, wp + ((size_t)kch + g) * 256);
     }
     const unsigned x0 = panel_x(tile, 0);
 #pragma unroll
@@ -558,20 +577,20 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
 #ifdef ARDAE_STAMPS
     const unsigned long long T0 = __builtin_amdgcn_s_memtime();
 #endif
-    const int tr = tile / ncp;
+    const int tr = tile;
     const int row0 = tr * WBM;
-    const int tnext = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;   // none: re-touch this tile (never used)
-    f32x16 acc[2][2];
+    const int tnext = tile + rts < nrt ? tile + rts : tile;   // none: re-touch this tile (never used)
+    f32x16 acc[2][NJ];
     tile_panels<0, NCH, NP, HP>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
 #ifdef ARDAE_STAMPS
     const unsigned long long T1 = __builtin_amdgcn_s_memtime();
     t_k += T1 - T0;
 #endif
     // Nothing may be in flight across the epilogue: it is compiler-scheduled code under register pressure, and a spill or
-    // copy of a register whose load has not landed would read garbage.  The s_nop covers the wait states between the last
-    // MFMA (inline asm: invisible to the hazard recogniser) and the first vector-ALU read of an accumulator.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7"
-                 : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1])
+    // copy of a register whose load has not landed would read garbage.  (The wait states between the last MFMA and the first
+    // vector-ALU read of an accumulator are part of that MFMA's asm statement, mfma_vab<.., LAST>.)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(acc[0][0]), "+v"(acc[0][NJ - 1]), "+v"(acc[1][0]), "+v"(acc[1][NJ - 1])
                  :
                  : "memory");
 #ifdef ARDAE_DBG_NOEPI
@@ -580,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
       if (sum == 12345.678f) a.Y[tid] = sum;
@@ -595,7 +614,7 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   };
   // the first tile has no predecessor whose stores could ride in its K loop: its own copy of the tile body
   do_tile(std::false_type{});
-  for (tile += gridDim.x; tile < ntiles; tile += gridDim.x) do_tile(std::integral_constant<bool, SC::DEFER>{});
+  for (tile += rts; tile < nrt; tile += rts) do_tile(std::integral_constant<bool, SC::DEFER>{});
 #ifndef ARDAE_DBG_NOEPI
   if (SC::DEFER && prev_row0 >= 0) epi.store_all(l0, l1, prev_row0, colw);
 #endif
@@ -613,21 +632,21 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
 
 int wide_grid(int ntiles, int ncp);
 
-template <int NCH, int NP, int EPI, int ACT, bool F1, bool F2>
+template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
 int launch_wide(const LinArgs& a, hipStream_t st) {
-  const int ncp = a.Nout / 256;
+  const int ncp = a.Nout / (128 * NJ);
   const int ntiles = (a.M / WBM) * ncp;
   const int grid = wide_grid(ntiles, ncp);
   if (g_prof_enabled) {
     char name[96];
-    snprintf(name, sizeof(name), "linear_wide_kernel<%d, %d, %d, %d, %d, %d>", NCH, NP, EPI, ACT, (int)F1, (int)F2);
+    snprintf(name, sizeof(name), "linear_wide_kernel<%d, %d, %d, %d, %d, %d, %d>", NCH, NP, NJ, EPI, ACT, (int)F1, (int)F2);
     double ksum = 0;
     for (int s = 0; s < a.nsrc; ++s) ksum += a.src[s].K;
     double tensors = 1.0 + (a.Y2 ? 1 : 0) + ((EPI == EPI_DACT || EPI == EPI_CHAIN) ? 1 : 0) + ((EPI == EPI_CHAIN) ? 1 : 0) +
                      ((EPI == EPI_DACT && a.Q) ? 1 : 0);
     prof_begin(st, name, 2.0 * a.M * (double)a.Nout * ksum, 4.0 * ((double)a.M * ksum + tensors * a.M * (double)a.Nout + ksum * a.Nout));
   }
-  hipLaunchKernelGGL((linear_wide_kernel<NCH, NP, EPI, ACT, F1, F2>), dim3(grid), dim3(256), 0, st, a, ntiles, ncp);
+  hipLaunchKernelGGL((linear_wide_kernel<NCH, NP, NJ, EPI, ACT, F1, F2>), dim3(grid), dim3(256), 0, st, a, a.M / WBM, ncp);
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;
@@ -636,8 +655,9 @@ int launch_wide(const LinArgs& a, hipStream_t st) {
 
 // explicit instantiations live in linear_wide_inst_*.hip
 #define ARDAE_WIDE_FOR_GEOS(X, EPI, ACT, F1, F2) \
-  X(8, 4, EPI, ACT, F1, F2)                       \
-  X(4, 1, EPI, ACT, F1, F2)
+  X(8, 4, 2, EPI, ACT, F1, F2)                    \
+  X(4, 1, 2, EPI, ACT, F1, F2)                    \
+  X(8, 8, 1, EPI, ACT, F1, F2)
 #define ARDAE_WIDE_FOR_ACT_FLAGS(X, ACT)          \
   ARDAE_WIDE_FOR_GEOS(X, EPI_ACT, ACT, false, false) \
   ARDAE_WIDE_FOR_GEOS(X, EPI_ACT, ACT, false, true)  \
@@ -646,8 +666,8 @@ int launch_wide(const LinArgs& a, hipStream_t st) {
 #define ARDAE_WIDE_FOR_DACT_FLAGS(X, ACT)          \
   ARDAE_WIDE_FOR_GEOS(X, EPI_DACT, ACT, false, false) \
   ARDAE_WIDE_FOR_GEOS(X, EPI_DACT, ACT, true, false)
-#define ARDAE_WIDE_EXTERN(NCH, NP, EPI, ACT, F1, F2) extern template int launch_wide<NCH, NP, EPI, ACT, F1, F2>(const LinArgs&, hipStream_t);
-#define ARDAE_WIDE_INSTANTIATE(NCH, NP, EPI, ACT, F1, F2) template int launch_wide<NCH, NP, EPI, ACT, F1, F2>(const LinArgs&, hipStream_t);
+#define ARDAE_WIDE_EXTERN(NCH, NP, NJ, EPI, ACT, F1, F2) extern template int launch_wide<NCH, NP, NJ, EPI, ACT, F1, F2>(const LinArgs&, hipStream_t);
+#define ARDAE_WIDE_INSTANTIATE(NCH, NP, NJ, EPI, ACT, F1, F2) template int launch_wide<NCH, NP, NJ, EPI, ACT, F1, F2>(const LinArgs&, hipStream_t);
 #ifndef ARDAE_WIDE_INST_TU
 ARDAE_WIDE_FOR_ACT_FLAGS(ARDAE_WIDE_EXTERN, ACT_NONE)
 ARDAE_WIDE_FOR_ACT_FLAGS(ARDAE_WIDE_EXTERN, ACT_RELU)

@@ -5,7 +5,7 @@ import torch
 import ardae_amd
 from ardae_amd import _lib as L
 from test_linear_gpu import pack
-M, K, N = int(os.environ.get("MROWS", "131072")), 256, 256
+M = int(os.environ.get("MROWS", "131072")); K = N = int(os.environ.get("KN", "256"))
 epi = int(os.environ.get("EPI", "1"))
 X = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / 16
 S = torch.nn.functional.softplus(torch.randn(M, N, device="cuda")); Q = torch.randn(M, N, device="cuda"); R = torch.randn(M, N, device="cuda")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time guard for the inline-asm kernels (linear_wide_kernel.h, linear_fchain_kernel.h, wgrad_wide.hip).
+"""Build-time guard for the inline-asm kernels (linear_wide_kernel.h, wgrad_wide.hip).
 
 Their operand loads are issued by inline asm long before use, so the compiler does not know that those registers are "in
 flight": a register copy or spill it inserts between such a load and the s_waitcnt that lands it reads garbage (seen once:
@@ -8,7 +8,11 @@ disassembles each kernel and scans it linearly:
   * a VGPR becomes in flight when a global_load_* / ds_read_* writes it and lands at the next s_waitcnt with vmcnt(0)
     (global) / lgkmcnt(0) (LDS) - partial counts are ignored, which only makes the check stricter;
   * v_mov_b32 / v_accvgpr_write_b32 / scratch_store / v_writelane reading an in-flight VGPR is a violation;
-  * any scratch usage is a violation.
+  * any scratch usage is a violation;
+  * a vector-ALU instruction that reads the result of an MFMA less than 18 wait states (s_nop) after it issued, with no other
+    MFMA in between, is a violation: linear_wide_kernel's MFMAs are inline asm, which the compiler's hazard recogniser does
+    not see (seen once: register copies of the accumulators placed right behind a tile's last MFMA gave wrong values in the
+    rows that MFMA writes last).
 Usage: check_kernel_registers.py <hipcc> <csrc dir> [file.hip ...]   (exit code 1 on violation)"""
 import os
 import re
@@ -17,7 +21,7 @@ import sys
 import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
-KERNELS = re.compile(r"linear_wide_kernel|linear_fchain_kernel|wgrad_wide_kernel")
+KERNELS = re.compile(r"linear_wide_kernel|wgrad_wide_kernel")
 
 
 def regs(tok):
@@ -30,12 +34,30 @@ def regs(tok):
 
 def scan(code):
     inflight_g, inflight_l, bad = set(), set(), []
+    mfma_dst, mfma_wait = set(), 0      # result registers of the most recent MFMA and the wait states seen since it issued
     for n, line in enumerate(code):
         s = line.split(";")[0].strip()
         if not s or s.endswith(":"):
             continue
         op, _, rest = s.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
+        # inline-asm MFMAs are invisible to the hazard recogniser: a vector-ALU read of a 16-pass MFMA's result needs 18 wait
+        # states; another MFMA in between occupies the pipe for 64 cycles, s_nop N counts N + 1
+        if op.startswith("v_mfma"):
+            mfma_dst, mfma_wait = regs(ops[0]), 0
+            continue
+        if op == "s_nop":
+            mfma_wait += int(rest.strip(), 0) + 1
+            continue
+        if mfma_dst and mfma_wait < 18 and op.startswith("v_"):
+            srcs = set()
+            for o in ops[1:]:
+                srcs |= regs(o)
+            hit = srcs & mfma_dst
+            if hit:
+                bad.append((n, s + "   [reads an MFMA result %d wait states after it issued]" % mfma_wait, sorted(hit)))
+        if mfma_dst and not op.startswith("s_") and not op.startswith("ds_") and not op.startswith("buffer_") and not op.startswith("global_"):
+            mfma_wait += 1
         if op == "s_waitcnt":
             if "vmcnt(0)" in rest:
                 inflight_g.clear()
