@@ -73,9 +73,14 @@ __device__ __forceinline__ void gstore1(unsigned voff, float v, float* sbase) {
   else asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 // Epilogue tensors (saved activations in, results out) are addressed through raw buffer descriptors: row base = ONE 32-bit
-// scalar offset (one s_add per access, no 64-bit pointer arithmetic, no descriptor or offset ever written by the vector ALU,
-// hence no s_nop), per-lane part in one VGPR per tensor.  num_records = the tensor's bytes: an access outside of it is
-// dropped by the hardware instead of faulting.
+// scalar offset (one s_add per access, no 64-bit pointer arithmetic), per-lane part in one VGPR per tensor.  num_records = the
+// tensor's bytes: an access outside of it is dropped by the hardware instead of faulting.
+// The s_nop 4 in every vector-memory asm statement is NOT optional: when the compiler runs out of SGPRs it parks them in VGPR
+// lanes and brings them back with v_readlane right before use; a scalar operand (descriptor, offset, base) written by the
+// vector ALU needs 5 wait states before a VMEM instruction reads it, and the hazard recogniser does not look inside inline
+// asm.  Seen twice: a memory fault from the saddr loads of the first version, and again from a buffer descriptor restored by
+// v_readlane in the rolled tile loop of the K = 32 instantiations (one panel per tile: the compiler keeps ~60 induction
+// SGPRs there) when the s_nop had been dropped from the buffer forms.  tools/check_kernel_registers.py enforces it.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
   const unsigned long long a = (unsigned long long)p;
@@ -91,10 +96,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
 // back-edge, and a register budget the compiler cannot exceed by renaming (NLT = NST = 2 needs 128 such slots)
 template <int OFF>
 __device__ __forceinline__ void bload1(float& dst, unsigned voff, const i32x4& rsrc, unsigned soff) {
-  asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen offset:%4" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void bstore1(unsigned voff, float v, const i32x4& rsrc, unsigned soff) {
-  asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void lds_read4(f32x4& dst, unsigned addr) {
@@ -140,7 +145,7 @@ __device__ __forceinline__ void store_panel(const f32x4 (&xv)[NX], unsigned wadd
 }
 template <int OFF>
 __device__ __forceinline__ void bload4(f32x4& dst, unsigned voff, const i32x4& rsrc, unsigned soff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
 }
 // a 1-KiB fragment of the packed weight image straight into four AGPRs
 __device__ __forceinline__ void gload4_agpr(f32x4& dst, unsigned voff, const float* sbase) {

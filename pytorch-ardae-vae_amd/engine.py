@@ -45,7 +45,12 @@ class ArdaeEngine:
     spends between dependent kernels of a stream shrink to a few (measured: 174 -> 151 us per big linear launch).  What
     changes from step to step lives in device memory: a 32-byte step state (Philox base offset, Adam's t and bias
     corrections, `ardae_step_state_advance`) and the two static image buffers the caller's batches are copied into.
-    Noise injection (parity tests), lists of cDAE batches and multi-rank runs fall back to eager launches of the same calls."""
+    Noise injection (parity tests) and lists of cDAE batches fall back to eager launches of the same calls.
+
+    Multi-rank runs (world > 1) replay too: the step is captured as a SEQUENCE of graphs cut at the gradient all-reduces
+    (capture ends where `_allreduce_mean` is reached, the collective runs eagerly between two replays, a new capture starts
+    behind it), so a rank submits three graphs and two collectives per step instead of ~110 launches - whatever the
+    backend (RCCL over xGMI in `bench.py --gpus N`, gloo in the rehearsal tests)."""
 
     RNG_STRIDE = 16   # Philox offsets reserved per step (draws use base + 0, 1, 2, ...)
 
@@ -96,9 +101,9 @@ class ArdaeEngine:
         self.step_count = 0
         # device-resident step state + graph bookkeeping
         self.state = torch.zeros(4, dtype=torch.int64, device=self.dev)
-        self.use_graph = bool(graph) and os.environ.get("ARDAE_GRAPH", "1") != "0" and \
-            (self.world == 1 or os.environ.get("ARDAE_GRAPH_DP") == "1")
+        self.use_graph = bool(graph) and os.environ.get("ARDAE_GRAPH", "1") != "0"
         self._graph, self._graph_key, self._xc, self._xv = None, None, None, None      # _xc: list of static batch buffers
+        self._capture = None          # segmented capture in progress (world > 1): see _allreduce_mean
         self._in_step, self._draws, self._warmed = False, 0, False
         self._last_beta, self._beta_stable = None, 0
         # The first half of the VAE update (sampler + decoder + ELBO pieces on the VAE batch, ~25 per-image launches) needs
@@ -153,7 +158,52 @@ class ArdaeEngine:
                                                    L.ptr(ws), ws.numel(), L.ptr(z0_out), L.ptr(out), L.stream_ptr()), "ardae_model_encode_hidden")
 
     def _allreduce_mean(self, t):
-        dist.allreduce_mean_(t, self.pg)
+        """Average a flat gradient buffer over the ranks.  While a multi-rank step is being captured this is a SEGMENT CUT: the
+        running capture ends here (after the side stream has joined - a graph must not end with a forked stream), the collective
+        is recorded as an eager item of the replay list, and a new capture begins behind it."""
+        if self.world == 1:
+            return
+        cap = self._capture
+        if cap is None:
+            dist.allreduce_mean_(t, self.pg)
+            return
+        if cap["side_open"]:
+            torch.cuda.current_stream().wait_stream(self._side)
+            cap["side_open"] = False
+        cap["ctx"].__exit__(None, None, None)
+        cap["items"] += [cap["graph"], t]
+        cap["graph"] = torch.cuda.CUDAGraph()
+        cap["ctx"] = torch.cuda.graph(cap["graph"], pool=cap["pool"])
+        cap["ctx"].__enter__()
+
+    def _capture_segments(self, xs, x_vae, beta):
+        """Capture one step as graphs cut at the all-reduces; returns the replay list [graph, tensor, graph, tensor, graph]."""
+        cap = {"items": [], "graph": torch.cuda.CUDAGraph(), "pool": torch.cuda.graph_pool_handle(), "side_open": False}
+        cap["ctx"] = torch.cuda.graph(cap["graph"], pool=cap["pool"])
+        cap["ctx"].__enter__()
+        self._capture = cap
+        try:
+            self._step_body(xs, x_vae, None, beta)
+        except BaseException:
+            self._capture = None
+            try:
+                cap["ctx"].__exit__(None, None, None)
+            except Exception:
+                pass
+            raise
+        self._capture = None
+        cap["ctx"].__exit__(None, None, None)
+        return cap["items"] + [cap["graph"]]
+
+    def _replay(self):
+        if isinstance(self._graph, list):
+            for item in self._graph:
+                if torch.is_tensor(item):
+                    dist.allreduce_mean_(item, self.pg)
+                else:
+                    item.replay()
+        else:
+            self._graph.replay()
 
     def _normal(self, out, draw=None):
         """One standard-normal draw.  Inside `step()` the offset comes from the device step state (graph-replayable);
@@ -304,13 +354,25 @@ class ArdaeEngine:
                         self._draws = 3
                         drawn = torch.cuda.Event()
                         drawn.record(self._side)
-                # eager launches reach the GPU in host order: the cDAE phase (the critical path) is enqueued before the
-                # side stream's ~30 small launches, which have the whole phase to finish in
-                for i, xc in enumerate(xs):
-                    self.cdae_phase(xc, nlist[i], drawn=drawn)
-                with torch.cuda.stream(self._side):
-                    nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
-                main.wait_stream(self._side)
+                if self._capture is not None:
+                    # segmented capture: the side stream's work must sit in the FIRST graph (it is joined at the first cut), and
+                    # replay order does not depend on the order of capture
+                    self._capture["side_open"] = True
+                    with torch.cuda.stream(self._side):
+                        nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
+                    for i, xc in enumerate(xs):
+                        self.cdae_phase(xc, nlist[i], drawn=drawn)
+                    if self._capture["side_open"]:
+                        main.wait_stream(self._side)
+                        self._capture["side_open"] = False
+                else:
+                    # eager launches reach the GPU in host order: the cDAE phase (the critical path) is enqueued before the
+                    # side stream's ~30 small launches, which have the whole phase to finish in
+                    for i, xc in enumerate(xs):
+                        self.cdae_phase(xc, nlist[i], drawn=drawn)
+                    with torch.cuda.stream(self._side):
+                        nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
+                    main.wait_stream(self._side)
             else:
                 for i, xc in enumerate(xs):
                     self.cdae_phase(xc, nlist[i])
@@ -348,7 +410,7 @@ class ArdaeEngine:
             self._beta_stable = self._beta_stable + 1 if b == self._last_beta else 0
             self._last_beta = b
             if self._graph is not None and self._graph_key == key:
-                self._graph.replay()
+                self._replay()
             elif self._warmed and self._beta_stable < 2:
                 self._step_body(self._xc, self._xv, None, b)
             elif not self._warmed:
@@ -356,11 +418,14 @@ class ArdaeEngine:
                 self._step_body(self._xc, self._xv, None, b)
                 self._warmed = True
             else:
-                g = torch.cuda.CUDAGraph()
                 try:
-                    with torch.cuda.graph(g):
-                        self._step_body(self._xc, self._xv, None, b)
-                except Exception as exc:   # capture refused (e.g. a collective): eager from now on
+                    if self.world > 1:
+                        g = self._capture_segments(self._xc, self._xv, b)
+                    else:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            self._step_body(self._xc, self._xv, None, b)
+                except Exception as exc:   # capture refused: eager from now on
                     self.use_graph = False
                     self._graph = None
                     import warnings
@@ -368,7 +433,7 @@ class ArdaeEngine:
                     self._step_body(self._xc, self._xv, None, b)
                 else:
                     self._graph, self._graph_key = g, key
-                    g.replay()
+                    self._replay()
             self.step_count += 1
             return
         self._step_body(xs, x_vae, noise, beta)

@@ -102,13 +102,14 @@ def test_linear_transposed_pack_and_two_sources():
 
 
 @pytest.mark.parametrize("M,K,Nout", [(8192, 256, 256), (24576, 256, 256), (65536, 256, 256), (16384, 32, 256),
-                                      (8192, 512, 512), (20480, 512, 512), (4096, 512, 1024), (8192, 32, 512), (12288, 512, 128)])
+                                      (8192, 512, 512), (20480, 512, 512), (4096, 512, 1024), (8192, 32, 512), (12288, 512, 128),
+                                      (65536, 32, 256), (40960, 32, 512)])
 @pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
 def test_linear_wide_kernel_epilogues(M, K, Nout, epi):
     """The weight-stationary N-row kernel (linear_wide_kernel: >= 128 tiles, K in {256, 32} with 256 columns per workgroup, K = 512
     with 128 columns per workgroup - configs #4's h 512 layers - in 2, 4 and 8 column panels, the XCD-aware and the plain
     workgroup -> tile maps): one tile per workgroup (8192 rows), one or two (24576: deferred stores carried into the next
-    tile), four (65536)."""
+    tile), four (65536; with K = 32 the tile loop is a rolled loop whose spilled SGPRs once reached a buffer instruction too early)."""
     test_linear_big_m_epilogues(M, K, Nout, epi, rpg=64)
 
 

@@ -9,6 +9,8 @@ disassembles each kernel and scans it linearly:
     (global) / lgkmcnt(0) (LDS) - partial counts are ignored, which only makes the check stricter;
   * v_mov_b32 / v_accvgpr_write_b32 / scratch_store / v_writelane reading an in-flight VGPR is a violation;
   * any scratch usage is a violation;
+  * a vector-memory instruction that reads an SGPR (descriptor, offset, base) which v_readlane / v_readfirstlane wrote fewer
+    than 5 wait states earlier is a violation (seen as GPU memory faults, twice);
   * a vector-ALU instruction that reads the result of an MFMA less than 18 wait states (s_nop) after it issued, with no other
     MFMA in between, is a violation: linear_wide_kernel's MFMAs are inline asm, which the compiler's hazard recogniser does
     not see (seen once: register copies of the accumulators placed right behind a tile's last MFMA gave wrong values in the
@@ -32,15 +34,43 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def sregs(tok):
+    m = re.match(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"s(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
 def scan(code):
     inflight_g, inflight_l, bad = set(), set(), []
     mfma_dst, mfma_wait = set(), 0      # result registers of the most recent MFMA and the wait states seen since it issued
+    valu_sgpr = {}                      # SGPR written by the vector ALU (v_readlane / v_readfirstlane) -> wait states since
     for n, line in enumerate(code):
         s = line.split(";")[0].strip()
         if not s or s.endswith(":"):
             continue
         op, _, rest = s.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
+        # a scalar operand written by the vector ALU needs 5 wait states before a vector-memory instruction reads it; the compiler
+        # inserts them for its own instructions, not for inline asm (every asm VMEM statement here carries its own s_nop 4)
+        if op in ("v_readlane_b32", "v_readfirstlane_b32"):
+            for k in list(valu_sgpr):
+                valu_sgpr[k] += 1
+            valu_sgpr.update({r: 0 for r in sregs(ops[0])})
+        else:
+            step = int(rest.strip(), 0) + 1 if op == "s_nop" else 1
+            if op.startswith("buffer_") or op.startswith("global_") or op.startswith("scratch_"):
+                used = set()
+                for o in ops:
+                    used |= sregs(o.split()[0])
+                hit = sorted(r for r in used if r in valu_sgpr and valu_sgpr[r] < 5)
+                if hit:
+                    bad.append((n, s + "   [scalar operand written by the vector ALU %d wait states earlier]" % min(valu_sgpr[r] for r in hit), hit))
+            for k in list(valu_sgpr):
+                valu_sgpr[k] += step
+                if valu_sgpr[k] >= 5:
+                    del valu_sgpr[k]
         # inline-asm MFMAs are invisible to the hazard recogniser: a vector-ALU read of a 16-pass MFMA's result needs 18 wait
         # states; another MFMA in between occupies the pipe for 64 cycles, s_nop N counts N + 1
         if op.startswith("v_mfma"):
