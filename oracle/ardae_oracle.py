@@ -30,6 +30,9 @@ Reference map (file:line in /root/reference):
   rmsprop_step()        torch.optim.RMSprop as constructed at ivae_ardae.py:625-626
   train_step()          ivae_ardae.py:707-846
   iwae_logprob()        models/ivae/mnist.py:378-437, utils/stat.py:65-85,127-158
+  res_conv() / res_linear_wn() / res_linear()   models/layers2.py:237-265,305-352, models/layers.py:25-85,559-622
+  resconv_trunk() / resconv_decode()            models/ivae/resconv.py:53-180, models/vae/resconv.py:79-136,
+                                                models/vae/auxresconv.py:26-185, models/ivae/auxresconv.py:48-134
 """
 import math
 from dataclasses import dataclass, field
@@ -38,6 +41,7 @@ import torch
 import torch.nn.functional as F
 
 LOG2PI = math.log(2.0 * math.pi)
+AUX_KINDS = ("auxmnist", "auxconv", "auxresconv")     # hierarchical samplers: two draws per call
 
 
 # --------------------------------------------------------------------------- #
@@ -46,7 +50,9 @@ LOG2PI = math.log(2.0 * math.pi)
 @dataclass
 class ModelCfg:
     """Implicit-posterior VAE hyper-parameters (ivae_ardae.py:295-314)."""
-    kind: str = "mnist"          # "mnist" (MNISTIPVAE) | "toy" (ToyIPVAE, enc_type='concat') | "conv" (ConvIPVAE, 28x28x1)
+    kind: str = "mnist"          # "mnist" (MNISTIPVAE) | "toy" (ToyIPVAE, enc_type='concat') | "conv" (ConvIPVAE, 28x28x1) | "auxmnist" | "auxconv"
+                                 # | "resconv" (ResConvIPVAE do_center, enc_type='res-wn-mlp': --model resconvct-res; c_dim 512, h_dim = fc width)
+                                 # | "auxresconv" (MNISTResConvAuxIPVAE do_center: --model auxresconvct; noise_dim = z0_dim, h_dim = c_dim 450)
     input_dim: int = 784
     noise_dim: int = 100
     h_dim: int = 256
@@ -157,6 +163,33 @@ def model_param_spec(c: ModelCfg):
               ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
               ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
         return s
+    if c.kind in ("resconv", "auxresconv"):
+        # weight-normalised residual blocks (models/layers2.py:50-93,237-265,305-352; models/layers.py:25-85 for encode.fc);
+        # every block owns three weight-normalised operators, parameters in the order direction, scale, bias
+        def wn(prefix, out, inn, conv):
+            return [(prefix + "direction", (out, inn, 3, 3) if conv else (out, inn)), (prefix + "scale", (out,)), (prefix + "bias", (out,))]
+        def block(prefix, out, inn, conv):
+            a, b_, c_ = ("conv_0h.", "conv_h1.", "conv_01.") if conv else ("dot_0h.", "dot_h1.", "dot_01.")
+            return wn(prefix + a, out, inn, conv) + wn(prefix + b_, out, out, conv) + wn(prefix + c_, out, inn, conv)
+        cdim = 512 if c.kind == "resconv" else c.h_dim
+        tp = "encode.inp_encode." if c.kind == "resconv" else "encode.inp_encode.enc."
+        s = []
+        for i, (o, inn) in zip((0, 2, 4, 6, 8), ((16, 1), (16, 16), (32, 16), (32, 32), (32, 32))):
+            s += block(f"{tp}{i}.", o, inn, True)
+        s += block(f"{tp}11.", cdim, 512, False)
+        if c.kind == "resconv":     # ResMLP(c_dim + noise -> h_dim -> z), n_layers = 1 (models/ivae/resconv.py:112-113)
+            assert c.n_layers == 1
+            s += block("encode.fc.layers.0.", c.h_dim, cdim + c.noise_dim, False) + block("encode.fc.fc.", c.z_dim, c.h_dim, False)
+        else:
+            s += [("encode.aux_encode.reparam.mean_fn.weight", (c.noise_dim, cdim)), ("encode.aux_encode.reparam.mean_fn.bias", (c.noise_dim,)),
+                  ("encode.aux_encode.reparam.logvar_fn.weight", (c.noise_dim, cdim)), ("encode.aux_encode.reparam.logvar_fn.bias", (c.noise_dim,)),
+                  ("encode.encode.fc.0.weight", (cdim, cdim + c.noise_dim)), ("encode.encode.fc.0.bias", (cdim,)),
+                  ("encode.encode.reparam.mean_fn.weight", (c.z_dim, cdim)), ("encode.encode.reparam.mean_fn.bias", (c.z_dim,)),
+                  ("encode.encode.reparam.logvar_fn.weight", (c.z_dim, cdim)), ("encode.encode.reparam.logvar_fn.bias", (c.z_dim,))]
+        s += block("decode.dec.0.", cdim, c.z_dim, False) + block("decode.dec.2.", 512, cdim, False)
+        for i, (o, inn) in zip((6, 8, 12, 14, 17), ((32, 32), (32, 32), (16, 32), (16, 16), (1, 16))):
+            s += block(f"decode.dec.{i}.", o, inn, True)
+        return s
     if c.kind == "toy":
         s = _mlp_spec("encode.inp_encode.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
         s += _ctxcat_mlp_spec("encode.fc.", c.h_dim, c.noise_dim, c.h_dim, c.z_dim, c.n_layers)
@@ -197,7 +230,16 @@ def init_params(spec, seed, special=None, dtype=torch.float32):
     for name, shape in spec:
         fan_in = shape[1] if len(shape) == 2 else (shape[1] * shape[2] * shape[3] if len(shape) == 4 else None)
         kind = special.get(name, ("default",))[0]
-        if kind == "normal":
+        if name.endswith(".scale"):          # weight-norm gains (layers2.py:66-71: 1 at construction); spread here so that gradients tell them apart
+            a = rng.uniform(0.7, 1.3, shape)
+        elif name.endswith(".bias") and (name[:-len("bias")] + "direction") in dict(spec):
+            wshape = dict(spec)[name[:-len("bias")] + "direction"]
+            bound = 1.0 / math.sqrt(wshape[1])                             # layers2.py:66 / 184-190: stdv = 1/sqrt(in_features | in_channels)
+            a = rng.uniform(-bound, bound, shape)
+        elif name.endswith(".direction"):
+            bound = 1.0 / math.sqrt(shape[1])
+            a = rng.uniform(-bound, bound, shape)
+        elif kind == "normal":
             a = rng.standard_normal(shape)
         elif kind == "zeros":
             a = np.zeros(shape)
@@ -225,6 +267,8 @@ def model_init_special(c: ModelCfg):
                 continue
             sp[name] = ("xavier",) if name.endswith("weight") else ("zeros",)
         return sp
+    if c.kind in ("resconv", "auxresconv"):   # no init override (the WN operators' and nn.Linear's own reset_parameters)
+        return {}
     if c.kind == "auxmnist":   # do_xavier=True: self.apply(weight_init) on the whole model (ivae/auxmnist.py:172-174)
         return {name: (("xavier",) if name.endswith("weight") else ("zeros",)) for name, _ in spec}
     for name, _ in spec:
@@ -268,6 +312,77 @@ def ctxcat_mlp(p, prefix, x, ctx, n_hidden, nonlin):
     return F.linear(torch.cat([h, ctx], 1), p[f"{prefix}fc.weight"], p[f"{prefix}fc.bias"])
 
 
+def _wn_weight(p, pre, norm):
+    """Effective weight of a weight-normalised operator: scale * direction / ||direction||  (norm over everything but the output
+    index; layers2.py:73-83,255-265) or scale * direction (models/layers.py:47-53 with norm=False, as ResMLP builds them)."""
+    d, sc = p[pre + "direction"], p[pre + "scale"]
+    view = (-1,) + (1,) * (d.dim() - 1)
+    if norm:
+        d = d / d.pow(2).flatten(1).sum(1).sqrt().view(view)
+    return sc.view(view) * d
+
+
+def res_conv(p, pre, x, stride, f):
+    """layers2.ResConv2d (3x3, padding 1; conv_h1 is 3x3 stride 1): conv_h1(f(conv_0h(x))) + conv_01(x)   (layers2.py:305-328)."""
+    h = f(F.conv2d(x, _wn_weight(p, pre + "conv_0h.", True), p[pre + "conv_0h.bias"], stride, 1))
+    return (F.conv2d(h, _wn_weight(p, pre + "conv_h1.", True), p[pre + "conv_h1.bias"], 1, 1)
+            + F.conv2d(x, _wn_weight(p, pre + "conv_01.", True), p[pre + "conv_01.bias"], stride, 1))
+
+
+def res_linear(p, pre, x, norm):
+    """ResLinear with its DEFAULT inner activation ReLU (layers2.py:331-352 with WNlinear, norm=True; models/layers.py:66-85 with
+    WeightNormalizedLinear norm=False inside ResMLP) and a projected skip (same_dim is False in every block these models build)."""
+    h = F.relu(F.linear(x, _wn_weight(p, pre + "dot_0h.", norm), p[pre + "dot_0h.bias"]))
+    return (F.linear(h, _wn_weight(p, pre + "dot_h1.", norm), p[pre + "dot_h1.bias"])
+            + F.linear(x, _wn_weight(p, pre + "dot_01.", norm), p[pre + "dot_01.bias"]))
+
+
+def resconv_trunk(c, p, x):
+    """The per-image trunk both families share (ivae/resconv.py:81-96, vae/auxresconv.py:36-63; do_center=True):
+    28 -> 14 -> 14 -> 7 -> 7 -> 4, flatten (NCHW), ResLinear 512 -> c_dim, ELU after every block."""
+    tp = "encode.inp_encode." if c.kind == "resconv" else "encode.inp_encode.enc."
+    h = (2 * x.reshape(x.size(0), 784) - 1).view(-1, 1, 28, 28)
+    for i, st in zip((0, 2, 4, 6, 8), (2, 1, 2, 1, 2)):
+        h = F.elu(res_conv(p, f"{tp}{i}.", h, st, F.elu))
+    return F.elu(res_linear(p, f"{tp}11.", h.reshape(h.size(0), 512), True))
+
+
+def spm4(lv):
+    """NormalDistribution.clip_logvar with nonlinearity='spm4' (models/reparam.py:30-31)."""
+    return F.softplus(lv + 4.) - 4.
+
+
+def auxres_encode(c, p, x, noise, nz):
+    """MNISTResConvAuxIPVAE's sampler (ivae/auxresconv.py:73-106): heads on the shared trunk, both log-variances clipped 'spm4';
+    noise = (eps0 [B*nz, z0_dim], eps [B*nz, z_dim]) already scaled by std."""
+    eps0, eps = noise
+    inp = resconv_trunk(c, p, x)
+    mu0 = F.linear(inp, p["encode.aux_encode.reparam.mean_fn.weight"], p["encode.aux_encode.reparam.mean_fn.bias"])
+    lv0 = spm4(F.linear(inp, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"]))
+    z0 = expand_rows(mu0, nz) + torch.exp(0.5 * expand_rows(lv0, nz)) * eps0
+    h = F.elu(F.linear(torch.cat([expand_rows(inp, nz), z0], 1), p["encode.encode.fc.0.weight"], p["encode.encode.fc.0.bias"]))
+    mu = F.linear(h, p["encode.encode.reparam.mean_fn.weight"], p["encode.encode.reparam.mean_fn.bias"])
+    lv = spm4(F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"]))
+    z = mu + torch.exp(0.5 * lv) * eps
+    return {"z": z, "h": h, "z0": z0, "inp": inp}
+
+
+def resconv_decode(c, p, z):
+    """models/vae/resconv.py:79-136: two ResLinears, then bilinear x2 upsampling (align_corners=True) between ResConv2d blocks,
+    4 -> 8 -> (slice) 7 -> 14 -> 28, logits [R, 784]."""
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+    h = F.elu(res_linear(p, "decode.dec.0.", z, True))
+    h = F.elu(res_linear(p, "decode.dec.2.", h, True)).view(-1, 32, 4, 4)
+    h = up(h)
+    h = F.elu(res_conv(p, "decode.dec.6.", h, 1, F.elu))
+    h = F.elu(res_conv(p, "decode.dec.8.", h, 1, F.elu))[:, :, :-1, :-1]
+    h = up(h)
+    h = F.elu(res_conv(p, "decode.dec.12.", h, 1, F.elu))
+    h = F.elu(res_conv(p, "decode.dec.14.", h, 1, F.elu))
+    h = up(h)
+    return res_conv(p, "decode.dec.17.", h, 1, F.elu).reshape(z.size(0), 784)
+
+
 def expand_rows(t, nz):
     """[B, d] -> [B*nz, d], image-major (utils/msc.py:21-40)."""
     return t.unsqueeze(1).expand(-1, nz, -1).reshape(t.size(0) * nz, -1)
@@ -296,6 +411,12 @@ def encode(c: ModelCfg, p, x, noise, nz):
         z = ctxcat_mlp(p, "encode.fc.", expand_rows(inp, nz), noise, c.n_layers, c.nonlin)
     elif c.kind in ("auxmnist", "auxconv"):
         z = aux_encode(c, p, x, noise, nz)["z"]
+    elif c.kind == "resconv":      # ivae/resconv.py:141-159, enc_type 'res-wn-mlp': ResMLP with ELU between its two ResLinears
+        inp = resconv_trunk(c, p, x)
+        t = F.elu(res_linear(p, "encode.fc.layers.0.", torch.cat([expand_rows(inp, nz), noise], 1), False))
+        z = res_linear(p, "encode.fc.fc.", t, False)
+    elif c.kind == "auxresconv":
+        z = auxres_encode(c, p, x, noise, nz)["z"]
     else:
         raise NotImplementedError
     return z.view(B, nz, c.z_dim)
@@ -341,7 +462,7 @@ def aux_encode(c: ModelCfg, p, x, noise, nz):
 
 def zero_noise(c: ModelCfg, rows, like):
     """The draws of an encode(x, std=0) call, multiplied by 0."""
-    if c.kind in ("auxmnist", "auxconv"):
+    if c.kind in AUX_KINDS:
         return (like.new_zeros(rows, c.noise_dim), like.new_zeros(rows, c.z_dim))
     return like.new_zeros(rows, c.noise_dim)
 
@@ -352,7 +473,9 @@ def cdae_context(c: ModelCfg, tc, p, x):
     if tc.ctx_type == "lt0":
         return encode(c, p, x, zero_noise(c, B, x), 1).reshape(B, c.z_dim)
     if tc.ctx_type == "hidden1a":
-        assert c.kind in ("auxmnist", "auxconv"), "hidden1a is the aux models' context"
+        assert c.kind in AUX_KINDS, "hidden1a is the aux models' context"
+        if c.kind == "auxresconv":      # Encoder.forward_hidden returns h alone: 450 columns (ivae/auxresconv.py:125-132, ivae_ardae.py:578-579)
+            return auxres_encode(c, p, x, zero_noise(c, B, x), 1)["h"]
         a = aux_encode(c, p, x, zero_noise(c, B, x), 1)
         return torch.cat([a["h0"], a["h"]], 1)
     raise NotImplementedError(tc.ctx_type)
@@ -370,6 +493,8 @@ def decode(c: ModelCfg, p, z):
         h = f(F.conv_transpose2d(h, p["decode.deconv2.weight"], p["decode.deconv2.bias"], stride=2, padding=2))
         logit = F.conv_transpose2d(h, p["decode.reparam.logit_fn.weight"], p["decode.reparam.logit_fn.bias"], stride=2, padding=2)
         return (logit[:, :, :28, :28].reshape(z.size(0), 784),)
+    if c.kind in ("resconv", "auxresconv"):
+        return (resconv_decode(c, p, z),)
     h = mlp(p, "decode.main.", z, c.n_layers - 1, c.nonlin, True)
     mu = F.linear(h, p["decode.reparam.mean_fn.weight"], p["decode.reparam.mean_fn.bias"])
     logvar = F.linear(h, p["decode.reparam.logvar_fn.weight"], p["decode.reparam.logvar_fn.bias"])
@@ -377,7 +502,7 @@ def decode(c: ModelCfg, p, z):
 
 
 def recon_rows(c: ModelCfg, dist, target):
-    if c.kind in ("mnist", "conv", "auxmnist", "auxconv"):
+    if c.kind in ("mnist", "conv", "auxmnist", "auxconv", "resconv", "auxresconv"):
         (logit,) = dist
         return F.binary_cross_entropy_with_logits(logit, target, reduction="none").sum(1)
     mu, logvar = dist
@@ -491,7 +616,7 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
     The std=0 encodes consume a draw that is multiplied by 0, so they are skipped here
     (they only advance the reference's RNG stream)."""
     N = B * tc.nz_cdae
-    aux = mc.kind in ("auxmnist", "auxconv")       # a second draw per sampler call: eps of z = mu + exp(lv/2) eps (ivae/auxmnist.py:113-114)
+    aux = mc.kind in AUX_KINDS       # a second draw per sampler call: eps of z = mu + exp(lv/2) eps (ivae/auxmnist.py:113-114)
     n = {"sampler": torch.randn(N, mc.noise_dim, generator=gen)}          # forward_hidden
     if aux:
         n["sampler_z"] = torch.randn(N, mc.z_dim, generator=gen)
@@ -505,7 +630,7 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
 
 def sampler_noise(mc: ModelCfg, noise, which):
     """The sampler's draws out of a step's noise dict: which = "sampler" (cDAE phase) | "vae"."""
-    return (noise[which], noise[which + "_z"]) if mc.kind in ("auxmnist", "auxconv") else noise[which]
+    return (noise[which], noise[which + "_z"]) if mc.kind in AUX_KINDS else noise[which]
 
 
 # --------------------------------------------------------------------------- #
@@ -575,7 +700,7 @@ def iwae_logprob(mc: ModelCfg, pm, x, sample_size, enc_noise, prop_noise):
     B = x.size(0)
     x = x.reshape(B, mc.input_dim)
     with torch.no_grad():
-        if mc.kind in ("auxmnist", "auxconv"):      # enc_noise = (eps0 [B,k,noise_dim], eps [B,k,z]); ivae/auxmnist.py:306-326
+        if mc.kind in AUX_KINDS:      # enc_noise = (eps0 [B,k,noise_dim], eps [B,k,z]); ivae/auxmnist.py:306-326
             noise = (enc_noise[0].reshape(B * sample_size, mc.noise_dim), enc_noise[1].reshape(B * sample_size, mc.z_dim))
         else:
             noise = enc_noise.reshape(B * sample_size, mc.noise_dim)
@@ -583,8 +708,8 @@ def iwae_logprob(mc: ModelCfg, pm, x, sample_size, enc_noise, prop_noise):
         mu = z.mean(1)
         zc = z - mu.unsqueeze(1)
         cov = zc.transpose(1, 2) @ zc / (sample_size - 1)
-        if mc.kind in ("auxmnist", "auxconv"):
-            cov = cov + 1e-5 * torch.eye(mc.z_dim, dtype=cov.dtype)      # ivae/auxmnist.py:321
+        if mc.kind in AUX_KINDS:
+            cov = cov + 1e-5 * torch.eye(mc.z_dim, dtype=cov.dtype)      # ivae/auxmnist.py:321, ivae/auxresconv.py:299
         Lc = torch.linalg.cholesky(cov)
         newz = mu.unsqueeze(1) + prop_noise @ Lc.transpose(1, 2)
         half_logdet = torch.log(torch.diagonal(Lc, dim1=1, dim2=2)).sum(1, keepdim=True)

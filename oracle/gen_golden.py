@@ -65,6 +65,12 @@ def build_reference(net, mc, cc, pm, pc, dtype):
                                   nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
     elif mc.kind == "auxconv":   # ivae_ardae.py:467-478
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
+    elif mc.kind == "resconv":   # ivae_ardae.py:359-370 (--model resconvct-res)
+        model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
+                                 noise_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=True, enc_type="res-wn-mlp")
+    elif mc.kind == "auxresconv":   # ivae_ardae.py:493-505 (--model auxresconvct)
+        model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim,
+                                         nonlinearity=mc.nonlin, do_center=True)
     elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
                                num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
@@ -137,7 +143,7 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
 def replay_noise(mc, tc, B_c, B_v, seed, dtype):
     """Re-draw, with the same seed and call sizes, what ref_step consumed (SURVEY 8 a-R)."""
     torch.manual_seed(seed)
-    if mc.kind in ("auxmnist", "auxconv"):
+    if mc.kind in O.AUX_KINDS:
         # one Encoder._forward call (ivae/auxmnist.py:110-116) draws eps0 [R, noise_dim] and eps [R, 1, z]; the two reparam modules
         # it runs then draw samples nobody uses (AuxEncoder.forward: randn_like [B, noise_dim], vae/auxmnist.py:66;
         # SimpleEncoder._forward_all: randn_like [R, z], :189)
@@ -171,7 +177,7 @@ def rel_l2(a, b):
 
 def synth_x(mc, B, seed):
     g = torch.Generator().manual_seed(seed)
-    if mc.kind in ("mnist", "conv", "auxmnist", "auxconv"):
+    if mc.kind in ("mnist", "conv", "auxmnist", "auxconv", "resconv", "auxresconv"):
         p = (torch.rand(mc.input_dim, generator=g) < 0.2).float() * 0.6 + 0.03
         return torch.bernoulli(p.expand(B, -1), generator=g)
     mu = (torch.randint(0, 5, (B, mc.input_dim), generator=g).float() - 2) * 2
@@ -179,8 +185,8 @@ def synth_x(mc, B, seed):
 
 
 # --------------------------------------------------------------------------- #
-def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0):
-    tol = 1e-4 if dtype == torch.float32 else 1e-10
+def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0, tol32=1e-4):
+    tol = tol32 if dtype == torch.float32 else 1e-10
     pm = O.init_params(O.model_param_spec(mc), pseed, O.model_init_special(mc), dtype)
     pc = O.init_params(O.cdae_param_spec(cc), pseed + 1, None, dtype)
     # tame the N(0,1) head so fp32 comparisons are meaningful at tiny nz as well (values still O(1..10))
@@ -265,6 +271,8 @@ def run_iwae_case(net, name, mc, B, k, dtype, store_params=True):
     """models/ivae/mnist.py:378-437 with the per-image draws captured by replaying the seed."""
     pm = O.init_params(O.model_param_spec(mc), 7, O.model_init_special(mc), dtype)
     cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=2 * mc.h_dim if mc.kind in ("auxmnist", "auxconv") else mc.z_dim, h_dim=32, n_layers=2)
+    if mc.kind == "auxresconv":
+        cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=mc.h_dim, h_dim=32, n_layers=2)
     pc = O.init_params(O.cdae_param_spec(cc), 8, None, dtype)
     model, _ = build_reference(net, mc, cc, pm, pc, dtype)
     x = synth_x(mc, B, 55).to(dtype)
@@ -273,7 +281,7 @@ def run_iwae_case(net, name, mc, B, k, dtype, store_params=True):
     with torch.no_grad():
         ref = model.logprob(x, sample_size=k)
     torch.manual_seed(99)
-    if mc.kind in ("auxmnist", "auxconv"):   # ONE Encoder._forward(nz=k) call for all images (ivae/auxmnist.py:314), then the per-image proposals
+    if mc.kind in O.AUX_KINDS:   # ONE Encoder._forward(nz=k) call for all images (ivae/auxmnist.py:314), then the per-image proposals
         e0 = torch.randn(B * k, mc.noise_dim)
         e = torch.randn(B * k, 1, mc.z_dim)
         torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * k, mc.z_dim, dtype=dtype)     # the two unused reparam samples
@@ -286,7 +294,7 @@ def run_iwae_case(net, name, mc, B, k, dtype, store_params=True):
     err = abs(float(mine) - float(ref)) / abs(float(ref))
     assert err < (1e-4 if dtype == torch.float32 else 1e-9), (float(mine), float(ref))
     fx = {"x": x.numpy(), "prop_noise": prop.numpy(), "logprob": ref.numpy(), "meta_k": np.int64(k)}
-    if mc.kind in ("auxmnist", "auxconv"):
+    if mc.kind in O.AUX_KINDS:
         fx["enc_noise"], fx["enc_noise_z"] = enc[0].numpy(), enc[1].numpy()
     else:
         fx["enc_noise"] = enc.numpy()
@@ -408,6 +416,22 @@ def main():
     auxc_c = O.CdaeCfg("grad", 32, 1600, 64, 2)
     run_case(net, rutils, "auxconv_b4_nz8", auxc_m, auxc_c, O.TrainCfg(nz_cdae=8, ctx_type="hidden1a"), B=4, steps=2, dtype=f32, store_full=False)
     run_iwae_case(net, "iwae_auxconv", auxc_m, B=2, k=64, dtype=f64, store_params=False)
+    # the shipped "implicit resconv" / "hierarchical resconv" recipes' model families (run_vae_dbmnist.sh: --model resconvct-res /
+    # auxresconvct, --model-nonlin elu, --cdae mlp-res, --std-scale 100, Adam betas (0.9, 0.999), RMSprop momentum 0.9, lr 1e-3 / 1e-4):
+    # weight-normalised residual conv trunk + decoder at their fixed sizes, a small mlp-res cDAE
+    res_m = O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu")
+    res_c = O.CdaeCfg("res", 32, 32, 64, 2)
+    res_t = O.TrainCfg(nz_cdae=8, std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)
+    run_case(net, rutils, "resconv_b4_nz8_f64", res_m, res_c, res_t, B=4, steps=1, dtype=f64, store_full=False)
+    # (fp32: the first Adam step at lr 1e-3 is sign-like, two fp32 evaluations of a 45-layer backward differ by ~1e-4 in a few updates)
+    run_case(net, rutils, "resconv_b4_nz8", res_m, res_c, res_t, B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    ares_m = O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu")
+    ares_c = O.CdaeCfg("res", 32, 450, 64, 2)
+    ares_t = O.TrainCfg(nz_cdae=8, std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9, ctx_type="hidden1a")
+    run_case(net, rutils, "auxresconv_b4_nz8_f64", ares_m, ares_c, ares_t, B=4, steps=1, dtype=f64, store_full=False)
+    run_case(net, rutils, "auxresconv_b4_nz8", ares_m, ares_c, ares_t, B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    run_iwae_case(net, "iwae_resconv", res_m, B=2, k=64, dtype=f64, store_params=False)
+    run_iwae_case(net, "iwae_auxresconv", ares_m, B=2, k=64, dtype=f64, store_params=False)
     # reference-written checkpoint (model / cDAE state_dict + utils.Adam / torch.optim.RMSprop state_dict) and the step after it
     run_ckpt_case(net, rutils, "ckpt_tiny_mnist_grad", tiny_m, tiny_c, tc, B=4, k_steps=2)
 

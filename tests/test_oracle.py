@@ -57,12 +57,17 @@ def test_oracle_step_matches_reference_fixture(golden_dir, name):
     ("conv_b4_nz8", O.ModelCfg("conv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 32, 64, 2), "lt0"),
     # hierarchical conv model (--model auxconv): oracle pinned against the reference's MNISTConvAuxIPVAE; its HIP path is not built yet
     ("auxconv_b4_nz8", O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 1600, 64, 2), "hidden1a"),
+    # weight-normalised residual-conv families of the shipped "implicit resconv" / "hierarchical resconv" recipes
+    ("resconv_b4_nz8", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu"), O.CdaeCfg("res", 32, 32, 64, 2), "lt0"),
+    ("auxresconv_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu"), O.CdaeCfg("res", 32, 450, 64, 2), "hidden1a"),
 ])
 def test_oracle_step_matches_reference_summaries(golden_dir, name, mc, cc, ctx):
     """Fixtures that hold summaries only (parameters regenerated from the seed): losses, latent statistics and the norm / sum /
     first elements of every gradient of step 0."""
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     tc = O.TrainCfg(nz_cdae=8, ctx_type=ctx)
+    if "resconv" in mc.kind:      # run_vae_dbmnist.sh: --std-scale 100, Adam (0.9, 0.999) lr 1e-3, RMSprop momentum 0.9
+        tc = O.TrainCfg(nz_cdae=8, std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9, ctx_type=ctx)
     ps = int(fx["meta_pseed"])
     pm = O.init_params(O.model_param_spec(mc), ps, O.model_init_special(mc))
     pc = O.init_params(O.cdae_param_spec(cc), ps + 1)
@@ -132,6 +137,16 @@ def test_oracle_iwae_matches_reference_fixture_auxconv(golden_dir):
     pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc), torch.float64)
     got = O.iwae_logprob(mc, pm, torch.tensor(fx["x"]), int(fx["meta_k"]), (torch.tensor(fx["enc_noise"]), torch.tensor(fx["enc_noise_z"])),
                          torch.tensor(fx["prop_noise"]))
+    assert abs(float(got) - float(fx["logprob"])) / abs(float(fx["logprob"])) < 1e-9
+
+
+@pytest.mark.parametrize("name,mc", [("iwae_resconv", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu")),
+                                     ("iwae_auxresconv", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu"))])
+def test_oracle_iwae_matches_reference_fixture_resconv(golden_dir, name, mc):
+    fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc), torch.float64)
+    enc = (torch.tensor(fx["enc_noise"]), torch.tensor(fx["enc_noise_z"])) if "enc_noise_z" in fx else torch.tensor(fx["enc_noise"])
+    got = O.iwae_logprob(mc, pm, torch.tensor(fx["x"]), int(fx["meta_k"]), enc, torch.tensor(fx["prop_noise"]))
     assert abs(float(got) - float(fx["logprob"])) / abs(float(fx["logprob"])) < 1e-9
 
 
