@@ -25,7 +25,8 @@ extern "C" {
 #define ARDAE_ABI_VERSION 1
 
 /* activations: reference utils/models.py:14-32 (F.relu, F.softplus beta=1 threshold=20) */
-enum { ARDAE_ACT_NONE = 0, ARDAE_ACT_RELU = 1, ARDAE_ACT_SOFTPLUS = 2 };
+enum { ARDAE_ACT_NONE = 0, ARDAE_ACT_RELU = 1, ARDAE_ACT_SOFTPLUS = 2,
+       ARDAE_ACT_ELU = 3 /* F.elu: model activation of the residual-conv kinds 5 / 6 only (not an ardae_linear epilogue) */ };
 
 /* epilogues of ardae_linear */
 enum {
@@ -178,7 +179,16 @@ int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float*
  *                        (z0 = mu0 + exp(lv0/2) eps0,  z = mu + exp(lv/2) eps)
  *   kind 4 (MNISTConvAuxIPVAE, models/ivae/auxconv.py): the same hierarchical sampler with two conv trunks
  *                        (encode.aux_encode.{conv1-3, fc, reparam.*}, encode.encode.{conv1-3, fc, reparam.*}) and ConvIPVAE's decoder;
- *                        noise_dim = z0_dim, h_dim = 800 (the fc width), 28 x 28 x 1 only; same noise layout as kind 3 */
+ *                        noise_dim = z0_dim, h_dim = 800 (the fc width), 28 x 28 x 1 only; same noise layout as kind 3
+ *   kind 5 (ResConvIPVAE, models/ivae/resconv.py, `--model resconvct-res`: do_center, enc_type 'res-wn-mlp'): weight-normalised
+ *                        residual blocks (models/layers2.py:50-93,237-352; models/layers.py:25-85,559-622), each operator's
+ *                        parameters in the order direction, scale, bias: encode.inp_encode.{0,2,4,6,8}.{conv_0h,conv_h1,conv_01},
+ *                        encode.inp_encode.11.{dot_0h,dot_h1,dot_01}, encode.fc.layers.0.*, encode.fc.fc.*, decode.dec.{0,2}.dot_*,
+ *                        decode.dec.{6,8,12,14,17}.conv_*; c_dim 512, h_dim = the ResMLP width, n_layers 1, act ARDAE_ACT_ELU, 28 x 28 x 1
+ *   kind 6 (MNISTResConvAuxIPVAE, models/ivae/auxresconv.py, `--model auxresconvct`): the same trunk as encode.inp_encode.enc.*
+ *                        (c_dim = h_dim, 450 in the recipe), encode.aux_encode.reparam.{mean_fn,logvar_fn}, encode.encode.fc.0,
+ *                        encode.encode.reparam.{mean_fn,logvar_fn} (log-variances clipped 'spm4'), the same decoder; noise_dim = z0_dim,
+ *                        noise layout of kind 3; its hidden1a context is h [B, h_dim] */
 typedef struct ardae_model_desc {
   int kind;
   int input_dim, noise_dim, h_dim, z_dim;

@@ -70,7 +70,7 @@ class ModelDesc(ctypes.Structure):
                 ("z_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2}
+ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2, "elu": 3}      # elu: the residual-conv model kinds only
 LOG_RECORD_FLOATS = 16
 EPI_ACT, EPI_DACT, EPI_CHAIN, EPI_DAE_LOSS = 0, 1, 2, 3
 

@@ -45,7 +45,7 @@ void set_last_error(const char* fmt, ...);
 // The saved tensor is always the POST-activation value a = act(pre); first/second derivatives are
 // rebuilt from it:  softplus: s = sigmoid(pre) = 1 - exp(-a),  s' = s(1-s);  relu: s = [a>0], s' = 0.
 // ----------------------------------------------------------------------------------------------
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2, ACT_ELU = 3 };   // ELU: runtime helpers only (elementwise kernels of the residual-conv models)
 
 // Both helpers go straight to the hardware exp2 / log2 units (v_exp_f32 / v_log_f32, ~1 ulp; __expf/__logf expand to the
 // denormal-safe sequences, ~3x the instructions, with divergent branches) plus a short series where the direct form would
@@ -86,10 +86,14 @@ __device__ __forceinline__ float act_d1(float a) {
   return 1.f;
 }
 
+// ELU (F.elu, alpha = 1; utils/models.py:17-18, nn.ELU in models/ivae/resconv.py:23-31): x > 0 ? x : exp(x) - 1; its derivative
+// from the saved OUTPUT a: a > 0 ? 1 : a + 1 (= exp(x))
 __device__ __forceinline__ float act_fwd_rt(int act, float x) {
+  if (act == ACT_ELU) return x > 0.f ? x : expm1f(x);
   return act == ACT_RELU ? act_fwd<ACT_RELU>(x) : act == ACT_SOFTPLUS ? act_fwd<ACT_SOFTPLUS>(x) : x;
 }
 __device__ __forceinline__ float act_d1_rt(int act, float a) {
+  if (act == ACT_ELU) return a > 0.f ? 1.f : a + 1.f;
   return act == ACT_RELU ? act_d1<ACT_RELU>(a) : act == ACT_SOFTPLUS ? act_d1<ACT_SOFTPLUS>(a) : 1.f;
 }
 

@@ -14,6 +14,7 @@
 #include "common.h"
 #include "auxmodel.h"
 #include "convmodel.h"
+#include "resmodel.h"
 #include "elementwise.h"
 #include "linear.h"
 #include "wgrad.h"
@@ -89,8 +90,14 @@ struct Bump {
 
 int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d != nullptr, "model: desc is NULL");
-  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 4,
-                  "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE), 3 (MNISTAuxIPVAE) or 4 (MNISTConvAuxIPVAE)");
+  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 6,
+                  "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE), 3 (MNISTAuxIPVAE), 4 (MNISTConvAuxIPVAE), 5 (ResConvIPVAE) or "
+                  "6 (MNISTResConvAuxIPVAE)");
+  if (d->kind >= 5) {
+    ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1 && d->h_dim >= 1 && d->act == ACT_ELU && (d->kind == 6 || d->n_layers == 1),
+                    "model: the residual-conv models are 28x28x1, ELU, and (kind 5) one ResMLP layer");
+    return 0;
+  }
   if (d->kind == 2 || d->kind == 4) {
     ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1, "model: ConvIPVAE is hard-wired to 28x28x1 inputs (input_dim 784)");
     ARDAE_CHECK_ARG(d->act == ACT_SOFTPLUS || d->act == ACT_RELU, "model: activation must be softplus or relu");
@@ -248,18 +255,21 @@ extern "C" {
 
 size_t ardae_model_param_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
+  if (d->kind >= 5) return res_model_param_floats(*d);
   if (d->kind == 4) return auxconv_model_param_floats(*d);
   if (d->kind == 3) return aux_model_param_floats(*d);
   return d->kind == 2 ? conv_model_param_floats(*d) : ModelLayout(*d).total;
 }
 size_t ardae_model_packed_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
+  if (d->kind >= 5) return res_model_packed_floats(*d);
   if (d->kind == 4) return auxconv_model_packed_floats(*d);
   if (d->kind == 3) return aux_model_packed_floats(*d);
   return d->kind == 2 ? conv_model_packed_floats(*d) : ModelPacked(ModelLayout(*d)).total;
 }
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
   if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
+  if (d->kind >= 5) return res_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 4) return auxconv_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 3) return aux_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 2) return conv_model_workspace_floats(*d, B, nz, mode == 3 ? 0 : mode);
@@ -273,6 +283,7 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind >= 5) return res_model_pack(*d, params, packed, st);
   if (d->kind == 4) return auxconv_model_pack(*d, params, packed, st);
   if (d->kind == 3) return aux_model_pack(*d, params, packed, st);
   if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
@@ -316,6 +327,7 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 0));
   ARDAE_CHECK_ARG(z_out, "model_encode: z_out is NULL");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind >= 5) return res_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st);
   if (d->kind == 3) {
     ARDAE_TRY(aux_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st));
     return 0;
@@ -373,9 +385,10 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
 int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B, float* workspace,
                               size_t workspace_floats_, float* z0_out, float* hidden_out, void* stream) {
   ARDAE_TRY(model_common(d, params, packed, x, B, 1, workspace, workspace_floats_, 0));
-  ARDAE_CHECK_ARG(d->kind == 3 || d->kind == 4, "model_encode_hidden: the hidden1a context exists for the aux models only (kinds 3, 4)");
+  ARDAE_CHECK_ARG(d->kind == 3 || d->kind == 4 || d->kind == 6, "model_encode_hidden: the hidden1a context exists for the aux models only (kinds 3, 4, 6)");
   ARDAE_CHECK_ARG(hidden_out, "model_encode_hidden: hidden_out is NULL");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind == 6) return res_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st);   // z0_out may be NULL
   if (d->kind == 4) ARDAE_TRY(auxconv_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
   else ARDAE_TRY(aux_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st));
   return 0;
@@ -385,6 +398,10 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
                        size_t workspace_floats_, float* out0, float* out1, void* stream) {
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed && z && workspace && out0 && R > 0, "model_decode: bad arguments");
+  if (d->kind >= 5) {
+    ARDAE_CHECK_ARG(workspace_floats_ >= res_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
+    return res_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
+  }
   if (d->kind == 2) {
     ARDAE_CHECK_ARG(workspace_floats_ >= conv_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
     return conv_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
@@ -432,6 +449,7 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && z_out && losses, "model_vae_forward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind >= 5) return res_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
   if (d->kind == 3) {
     ARDAE_TRY(aux_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st));
     return 0;
@@ -550,6 +568,9 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
+  if (d->kind >= 5) {
+    return res_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
+  }
   if (d->kind == 2) {
     return conv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }

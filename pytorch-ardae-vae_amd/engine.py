@@ -70,10 +70,10 @@ class ArdaeEngine:
         z, nd = model.z_dim, model._noise_width          # floats per row of a sampler draw (aux models: [eps0 | eps])
         if cfg.cdae_ctx_type not in ("lt0", "hidden1a"):
             raise NotImplementedError(f"cdae_ctx_type {cfg.cdae_ctx_type!r}")          # ivae_ardae.py:743-744
-        if cfg.cdae_ctx_type == "hidden1a" and model._kind not in ("auxmnist", "auxconv"):
+        if cfg.cdae_ctx_type == "hidden1a" and not model.hidden_dim:
             raise NotImplementedError("hidden1a is the aux models' context (ivae_ardae.py:572-580)")
         self.hidden_ctx = cfg.cdae_ctx_type == "hidden1a"
-        ctx_dim = 2 * model.h_dim if self.hidden_ctx else z
+        ctx_dim = model.hidden_dim if self.hidden_ctx else z
         if int(cdae.context_dim) != ctx_dim:
             raise ValueError(f"cdae.context_dim = {cdae.context_dim}, but the {cfg.cdae_ctx_type} context has {ctx_dim} columns")
         f = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)

@@ -32,6 +32,32 @@ def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers):
         s += [("decode.deconv1.weight", (32, 32, 5, 5)), ("decode.deconv1.bias", (32,)),
               ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
               ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
+    elif kind in ("resconv", "auxresconv"):
+        # weight-normalised residual blocks (models/layers2.py:50-93,237-352; models/layers.py:25-85 inside ResMLP): three operators per
+        # block, each with direction / scale / bias; ivae/resconv.py:81-125, vae/auxresconv.py:36-63,94,149-153, vae/resconv.py:89-109
+        def wn(prefix, out, inn, conv):
+            return [(prefix + "direction", (out, inn, 3, 3) if conv else (out, inn)), (prefix + "scale", (out,)), (prefix + "bias", (out,))]
+
+        def block(prefix, out, inn, conv):
+            a, b, c = ("conv_0h.", "conv_h1.", "conv_01.") if conv else ("dot_0h.", "dot_h1.", "dot_01.")
+            return wn(prefix + a, out, inn, conv) + wn(prefix + b, out, out, conv) + wn(prefix + c, out, inn, conv)
+        cdim = 512 if kind == "resconv" else h_dim
+        tp = "encode.inp_encode." if kind == "resconv" else "encode.inp_encode.enc."
+        s = []
+        for i, (o, inn) in zip((0, 2, 4, 6, 8), ((16, 1), (16, 16), (32, 16), (32, 32), (32, 32))):
+            s += block(f"{tp}{i}.", o, inn, True)
+        s += block(f"{tp}11.", cdim, 512, False)
+        if kind == "resconv":
+            s += block("encode.fc.layers.0.", h_dim, cdim + noise_dim, False) + block("encode.fc.fc.", z_dim, h_dim, False)
+        else:
+            s += [("encode.aux_encode.reparam.mean_fn.weight", (noise_dim, cdim)), ("encode.aux_encode.reparam.mean_fn.bias", (noise_dim,)),
+                  ("encode.aux_encode.reparam.logvar_fn.weight", (noise_dim, cdim)), ("encode.aux_encode.reparam.logvar_fn.bias", (noise_dim,)),
+                  ("encode.encode.fc.0.weight", (cdim, cdim + noise_dim)), ("encode.encode.fc.0.bias", (cdim,)),
+                  ("encode.encode.reparam.mean_fn.weight", (z_dim, cdim)), ("encode.encode.reparam.mean_fn.bias", (z_dim,)),
+                  ("encode.encode.reparam.logvar_fn.weight", (z_dim, cdim)), ("encode.encode.reparam.logvar_fn.bias", (z_dim,))]
+        s += block("decode.dec.0.", cdim, z_dim, False) + block("decode.dec.2.", 512, cdim, False)
+        for i, (o, inn) in zip((6, 8, 12, 14, 17), ((32, 32), (32, 32), (16, 32), (16, 16), (1, 16))):
+            s += block(f"decode.dec.{i}.", o, inn, True)
     elif kind == "toy":
         s = _mlp("encode.inp_encode.", input_dim, h_dim, h_dim, n_layers - 1)
         s += _mlp("encode.fc.", h_dim, h_dim, z_dim, n_layers, extra_in=noise_dim)

@@ -75,9 +75,12 @@ class FlatParamModule(nn.Module):
 
     def _default_init(self):
         """nn.Linear's default init (kaiming_uniform(a=sqrt 5) == U(+-1/sqrt(fan_in)) for weight and bias)."""
+        spec = dict(self._spec)
         with torch.no_grad():
             for name, p in self.named_parameters():
-                wshape = p.shape if name.endswith("weight") else dict(self._spec)[name[:-len("bias")] + "weight"]
+                if name.endswith(".scale") or name.endswith(".direction") or (name[:-len("bias")] + "direction") in spec:
+                    continue                                        # weight-normalised operators: reset_parameters() of the owning model
+                wshape = p.shape if name.endswith("weight") else spec[name[:-len("bias")] + "weight"]
                 fan_in = wshape[1] * (wshape[2] * wshape[3] if len(wshape) == 4 else 1)   # torch's fan_in for (transposed) convs too
                 bound = 1.0 / math.sqrt(fan_in)
                 p.uniform_(-bound, bound)
@@ -96,6 +99,10 @@ class FlatParamModule(nn.Module):
 
 def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
+
+
+KIND_IDS = {"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4, "resconv": 5, "auxresconv": 6}     # ardae_model_desc.kind
+AUX_KINDS = ("auxmnist", "auxconv", "auxresconv")                                                           # hierarchical samplers
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -259,16 +266,17 @@ class ImplicitPosteriorVAE(FlatParamModule):
         assert enc_type in self._enc_types               # ivae/mnist.py:224; the other toy encoders are out of scope
         if energy_func is not normal_energy_func:
             raise NotImplementedError("only utils.normal_energy_func is implemented on the HIP path")
-        if nonlinearity not in ("softplus", "relu"):
+        if nonlinearity not in (("elu",) if self._kind in ("resconv", "auxresconv") else ("softplus", "relu")):
             raise NotImplementedError(f"nonlinearity {nonlinearity!r}")
         self.energy_func = energy_func
         self.input_dim, self.noise_dim, self.h_dim, self.z_dim = input_dim, noise_dim, h_dim, z_dim
         self.latent_dim = z_dim
         self.nonlinearity, self.num_hidden_layers, self.init, self.enc_type = nonlinearity, num_hidden_layers, init, enc_type
-        self._desc = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4}[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers,
-                                 L.ACT[nonlinearity])
+        self._desc = L.ModelDesc(KIND_IDS[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, L.ACT[nonlinearity])
         # floats per row of a sampler draw: the aux models take two draws per call, laid out side by side [eps0 | eps]
-        self._noise_width = noise_dim + z_dim if self._kind in ("auxmnist", "auxconv") else noise_dim
+        self._noise_width = noise_dim + z_dim if self._kind in AUX_KINDS else noise_dim
+        # columns of the `hidden1a` cDAE context (ivae_ardae.py:572-580): cat(h0, h) for the MLP / conv aux models, h alone for auxresconv
+        self.hidden_dim = {"auxmnist": 2 * h_dim, "auxconv": 2 * h_dim, "auxresconv": h_dim}.get(self._kind, 0)
         self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers), {"encode": _EncodeBox})
         object.__setattr__(self.encode, "_owner_ref", weakref.ref(self))   # `model.encode(x, std=0)` (ivae_ardae.py:735)
         self.reset_parameters()
@@ -277,6 +285,17 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self._default_init()
         with torch.no_grad():
             p = dict(self.named_parameters())
+            if self._kind in ("resconv", "auxresconv"):
+                # WNlinear / WNconv2d / WeightNormalizedLinear.reset_parameters (layers2.py:66-71,184-190, layers.py:40-45): direction and bias
+                # U(+-1/sqrt(in_features | in_channels)), scale 1; the plain nn.Linear layers of the aux sampler keep torch's default
+                spec = dict(self._spec)
+                for name, t in p.items():
+                    if name.endswith(".scale"):
+                        t.fill_(1.0)
+                    elif name.endswith(".direction") or (name[:-len("bias")] + "direction") in spec:
+                        d = spec[name if name.endswith(".direction") else name[:-len("bias")] + "direction"]
+                        t.uniform_(-1.0 / math.sqrt(d[1]), 1.0 / math.sqrt(d[1]))
+                return
             if self._kind == "auxmnist":                  # self.apply(weight_init) on the whole model (ivae/auxmnist.py:172-174)
                 if self.do_xavier:
                     for t in p.values():
@@ -341,12 +360,12 @@ class ImplicitPosteriorVAE(FlatParamModule):
 
     def _hidden(self, input):
         """cat(h0, h) [B, 2 h] of the std = 0 pass (aux models; the `hidden1a` cDAE context)."""
-        if self._kind not in ("auxmnist", "auxconv"):
+        if self._kind not in AUX_KINDS:
             raise NotImplementedError("hidden contexts exist for the aux models only")
         x = self._x(input)
         B, lib = x.size(0), L.lib()
         ws = self._ws(lib.ardae_model_workspace_floats(ctypes.byref(self._desc), B, 1, 0))
-        hid = torch.empty(B, 2 * self.h_dim, device=x.device)
+        hid = torch.empty(B, self.hidden_dim, device=x.device)
         L.check(lib.ardae_model_encode_hidden(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(x), B, L.ptr(ws),
                                               ws.numel(), None, L.ptr(hid), L.stream_ptr()), "ardae_model_encode_hidden")
         return hid
@@ -428,8 +447,8 @@ class ImplicitPosteriorVAE(FlatParamModule):
             mu = zs.mean(1)
             zc = zs - mu.unsqueeze(1)
             cov = zc.transpose(1, 2) @ zc / (k - 1)           # utils/stat.py:127-158
-            if self._kind in ("auxmnist", "auxconv"):
-                cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321, ivae/auxconv.py
+            if self._kind in AUX_KINDS:
+                cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321, ivae/auxconv.py, ivae/auxresconv.py:299
             cov = cov.contiguous()
             Lc = torch.empty_like(cov)                        # all B factorisations in one launch (MultivariateNormal's, ivae/mnist.py:397)
             L.check(L.lib().ardae_cholesky_batched(L.ptr(cov), B, zd, L.ptr(Lc), L.stream_ptr()), "ardae_cholesky_batched")
@@ -496,6 +515,39 @@ class MNISTConvAuxIPVAE(ImplicitPosteriorVAE):
             raise NotImplementedError("MNISTConvAuxIPVAE: the reference decoder (models/vae/conv.py:79-136) is hard-wired to 28x28x1")
         self.input_height, self.input_channels, self.z0_dim, self.do_xavier = input_height, input_channels, z0_dim, do_xavier
         super().__init__(energy_func, 784, z0_dim, 800, z_dim, nonlinearity, 1, "none", "concat")
+
+
+class ResConvIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/resconv.py::ImplicitPosteriorVAE as `--model resconvct-res` builds it (ivae_ardae.py:359-370; the shipped "implicit
+    resconv" recipe): weight-normalised residual-conv trunk and decoder, ResMLP sampler head, ELU, 28x28x1, c_dim 512."""
+    _kind = "resconv"
+
+    def __init__(self, energy_func=normal_energy_func, input_height=28, input_channels=1, z_dim=32, noise_dim=100, c_dim=512, h_dim=800,
+                 num_hidden_layers=1, nonlinearity="elu", do_center=False, do_m5bias=False, enc_noise=False, enc_type="mlp"):
+        if input_height != 28 or input_channels != 1:
+            raise AssertionError("input_height == 28 and input_channels == 1")           # ivae/resconv.py:218-219
+        if not do_center or enc_type != "res-wn-mlp" or enc_noise or do_m5bias or c_dim != 512 or num_hidden_layers != 1:
+            raise NotImplementedError("the HIP engine builds ResConvIPVAE as --model resconvct-res does: do_center=True, "
+                                      "enc_type='res-wn-mlp', c_dim=512, one ResMLP layer, no enc_noise / do_m5bias")
+        self.input_height, self.input_channels, self.c_dim = input_height, input_channels, c_dim
+        self.do_center, self.do_m5bias, self.enc_noise = do_center, do_m5bias, enc_noise
+        super().__init__(energy_func, 784, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, "none", "concat")
+        self.enc_type = enc_type
+
+
+class MNISTResConvAuxIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/auxresconv.py::ImplicitPosteriorVAE (`--model auxresconvct`, the shipped "hierarchical resconv" recipe): the
+    residual-conv trunk shared by a Gaussian z0 head and the z head (log-variances clipped 'spm4'), the residual-conv decoder; its
+    hidden1a cDAE context is h [B, c_dim].  A sampler call takes two draws: noise = (eps0 [rows, z0_dim], eps [rows, z_dim])."""
+    _kind = "auxresconv"
+
+    def __init__(self, energy_func=normal_energy_func, input_height=28, input_channels=1, z0_dim=100, z_dim=32, c_dim=450, nonlinearity="elu",
+                 do_center=False, do_m5bias=False):
+        assert input_height == 28 and input_channels == 1 and nonlinearity == "elu"     # ivae/auxresconv.py:67-69
+        if not do_center or do_m5bias:
+            raise NotImplementedError("the HIP engine builds MNISTResConvAuxIPVAE as --model auxresconvct does (do_center=True, no do_m5bias)")
+        self.input_height, self.input_channels, self.z0_dim, self.c_dim, self.do_center, self.do_m5bias = input_height, input_channels, z0_dim, c_dim, True, False
+        super().__init__(energy_func, 784, z0_dim, c_dim, z_dim, nonlinearity, 1, "none", "concat")
 
 
 class ToyIPVAE(ImplicitPosteriorVAE):

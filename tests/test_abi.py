@@ -39,11 +39,13 @@ def test_abi_version_and_error_channel():
 
 
 @pytest.mark.parametrize("kind,args", [("mnist", (784, 100, 256, 32, 2)), ("toy", (2, 10, 256, 2, 2)), ("mnist", (24, 10, 64, 8, 2)),
-                                       ("conv", (784, 100, 800, 32, 1)), ("auxmnist", (784, 100, 300, 32, 2)), ("auxmnist", (24, 10, 48, 8, 3)), ("auxconv", (784, 100, 800, 32, 1))])
+                                       ("conv", (784, 100, 800, 32, 1)), ("auxmnist", (784, 100, 300, 32, 2)), ("auxmnist", (24, 10, 48, 8, 3)), ("auxconv", (784, 100, 800, 32, 1)),
+                                       ("resconv", (784, 100, 512, 32, 1)), ("auxresconv", (784, 100, 450, 32, 1))])
 def test_model_layout_matches_c_side(kind, args):
     spec = layout.model_spec(kind, *args)
     _, total = layout.offsets(spec)
-    d = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4}[kind], *args, 2)
+    d = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4, "resconv": 5, "auxresconv": 6}[kind], *args,
+                    3 if "resconv" in kind else 2)
     assert L.lib().ardae_model_param_floats(ctypes.byref(d)) == total
     assert L.lib().ardae_model_packed_floats(ctypes.byref(d)) > total
     assert L.lib().ardae_model_workspace_floats(ctypes.byref(d), 8, 16, 1) > 0
@@ -68,6 +70,9 @@ def test_survey_parameter_counts():
     assert tot(layout.cdae_spec("grad", 32, 32, 512, 4)) == 2923521
     assert tot(layout.model_spec("conv", 784, 100, 800, 32, 1)) == 757773
     assert tot(layout.cdae_spec("res", 32, 32, 1024, 6)) == 17943584
+    # the reference's own parameter counts of the two residual-conv models (oracle/gen_golden.py asserts names and shapes against them)
+    assert tot(layout.model_spec("resconv", 784, 100, 512, 32, 1)) == 2961487
+    assert tot(layout.model_spec("auxresconv", 784, 100, 450, 32, 1)) == 2151637
 
 
 def test_modules_refuse_cpu_execution():

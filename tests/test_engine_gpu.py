@@ -25,11 +25,22 @@ CASES = {
     "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, True),
     # the shipped "hierarchical conv" recipe's model family (run_vae_dbmnist.sh --model auxconv, hidden1a context of 1600 columns)
     "auxconv_b4_nz8": (O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 1600, 64, 2), 8, False),
+    # the shipped "implicit resconv" / "hierarchical resconv" recipes' model families (--model resconvct-res / auxresconvct, ELU,
+    # mlp-res cDAE, --std-scale 100, Adam (0.9, 0.999) lr 1e-3, RMSprop momentum 0.9; the second with the hidden1a context of 450 columns)
+    "resconv_b4_nz8": (O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu"), O.CdaeCfg("res", 32, 32, 64, 2), 8, False),
+    "auxresconv_b4_nz8": (O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu"), O.CdaeCfg("res", 32, 450, 64, 2), 8, False),
 }
+RES_RECIPE = dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)     # run_vae_dbmnist.sh, the two resconv lines
 
 
 def build(mc, cc):
-    if mc.kind == "auxconv":
+    if mc.kind == "resconv":
+        model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers, noise_dim=mc.noise_dim,
+                                 nonlinearity=mc.nonlin, do_center=True, enc_type="res-wn-mlp")
+    elif mc.kind == "auxresconv":
+        model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim, nonlinearity=mc.nonlin,
+                                         do_center=True)
+    elif mc.kind == "auxconv":
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "auxmnist":
         model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
@@ -87,7 +98,9 @@ def noise_of(fx, t, dev):
 
 
 def train_config(mc, nz, **kw):
-    return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a" if mc.kind in ("auxmnist", "auxconv") else "lt0", **kw)
+    if mc.kind in ("resconv", "auxresconv"):
+        kw = dict(RES_RECIPE, **kw)
+    return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a" if mc.kind in O.AUX_KINDS else "lt0", **kw)
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -631,5 +644,66 @@ def test_iwae_logprob_golden_auxconv(golden_dir):
     got = model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=k,
                         enc_noise=(torch.tensor(fx["enc_noise"]).float().cuda(), torch.tensor(fx["enc_noise_z"]).float().cuda()),
                         prop_noise=torch.tensor(fx["prop_noise"]).float().cuda())
+    ref = float(fx["logprob"])
+    assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
+
+
+@pytest.mark.parametrize("name", ["resconv_b4_nz8", "auxresconv_b4_nz8"])
+def test_resconv_vae_phase_grads_vs_oracle(golden_dir, name):
+    """The weight-normalised residual-conv families: EVERY gradient tensor of the VAE phase - direction, scale and bias
+    of all 45 weight-normalised operators (conv trunk, ResLinear / ResMLP sampler head or the two Gaussian heads with 'spm4' clipping,
+    ResLinear + upsampling ResConv decoder) - against the oracle (pinned to the reference's own classes at 4e-14 / 2e-13 in float64),
+    plus the cDAE context (lt0 / hidden1a) and the decoder-only entry point."""
+    mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, name)
+    model, cdae = build(mc, cc)
+    assert [k for k in model.state_dict()] == [n for n, _ in O.model_param_spec(mc)]
+    model.load_state_dict(pm); cdae.load_state_dict(pc)
+    model, cdae = model.to("cuda"), cdae.to("cuda")
+    B = int(fx["meta_B"])
+    tcfg = train_config(mc, nz)
+    tc = O.TrainCfg(nz_cdae=nz, ctx_type=tcfg.cdae_ctx_type, **RES_RECIPE)
+    eng = net.ArdaeEngine(model, cdae, tcfg, batch_size=B)
+    noise = noise_of(fx, 0, "cuda")
+    xv = torch.tensor(fx["s0/x_vae"])
+    if mc.kind == "auxresconv":
+        hid = model.encode.forward_hidden(xv.cuda(), std=0)
+        assert hid.shape == (B, 450) and rel_l2(hid, O.cdae_context(mc, tc, pm, xv)) < 1e-5
+    z0 = model.encode(xv.cuda(), std=0)
+    assert rel_l2(z0.reshape(B, -1), O.encode(mc, pm, xv, O.zero_noise(mc, B, xv), 1).reshape(B, -1)) < 1e-5
+    eng.vae_phase(xv.cuda(), noise=noise, apply_update=False)
+    cpu_noise = {k[len("s0/noise/"):]: torch.tensor(v) for k, v in fx.items() if k.startswith("s0/noise/")}
+    mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, tc, pm, pc, xv, cpu_noise)
+    s = eng.stats()
+    assert rel(s["model_loss"], mloss) < 1e-4 and rel(s["recon"], rec) < 2e-5 and rel(s["prior"], pri) < 2e-5
+    off = 0
+    for n, shp in O.model_param_spec(mc):
+        k = int(np.prod(shp))
+        assert rel_l2(eng.grads_m[off:off + k].cpu(), gm[n].reshape(-1)) < 2e-3, n
+        off += k
+    z = torch.randn(6, mc.z_dim)
+    (logit,) = model.decode_params(z.cuda())
+    assert rel_l2(logit, O.decode(mc, pm, z)[0]) < 1e-5
+    # more Monte-Carlo samples than the fixture has: the sampler on B * 40 rows against the oracle
+    gsm = torch.Generator().manual_seed(3)
+    wide = torch.randn(B * 40, model._noise_width, generator=gsm)
+    zs = model.forward_hidden(xv.cuda(), nz=40, noise=wide.cuda())
+    nref = (wide[:, :mc.noise_dim], wide[:, mc.noise_dim:]) if mc.kind == "auxresconv" else wide
+    assert rel_l2(zs.reshape(B * 40, -1), O.encode(mc, pm, xv, nref, 40).reshape(B * 40, -1)) < 1e-5
+
+
+@pytest.mark.parametrize("name,kind,h", [("iwae_resconv", "resconv", 512), ("iwae_auxresconv", "auxresconv", 450)])
+def test_iwae_logprob_golden_resconv(golden_dir, name, kind, h):
+    """logprob (ivae/resconv.py:325-380, ivae/auxresconv.py:275-345) of the residual-conv models against the reference's value with injected draws."""
+    fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    mc = O.ModelCfg(kind, 784, 100, h, 32, 1, "elu")
+    pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc))
+    model, _ = build(mc, O.CdaeCfg("res", 32, 450 if kind == "auxresconv" else 32, 32, 2))
+    model.load_state_dict(pm)
+    model = model.to("cuda")
+    k = int(fx["meta_k"])
+    enc = torch.tensor(fx["enc_noise"]).float().cuda()
+    if "enc_noise_z" in fx:
+        enc = (enc, torch.tensor(fx["enc_noise_z"]).float().cuda())
+    got = model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=k, enc_noise=enc, prop_noise=torch.tensor(fx["prop_noise"]).float().cuda())
     ref = float(fx["logprob"])
     assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
