@@ -44,6 +44,17 @@ def cfg(i):
         c = net.MLPGradCARDAE(input_dim=32, context_dim=1600, std=1., h_dim=256, num_hidden_layers=5, nonlinearity="softplus",
                               noise_type="gaussian", enc_ctx=True, enc_input=True)
         return m, c, 128, 625, lambda B, dev: (torch.rand(B, 1, 28, 28, device=dev) < 0.13).float(), dict(z=32, h=256, L=5, kind="grad", ctx="hidden1a")
+    if i in (9, 10):   # the shipped "implicit resconv" / "hierarchical resconv" recipes (run_vae_dbmnist.sh: --model resconvct-res / auxresconvct, ELU,
+        # --cdae mlp-res h 512 L 5, nz_cdae 625, --std-scale 100, --num-cdae-updates 2, Adam (0.9, 0.999) lr 1e-3, RMSprop momentum 0.9)
+        if i == 9:
+            m = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=32, h_dim=512, num_hidden_layers=1, noise_dim=100, nonlinearity="elu",
+                                 do_center=True, enc_type="res-wn-mlp")
+        else:
+            m = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=32, c_dim=450, z0_dim=100, nonlinearity="elu", do_center=True)
+        c = net.MLPResCARDAE(input_dim=32, context_dim=32 if i == 9 else 450, std=1., h_dim=512, num_hidden_layers=5, nonlinearity="softplus",
+                             noise_type="gaussian", enc_ctx=True, enc_input=True)
+        return m, c, 128, 625, lambda B, dev: (torch.rand(B, 1, 28, 28, device=dev) < 0.13).float(), dict(
+            z=32, h=512, L=5, kind="res", ctx="lt0" if i == 9 else "hidden1a", updates=2, tcfg=dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9))
     raise SystemExit(f"no config {i}")
 
 def cdae_flops(B, nz, z, h, L, kind):
@@ -58,7 +69,8 @@ for i in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5]:
     torch.manual_seed(0)
     m, c, B, nz, data, shp = cfg(i)
     m, c = m.to(dev), c.to(dev)
-    eng = net.ArdaeEngine(m, c, net.TrainConfig(nz_cdae=nz, cdae_ctx_type=shp.pop("ctx", "lt0")), batch_size=B)
+    updates = shp.pop("updates", 1)
+    eng = net.ArdaeEngine(m, c, net.TrainConfig(nz_cdae=nz, cdae_ctx_type=shp.pop("ctx", "lt0"), num_cdae_updates=updates, **shp.pop("tcfg", {})), batch_size=B)
     x1, x2 = data(B, dev), data(B, dev)
     steps = int(os.environ.get("CFG_STEPS", "20" if i < 4 else "5"))
     for _ in range(3):
@@ -69,7 +81,7 @@ for i in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5]:
         eng.step(x1, x2)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    fl = cdae_flops(B, nz, **shp)
+    fl = updates * cdae_flops(B, nz, **shp)
     st = eng.stats()
     print(f"config #{i}: {B} images x {nz} samples per GPU: {dt*1e3:8.2f} ms/step  {1/dt:7.1f} steps/s  cDAE-update FLOPs {fl/1e12:.3f} T -> >= {fl/dt/1e12:5.1f} TFLOP/s"
           f"  (cdae_loss {st['cdae_loss']:.4f}, model_loss {st['model_loss']:.2f})", flush=True)
