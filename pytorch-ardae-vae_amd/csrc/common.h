@@ -7,6 +7,7 @@
 
 namespace ardae {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -56,19 +57,74 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2, ACT_ELU = 3 };   
 // for in matrix time: branch-free, ~11 instructions each.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
+// x < thr ? lo : hi as compare + v_cndmask.  Written as asm because the compiler turns a `?:` whose arms hold a transcendental
+// into a divergent branch per element (saveexec / xor / or around each arm: +5 scalar instructions and no interleaving of
+// neighbouring elements - 64 such diamonds per tile in the N-row epilogues).
+__device__ __forceinline__ float select_lt(float x, float thr, float lo, float hi) {
+  float r;
+  asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(r) : "v"(x), "v"(thr), "v"(hi), "v"(lo) : "vcc");
+  return r;
+}
+
 __device__ __forceinline__ float softplus_f(float x) {
   // max(x,0) + log1p(exp(-|x|)) is the overflow-free form of log(1+exp(x)).  F.softplus' threshold (x > 20 -> x) needs no
   // select: there exp(-x) < 2.1e-9 is below half an ulp of x, so the sum rounds to x exactly.
   const float t = fast_exp(-fabsf(x));
   const float series = t * (1.f - t * (0.5f - t * (1.f / 3.f)));                  // log1p(t), |err| < t^4/4
   const float direct = __builtin_amdgcn_logf(1.f + t) * 0.693147180559945309f;    // rounding of 1+t: rel. err <= 6e-8 / t
-  return fmaxf(x, 0.f) + (t < 8e-3f ? series : direct);
+  return fmaxf(x, 0.f) + select_lt(t, 8e-3f, series, direct);
 }
 
 // softplus'(pre) = sigmoid(pre) = 1 - exp(-a) from the saved output a = softplus(pre)
 __device__ __forceinline__ float softplus_d1_from_out(float a) {
   const float series = a * (1.f - a * (0.5f - a * (1.f / 6.f)));
-  return a < 0.02f ? series : 1.f - fast_exp(-a);
+  return select_lt(a, 0.02f, series, 1.f - fast_exp(-a));
+}
+
+// Two elements at a time: everything that is not a transcendental or a select becomes one packed instruction
+// (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two FP32 results per lane per issue slot).  Same arithmetic as the scalar forms.
+__device__ __forceinline__ f32x2 softplus_f2(f32x2 x) {
+  f32x2 t;
+  t[0] = __builtin_amdgcn_exp2f(__builtin_fabsf(x[0]) * -1.44269504088896341f);
+  t[1] = __builtin_amdgcn_exp2f(__builtin_fabsf(x[1]) * -1.44269504088896341f);
+  const f32x2 series = t * (1.f - t * (0.5f - t * (1.f / 3.f)));
+  const f32x2 w = 1.f + t;
+  f32x2 lg;
+  lg[0] = __builtin_amdgcn_logf(w[0]);
+  lg[1] = __builtin_amdgcn_logf(w[1]);
+  const f32x2 direct = lg * 0.693147180559945309f;
+  f32x2 r;
+  r[0] = fmaxf(x[0], 0.f);
+  r[1] = fmaxf(x[1], 0.f);
+  f32x2 l1p;
+  l1p[0] = select_lt(t[0], 8e-3f, series[0], direct[0]);
+  l1p[1] = select_lt(t[1], 8e-3f, series[1], direct[1]);
+  return r + l1p;
+}
+// em = exp(-a) (= 1 - sigmoid) is handed back too: the CHAIN epilogue of the N-row kernel needs it
+__device__ __forceinline__ f32x2 softplus_d1_from_out2(f32x2 a, f32x2& em) {
+  const f32x2 t = a * -1.44269504088896341f;
+  em[0] = __builtin_amdgcn_exp2f(t[0]);
+  em[1] = __builtin_amdgcn_exp2f(t[1]);
+  const f32x2 direct = 1.f - em;
+  const f32x2 series = a * (1.f - a * (0.5f - a * (1.f / 6.f)));
+  f32x2 r;
+  r[0] = select_lt(a[0], 0.02f, series[0], direct[0]);
+  r[1] = select_lt(a[1], 0.02f, series[1], direct[1]);
+  return r;
+}
+template <int ACT>
+__device__ __forceinline__ f32x2 act_fwd2(f32x2 x) {
+  if (ACT == ACT_RELU) { f32x2 r; r[0] = fmaxf(x[0], 0.f); r[1] = fmaxf(x[1], 0.f); return r; }
+  if (ACT == ACT_SOFTPLUS) return softplus_f2(x);
+  return x;
+}
+template <int ACT>
+__device__ __forceinline__ f32x2 act_d1_2(f32x2 a, f32x2& em) {
+  if (ACT == ACT_RELU) { f32x2 r; r[0] = a[0] > 0.f ? 1.f : 0.f; r[1] = a[1] > 0.f ? 1.f : 0.f; em = 1.f - r; return r; }
+  if (ACT == ACT_SOFTPLUS) return softplus_d1_from_out2(a, em);
+  em = f32x2{0.f, 0.f};
+  return f32x2{1.f, 1.f};
 }
 
 template <int ACT>

@@ -43,6 +43,10 @@
 #include "linear.h"
 #include "profile.h"
 
+// Epilogue operands are read once and results are not re-read before >= 100 MB of other traffic has passed: non-temporal
+// (no allocation in the L2 / MALL ahead of the activation panels); +1 % on the whole step (A/B on one device, round 2).
+#define ARDAE_NT_LD " nt"
+#define ARDAE_NT_ST " nt"
 namespace ardae {
 namespace wide {
 
@@ -94,12 +98,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
 // "+v": the destination is TIED to the register of the value it replaces (the previous tile's result, stored a few chunks
 // earlier), so that an epilogue operand / result slot is one physical register for the whole kernel - no copies at the loop
 // back-edge, and a register budget the compiler cannot exceed by renaming (NLT = NST = 2 needs 128 such slots)
-template <int OFF>
-__device__ __forceinline__ void bload1(float& dst, unsigned voff, const i32x4& rsrc, unsigned soff) {
-  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen offset:%4" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
+// Slots are register PAIRS (two consecutive rows of an accumulator column: what the packed FP32 instructions of the epilogue
+// arithmetic want); H = which half this dword lands in.
+template <int OFF, int H>
+__device__ __forceinline__ void bload1(f32x2& dst, unsigned voff, const i32x4& rsrc, unsigned soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen offset:%4" ARDAE_NT_LD : "+v"(dst[H]) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void bstore1(unsigned voff, float v, const i32x4& rsrc, unsigned soff) {
-  asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, %3 offen" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, %3 offen" ARDAE_NT_ST ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void lds_read4(f32x4& dst, unsigned addr) {
@@ -116,12 +122,8 @@ __device__ __forceinline__ void wait_panel(f32x4 (&x)[NX]) {
   else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "n"(VM) : "memory");
 }
 template <int VM>
-__device__ __forceinline__ void wait16(float* v) {
-  asm volatile("s_waitcnt vmcnt(%16)"
-               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-               : "n"(VM)
-               : "memory");
+__device__ __forceinline__ void wait16(f32x2* v) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "n"(VM) : "memory");
 }
 
 // panel geometry for NCH chunks of 8 k: 2*NCH float4 per row, 256 / (2*NCH) rows per pass, NX passes
@@ -150,6 +152,12 @@ __device__ __forceinline__ void bload4(f32x4& dst, unsigned voff, const i32x4& r
 // a 1-KiB fragment of the packed weight image straight into four AGPRs
 __device__ __forceinline__ void gload4_agpr(f32x4& dst, unsigned voff, const float* sbase) {
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=a"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// first tile only: the slab loads are still landing (in order) while the K loop starts - chunk g waits for ITS fragment
+template <int VM, int NJ>
+__device__ __forceinline__ void wait_slab(f32x4 (&b)[NJ]) {
+  if constexpr (NJ == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+a"(b[0]), "+a"(b[1]) : "n"(VM) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%1)" : "+a"(b[0]) : "n"(VM) : "memory");   // (the same variable twice would be two operands: copies)
 }
 // acc += A x B (one k-pair); FIRST: the tile's first MFMA of this accumulator (SrcC = 0, no zero-initialisation needed);
 // LAST: the tile's very last MFMA.  The hazard recogniser does not see inline-asm MFMAs, and the compiler is free to put its own
@@ -193,6 +201,14 @@ struct Sched {
     for (int k = 0; k < XW; ++k) n += vmem(p * NCH + k);
     return n > 63 ? 63 : n;
   }
+  // first tile (the prologue issues: first panel, then the slab in chunk order): vector-memory operations younger than the
+  // slab fragment of chunk g = (p, c) when that chunk starts.  vmcnt retires in order, so capping at 63 only waits longer.
+  static constexpr int vm_slab(int p, int c) {
+    const int g = p * NCH + c;
+    int n = (G - 1 - g) * NJ + NX * (c > 0 ? p + 1 : p);
+    for (int k = 0; k < g; ++k) n += vmem(k);
+    return n > 63 ? 63 : n;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -213,7 +229,7 @@ struct WideEpi {
   unsigned vY, vY2, vL0, vL1, vRS, vC;   // per-lane byte offsets
   i32x4 rY, rY2, rL0, rL1, rRS;          // buffer descriptors: Y, Y2, first / second loaded tensor, per-row sigma
   unsigned sY, sY2, sL0, sL1;            // their row strides in bytes
-  float bcol[2], wsig[2], wfc[2];
+  float bcol0, wsig0, wfc0; unsigned pad_; float bcol1, wsig1, wfc1;   // column operands of the wave's two 32-column blocks.  Scalars, and the two blocks' values NOT adjacent: as arrays (or adjacent floats) the compiler paired wsig0/wsig1 through a stack slot to feed op_sel broadcasts of the packed instructions
   int colw_loaded;
 
   __device__ __forceinline__ WideEpi(const LinArgs& a_, int lane) : a(a_), colw_loaded(-1) {
@@ -224,7 +240,7 @@ struct WideEpi {
     vL1 = (EPI == EPI_CHAIN) ? (unsigned)((4 * hh * a.ldR + l31) * 4) : (EPI == EPI_DACT && F1) ? (unsigned)((4 * hh * a.ldQ + l31) * 4) : 0u;
     vRS = (unsigned)(16 * hh);
     vC = (unsigned)(l31 * 4);
-    bcol[0] = bcol[1] = wsig[0] = wsig[1] = wfc[0] = wfc[1] = 0.f;
+    bcol0 = bcol1 = wsig0 = wsig1 = wfc0 = wfc1 = 0.f;
     const unsigned M = (unsigned)a.M;
     const float* y2 = a.Y2 ? a.Y2 : a.Y;
     const int ld2 = a.Y2 ? a.ldY2 : a.ldY;
@@ -248,9 +264,10 @@ struct WideEpi {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = colw + 32 * j + l31;
-      bcol[j] = a.bias ? a.bias[col] : 0.f;
-      wsig[j] = (F2 && a.rowscale_w) ? a.rowscale_w[col] : 0.f;
-      wfc[j] = (F1 && a.R) ? a.R[col] : 0.f;
+      const float b = a.bias ? a.bias[col] : 0.f;
+      const float w = (F2 && a.rowscale_w) ? a.rowscale_w[col] : 0.f;
+      const float f = (F1 && a.R) ? a.R[col] : 0.f;
+      if (j == 0) { bcol0 = b; wsig0 = w; wfc0 = f; } else { bcol1 = b; wsig1 = w; wfc1 = f; }
     }
   }
 
@@ -262,94 +279,95 @@ struct WideEpi {
     gload1<128 * JJ>(rbj, vC, p);
   }
 
-  // results replace the operands in place: l0[e] <- Y, l1[e] <- Y2
+  // results replace the operands in place: l0 <- Y, l1 <- Y2; one register pair = accumulator elements 2k, 2k + 1 of the half-block
   template <int HB>
-  __device__ __forceinline__ void math(const f32x16& acc16, float* l0, float* l1, float brow, float& csum) const {
+  __device__ __forceinline__ void math(const f32x16& acc16, f32x2* l0, f32x2* l1, float brow, f32x2& csum) const {
     constexpr int J = HB >> 2, H = HB & 1;
+    const float ws = J == 0 ? wsig0 : wsig1, nw = -(J == 0 ? wfc0 : wfc1);
+    const f32x2 brow2 = {brow, brow}, wsig2 = {ws, ws}, nwfc2 = {nw, nw};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = acc16[8 * H + e];
-      float y, y2 = 0.f;
+    for (int k = 0; k < 4; ++k) {
+      f32x2 v;
+      v[0] = acc16[8 * H + 2 * k];
+      v[1] = acc16[8 * H + 2 * k + 1];
+      f32x2 em;
       if (EPI == EPI_ACT) {
-        y = act_fwd<ACT>((F2 && a.rowscale) ? __builtin_fmaf(l0[e], wsig[J], v + brow) : v + brow);
-        if (F1) y2 = a.Y2 ? -wfc[J] * act_d1<ACT>(y) : y;
+        f32x2 x = v + brow2;
+        if (F2 && a.rowscale) x = l0[k] * wsig2 + x;
+        const f32x2 y = act_fwd2<ACT>(x);
+        if (NST == 2) l1[k] = (F1 && a.Y2) ? nwfc2 * act_d1_2<ACT>(y, em) : y;
+        l0[k] = y;
       } else if (EPI == EPI_DACT) {
         // result IN PLACE (see EPI_CHAIN below): the final multiply-add is asm with the slot as a read-write operand
-        const float d1 = act_d1<ACT>(l0[e]);
-        if (F1) asm volatile("v_fma_f32 %0, %1, %2, %3" : "+v"(l0[e]) : "v"(v), "v"(d1), "v"(l1[e]));
-        else asm volatile("v_mul_f32 %0, %1, %2" : "+v"(l0[e]) : "v"(v), "v"(d1));
-        csum += l0[e];
-        continue;
+        const f32x2 d1 = act_d1_2<ACT>(l0[k], em);
+        if (F1) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "+v"(l0[k]) : "v"(v), "v"(d1), "v"(l1[k]));
+        else asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(l0[k]) : "v"(v), "v"(d1));
       } else {
         // both results IN PLACE, by construction: the final multiplies are asm with the slot as a read-write operand
-        const float em = (ACT == ACT_SOFTPLUS) ? fast_exp(-l0[e]) : 0.f;   // 1 - s without cancellation
-        const float d1 = act_d1<ACT>(l0[e]);
-        const float vem = v * em;
-        asm volatile("v_mul_f32 %0, %1, %2" : "+v"(l0[e]) : "v"(v), "v"(d1));   // Y  = V s
-        asm volatile("v_mul_f32 %0, %1, %0" : "+v"(l1[e]) : "v"(vem));          // Y2 = V R (1 - s)
-        csum += l0[e];
-        continue;
+        const f32x2 d1 = act_d1_2<ACT>(l0[k], em);                                  // em = 1 - s without cancellation
+        const f32x2 vem = v * em;
+        asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(l0[k]) : "v"(v), "v"(d1));   // Y  = V s
+        asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(l1[k]) : "v"(vem));          // Y2 = V R (1 - s)
       }
-      csum += y;
-      l0[e] = y;
-      if (NST == 2) l1[e] = y2;
+      csum += l0[k];
     }
   }
 
   template <int HB>
-  __device__ __forceinline__ void stores(const float* y, const float* y2, int row0, int colw) const {
+  __device__ __forceinline__ void stores(const f32x2* y, const f32x2* y2, int row0, int colw) const {
     constexpr int J = HB >> 2, I = (HB >> 1) & 1, H = HB & 1;
     const unsigned r0 = (unsigned)(row0 + 32 * I + 16 * H), c4 = (unsigned)(colw + 32 * J) * 4u;
     unsigned oy = r0 * sY + c4;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      bstore1(vY, y[e], rY, oy);
+      bstore1(vY, y[e >> 1][e & 1], rY, oy);
       oy += (e == 3) ? 5u * sY : sY;
     }
     if (NST == 2) {
       unsigned o2 = r0 * sY2 + c4;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        bstore1(vY2, y2[e], rY2, o2);
+        bstore1(vY2, y2[e >> 1][e & 1], rY2, o2);
         o2 += (e == 3) ? 5u * sY2 : sY2;
       }
     }
   }
 
-  __device__ __forceinline__ void store_all(const float* y, const float* y2, int row0, int colw) const {
-    stores<0>(y + 0, y2 + 0, row0, colw); stores<1>(y + 8, y2 + 8, row0, colw); stores<2>(y + 16, y2 + 16, row0, colw);
-    stores<3>(y + 24, y2 + 24, row0, colw);
+  __device__ __forceinline__ void store_all(const f32x2* y, const f32x2* y2, int row0, int colw) const {
+    stores<0>(y + 0, y2 + 0, row0, colw); stores<1>(y + 4, y2 + 4, row0, colw); stores<2>(y + 8, y2 + 8, row0, colw);
+    stores<3>(y + 12, y2 + 12, row0, colw);
     if constexpr (NJ == 2) {
-      stores<4>(y + 32, y2 + 32, row0, colw); stores<5>(y + 40, y2 + 40, row0, colw);
-      stores<6>(y + 48, y2 + 48, row0, colw); stores<7>(y + 56, y2 + 56, row0, colw);
+      stores<4>(y + 16, y2 + 16, row0, colw); stores<5>(y + 20, y2 + 20, row0, colw);
+      stores<6>(y + 24, y2 + 24, row0, colw); stores<7>(y + 28, y2 + 28, row0, colw);
     }
   }
 
   template <int VM, bool STORE_NOW>
-  __device__ __forceinline__ void run(f32x16 (&acc)[2][NJ], float* l0, float* l1, float (&rb)[NJ], int lane, int row0, int colw, int tile_row) const {
+  __device__ __forceinline__ void run(f32x16 (&acc)[2][NJ], f32x2* l0, f32x2* l1, float (&rb)[NJ], int lane, int row0, int colw, int tile_row) const {
     // one wait for everything the epilogue reads (issued >= NCH/2 chunks ago)
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rb[0]), "+v"(rb[NJ - 1]) : "n"(VM) : "memory");
-    if (NLT >= 1) { wait16<VM>(l0); wait16<VM>(l0 + 16); if (NJ == 2) { wait16<VM>(l0 + 32); wait16<VM>(l0 + 48); } }
-    if (NLT == 2) { wait16<VM>(l1); wait16<VM>(l1 + 16); if (NJ == 2) { wait16<VM>(l1 + 32); wait16<VM>(l1 + 48); } }
+    if (NLT >= 1) { wait16<VM>(l0); wait16<VM>(l0 + 8); if (NJ == 2) { wait16<VM>(l0 + 16); wait16<VM>(l0 + 24); } }
+    if (NLT == 2) { wait16<VM>(l1); wait16<VM>(l1 + 8); if (NJ == 2) { wait16<VM>(l1 + 16); wait16<VM>(l1 + 24); } }
     const bool has_rb = EPI == EPI_ACT && a.rowbias != nullptr;
-    const float br0 = bcol[0] + (has_rb ? rb[0] : 0.f), br1 = bcol[1] + (has_rb ? rb[NJ - 1] : 0.f);
-    float csum[2] = {0.f, 0.f};
+    const float br0 = bcol0 + (has_rb ? rb[0] : 0.f), br1 = bcol1 + (has_rb ? rb[NJ - 1] : 0.f);
+    f32x2 csum[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     // one half-block at a time (the scheduler would otherwise interleave all 64 elements and run out of registers)
     math<0>(acc[0][0], l0 + 0, l1 + 0, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
-    math<1>(acc[0][0], l0 + 8, l1 + 8, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
-    math<2>(acc[1][0], l0 + 16, l1 + 16, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
-    math<3>(acc[1][0], l0 + 24, l1 + 24, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
+    math<1>(acc[0][0], l0 + 4, l1 + 4, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
+    math<2>(acc[1][0], l0 + 8, l1 + 8, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
+    math<3>(acc[1][0], l0 + 12, l1 + 12, br0, csum[0]); __builtin_amdgcn_sched_barrier(0);
     if constexpr (NJ == 2) {
-      math<4>(acc[0][1], l0 + 32, l1 + 32, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
-      math<5>(acc[0][1], l0 + 40, l1 + 40, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
-      math<6>(acc[1][1], l0 + 48, l1 + 48, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
-      math<7>(acc[1][1], l0 + 56, l1 + 56, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+      math<4>(acc[0][1], l0 + 16, l1 + 16, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+      math<5>(acc[0][1], l0 + 20, l1 + 20, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+      math<6>(acc[1][1], l0 + 24, l1 + 24, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
+      math<7>(acc[1][1], l0 + 28, l1 + 28, br1, csum[1]); __builtin_amdgcn_sched_barrier(0);
     }
     if (STORE_NOW) store_all(l0, l1, row0, colw);
     if (a.colsum != nullptr) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const float c2 = csum[j] + __shfl_xor(csum[j], 32);
+        const float c1 = csum[j][0] + csum[j][1];
+        const float c2 = c1 + __shfl_xor(c1, 32);
         if (lane < 32) a.colsum[(size_t)tile_row * a.Nout + colw + 32 * j + lane] = c2;
       }
     }
@@ -369,7 +387,7 @@ struct PanelCtx {
 // One chunk: wait for its A fragments (LDS), then 8 NJ MFMAs with the chunk's memory instructions spread evenly behind them
 // (an MFMA keeps the pipe busy for 64 cycles while the wave is free to issue; with one wave per SIMD nobody else would fill
 // a gap, and more than a handful of instructions behind one MFMA is a gap).
-template <int C, int P, int NCH, int NP, bool HP, class EPI_T>
+template <int C, int P, int NCH, int NP, bool HP, bool FT, class EPI_T>
 struct ChunkOps {
   using SC = Sched<NCH, NP, EPI_T::NJ, EPI_T::NLT, EPI_T::NST, HP>;
   static constexpr int NX = PanelGeo<NCH>::NX;
@@ -386,7 +404,7 @@ struct ChunkOps {
   };
 
   template <int K>
-  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&xv)[NX], float* l0, float* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
+  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     using PG = PanelGeo<NCH>;
     const EPI_T& ep = x.epi;
     if constexpr (K < o_x) {   // fragment read of the next chunk (chunk 0 of the next panel after the last one)
@@ -408,11 +426,11 @@ struct ChunkOps {
       constexpr int roff = 32 * I + 16 * H + (e & 3) + 8 * (e >> 2);
       if constexpr (tns == 0) {
         if constexpr (fresh) q.py = (unsigned)(x.prev_row0 + roff) * ep.sY + (unsigned)(x.colw + 32 * J) * 4u;
-        bstore1(ep.vY, l0[8 * HB + e], ep.rY, q.py);
+        bstore1(ep.vY, l0[4 * HB + (e >> 1)][e & 1], ep.rY, q.py);
         q.py += (e == 3) ? 5u * ep.sY : ep.sY;
       } else {
         if constexpr (fresh) q.py2 = (unsigned)(x.prev_row0 + roff) * ep.sY2 + (unsigned)(x.colw + 32 * J) * 4u;
-        bstore1(ep.vY2, l1[8 * HB + e], ep.rY2, q.py2);
+        bstore1(ep.vY2, l1[4 * HB + (e >> 1)][e & 1], ep.rY2, q.py2);
         q.py2 += (e == 3) ? 5u * ep.sY2 : ep.sY2;
       }
     } else if constexpr (K < o_op) {
@@ -427,14 +445,14 @@ struct ChunkOps {
       constexpr int roff = 32 * I + 16 * H + (e & 3) + 8 * (e >> 2);      // row of element e inside the tile (without the lane part)
       if constexpr (EPI_T::SIGMA_OPERAND) {   // EPI_ACT with a per-row scale: sigma of the row
         constexpr int off = ((e & 3) + 8 * (e >> 2)) * 4;
-        bload1<off>(l0[8 * HB + e], ep.vRS, ep.rRS, (unsigned)(x.row0 + 32 * I + 16 * H) * 4u);
+        bload1<off, (e & 1)>(l0[4 * HB + (e >> 1)], ep.vRS, ep.rRS, (unsigned)(x.row0 + 32 * I + 16 * H) * 4u);
       } else if constexpr (tns == 0) {
         if constexpr (fresh) q.p0 = (unsigned)(x.row0 + roff) * ep.sL0 + (unsigned)(x.colw + 32 * J) * 4u;
-        bload1<0>(l0[8 * HB + e], ep.vL0, ep.rL0, q.p0);
+        bload1<0, (e & 1)>(l0[4 * HB + (e >> 1)], ep.vL0, ep.rL0, q.p0);
         q.p0 += (e == 3) ? 5u * ep.sL0 : ep.sL0;
       } else {
         if constexpr (fresh) q.p1 = (unsigned)(x.row0 + roff) * ep.sL1 + (unsigned)(x.colw + 32 * J) * 4u;
-        bload1<0>(l1[8 * HB + e], ep.vL1, ep.rL1, q.p1);
+        bload1<0, (e & 1)>(l1[4 * HB + (e >> 1)], ep.vL1, ep.rL1, q.p1);
         q.p1 += (e == 3) ? 5u * ep.sL1 : ep.sL1;
       }
     }
@@ -442,7 +460,7 @@ struct ChunkOps {
 
   // the instructions behind MFMA S
   template <int S, int R = 0>
-  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&xv)[NX], float* l0, float* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
+  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     if constexpr (R < PER && S * PER + R < total) {
       op<S * PER + R>(A, xv, l0, l1, rb, x, q);
       slot<S, R + 1>(A, xv, l0, l1, rb, x, q);
@@ -450,7 +468,7 @@ struct ChunkOps {
   }
 
   template <int S>
-  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], float* l0, float* l1,
+  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
                                                float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     if constexpr (S < NMF) {
       constexpr int kq = S / (2 * NJ), i = (S / NJ) & 1, j = S % NJ;
@@ -460,45 +478,46 @@ struct ChunkOps {
     }
   }
 
-  static __device__ __forceinline__ void run(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], float* l0, float* l1,
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
                                              float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x) {
     // this chunk's fragments (and, at XW + 1, this wave's panel writes) have landed in / left for LDS
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[C & 1][0]), "+v"(A[C & 1][1]) : : "memory");
+    if constexpr (FT) wait_slab<SC::vm_slab(P, C), NJ>(Bw[GC]);
     if (C == SC::BAR) __builtin_amdgcn_s_barrier();
     Ptrs q{0u, 0u, 0u, 0u};
     steps<0>(acc, A, Bw, xv, l0, l1, rb, x, q);
   }
 };
 
-template <int P, int NCH, int NP, bool HP, class EPI_T>
-__device__ __forceinline__ void panel(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], float* l0, float* l1,
+template <int P, int NCH, int NP, bool HP, bool FT, class EPI_T>
+__device__ __forceinline__ void panel(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], f32x2* l0, f32x2* l1,
                                       float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x) {
-  ChunkOps<0, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
-  ChunkOps<1, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
-  ChunkOps<2, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
-  ChunkOps<3, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+  ChunkOps<0, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+  ChunkOps<1, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+  ChunkOps<2, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+  ChunkOps<3, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
   if constexpr (NCH == 8) {
-    ChunkOps<4, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
-    ChunkOps<5, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
-    ChunkOps<6, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
-    ChunkOps<7, P, NCH, NP, HP, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+    ChunkOps<4, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+    ChunkOps<5, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+    ChunkOps<6, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+    ChunkOps<7, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
   }
 }
 
 // panels P .. NP-1 of one tile, straight-line: values defined by the asm loads must never meet at a control-flow join
 // (the compiler would reconcile them with register copies - of registers whose loads are still in flight)
-template <int P, int NCH, int NP, bool HP, class EPI_T, class PX>
-__device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], const f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], float* l0,
-                                            float* l1, float (&rb)[EPI_T::NJ], const EPI_T& epi, const i32x4& rX, unsigned xvoff, unsigned xstep, int& buf,
+template <int P, int NCH, int NP, bool HP, bool FT, class EPI_T, class PX>
+__device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], f32x2* l0,
+                                            f32x2* l1, float (&rb)[EPI_T::NJ], const EPI_T& epi, const i32x4& rX, unsigned xvoff, unsigned xstep, int& buf,
                                             unsigned rlane, unsigned wlane, int row0, int colw, int prev_row0, int tile, int tnext, const PX& panel_x) {
   if constexpr (P < NP) {
     constexpr bool lastp = P + 1 == NP;
     const int bnext = buf + 1 == NBUF ? 0 : buf + 1;
     const PanelCtx<NCH, EPI_T> x{epi, rX, xvoff, xstep, panel_x(lastp ? tnext : tile, lastp ? 0 : P + 1), rlane + buf * WBUF_BYTES, rlane + bnext * WBUF_BYTES,
                                  wlane + bnext * WBUF_BYTES, row0, colw, prev_row0};
-    panel<P, NCH, NP, HP>(acc, A, Bw, xv, l0, l1, rb, x);
+    panel<P, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, x);
     buf = bnext;
-    tile_panels<P + 1, NCH, NP, HP>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
+    tile_panels<P + 1, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
   }
 }
 
@@ -545,24 +564,27 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   auto panel_x = [&](int rt, int p) -> unsigned { return (unsigned)(rt * WBM) * ldx4 + (unsigned)(p * 8 * NCH) * 4u; };
 
   f32x4 A[2][2], Bw[G][NJ], xv[NX];
-  float l0[32 * NJ], l1[32 * NJ], rb[NJ];
+  f32x2 l0[16 * NJ], l1[16 * NJ];
+  float rb[NJ];
 #pragma unroll
-  for (int i = 0; i < 32 * NJ; ++i) l0[i] = l1[i] = 0.f;   // the slots' registers exist from here on (tied asm operands read them)
+  for (int i = 0; i < 16 * NJ; ++i) l0[i] = l1[i] = f32x2{0.f, 0.f};   // the slots' registers exist from here on (tied asm operands read them)
   int tile = rt0;   // row tile
   // ---- prologue: the wave's weight slab into its AGPRs, first panel into LDS buffer 0, fragment set 0 in flight
   {
     const unsigned bvoff = (unsigned)lane * 16u;
     const int kch = a.src[0].K >> 3;
     const float* wp = a.src[0].wp + (size_t)(cp * 4 * NJ + wave * NJ) * kch * 256;
+    const unsigned x0 = panel_x(tile, 0);
+#pragma unroll
+    for (int u = 0; u < NX; ++u) bload4<0>(xv[u], xvoff, rX, x0 + (unsigned)u * xstep);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       gload4_agpr(Bw[g][0], bvoff, wp + (size_t)g * 256);
       if constexpr (NJ == 2) gload4_agpr(Bw[g][1], bvoff, wp + ((size_t)kch + g) * 256);
     }
-    const unsigned x0 = panel_x(tile, 0);
-#pragma unroll
-    for (int u = 0; u < NX; ++u) bload4<0>(xv[u], xvoff, rX, x0 + (unsigned)u * xstep);
-    wait_panel<0, NX>(xv);   // everything landed, the slab included (vmcnt retires in order)
+    // the panel is older than the slab: it has landed when at most the NJ G slab loads are outstanding; the slab keeps
+    // landing behind the first tile's MFMAs (ChunkOps<.., FT = true> waits per chunk)
+    wait_panel<(NJ * G > 63 ? 63 : NJ * G), NX>(xv);
     store_panel<NCH, NX>(xv, wlane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -577,8 +599,8 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
   // one tile: K loop (with the previous tile's stores riding along when HP) + epilogue arithmetic
-  auto do_tile = [&](auto hp_tag) {
-    constexpr bool HP = decltype(hp_tag)::value;
+  auto do_tile = [&](auto ft_tag) {
+    constexpr bool FT = decltype(ft_tag)::value, HP = SC::DEFER && !FT;
 #ifdef ARDAE_STAMPS
     const unsigned long long T0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -586,7 +608,7 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
     const int row0 = tr * WBM;
     const int tnext = tile + rts < nrt ? tile + rts : tile;   // none: re-touch this tile (never used)
     f32x16 acc[2][NJ];
-    tile_panels<0, NCH, NP, HP>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
+    tile_panels<0, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
 #ifdef ARDAE_STAMPS
     const unsigned long long T1 = __builtin_amdgcn_s_memtime();
     t_k += T1 - T0;
@@ -618,8 +640,8 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
 #endif
   };
   // the first tile has no predecessor whose stores could ride in its K loop: its own copy of the tile body
-  do_tile(std::false_type{});
-  for (tile += rts; tile < nrt; tile += rts) do_tile(std::integral_constant<bool, SC::DEFER>{});
+  do_tile(std::true_type{});
+  for (tile += rts; tile < nrt; tile += rts) do_tile(std::false_type{});
 #ifndef ARDAE_DBG_NOEPI
   if (SC::DEFER && prev_row0 >= 0) epi.store_all(l0, l1, prev_row0, colw);
 #endif

@@ -15,6 +15,9 @@ disassembles each kernel and scans it linearly:
     MFMA in between, is a violation: linear_wide_kernel's MFMAs are inline asm, which the compiler's hazard recogniser does
     not see (seen once: register copies of the accumulators placed right behind a tile's last MFMA gave wrong values in the
     rows that MFMA writes last).
+  * linear_wide_kernel keeps its weight slab in AGPRs that are still being loaded while the first tile runs: ANY v_accvgpr_*
+    instruction there is a violation (seen once: a wait statement naming one AGPR quadruple twice made the compiler rotate
+    the slab through copies).
 Usage: check_kernel_registers.py <hipcc> <csrc dir> [file.hip ...]   (exit code 1 on violation)"""
 import os
 import re
@@ -42,7 +45,7 @@ def sregs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def scan(code):
+def scan(code, no_agpr_moves=False):
     inflight_g, inflight_l, bad = set(), set(), []
     mfma_dst, mfma_wait = set(), 0      # result registers of the most recent MFMA and the wait states seen since it issued
     valu_sgpr = {}                      # SGPR written by the vector ALU (v_readlane / v_readfirstlane) -> wait states since
@@ -52,6 +55,8 @@ def scan(code):
             continue
         op, _, rest = s.partition(" ")
         ops = [o.strip() for o in rest.split(",")]
+        if no_agpr_moves and op.startswith("v_accvgpr"):
+            bad.append((n, s + "   [copy of a weight-slab AGPR]", []))
         # a scalar operand written by the vector ALU needs 5 wait states before a vector-memory instruction reads it; the compiler
         # inserts them for its own instructions, not for inline asm (every asm VMEM statement here carries its own s_nop 4)
         if op in ("v_readlane_b32", "v_readfirstlane_b32"):
@@ -129,7 +134,7 @@ def check(hipcc, src, inc):
             continue
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\S+)", body).group(1))
         fm = re.search(re.escape(name) + r":.*?s_endpgm", t, re.S)
-        bad = scan(fm.group(0).split("\n"))
+        bad = scan(fm.group(0).split("\n"), no_agpr_moves="linear_wide_kernel" in name)
         if scratch != 0 or bad:
             res.append((name, scratch, bad))
     return src, res
@@ -138,7 +143,7 @@ def check(hipcc, src, inc):
 def main():
     hipcc, csrc = sys.argv[1], sys.argv[2]
     files = sys.argv[3:] or [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))
-                             if re.match(r"(linear_wide_inst_|linear_fchain_inst_|wgrad_wide).*\.hip$", f)]
+                             if re.match(r"(linear_wide_inst_|wgrad_wide).*\.hip$", f)]
     inc = os.path.join(csrc, "..", "..", "include")
     with ThreadPoolExecutor(max_workers=8) as ex:
         results = list(ex.map(lambda f: check(hipcc, f, inc), files))
