@@ -25,8 +25,11 @@ extern "C" {
 #define ARDAE_ABI_VERSION 1
 
 /* activations: reference utils/models.py:14-32 (F.relu, F.softplus beta=1 threshold=20) */
-enum { ARDAE_ACT_NONE = 0, ARDAE_ACT_RELU = 1, ARDAE_ACT_SOFTPLUS = 2,
-       ARDAE_ACT_ELU = 3 /* F.elu: model activation of the residual-conv kinds 5 / 6 only (not an ardae_linear epilogue) */ };
+/* get_nonlinear_func (reference utils/models.py:14-32): relu, softplus ('csoftplus' = log(exp(x) + 1) is the same function; it is evaluated in softplus' overflow- and cancellation-free form), elu (alpha 1), tanh, leaky_relu
+ * (slope 0.2).  'swish' is not offered (derivatives are rebuilt from saved OUTPUTS; x sigmoid(x) is not invertible).  The
+ * software-pipelined N-row kernels exist for NONE / RELU / SOFTPLUS (every shipped recipe); ELU / TANH / LEAKY layers run on the
+ * generic kernels. */
+enum { ARDAE_ACT_NONE = 0, ARDAE_ACT_RELU = 1, ARDAE_ACT_SOFTPLUS = 2, ARDAE_ACT_ELU = 3, ARDAE_ACT_TANH = 4, ARDAE_ACT_LEAKY_RELU = 5 };
 
 /* epilogues of ardae_linear */
 enum {
@@ -146,7 +149,7 @@ typedef struct ardae_cdae_desc {
   int context_dim; /* c */
   int h_dim;
   int n_layers;    /* --cdae-n-layers */
-  int act;         /* ARDAE_ACT_SOFTPLUS (mlp-grad needs a twice-differentiable activation)                          */
+  int act;         /* any ARDAE_ACT_* but NONE (with a piecewise linear one mlp-grad's second-order terms are zero)  */
 } ardae_cdae_desc;
 size_t ardae_cdae_param_floats(const ardae_cdae_desc* d);
 size_t ardae_cdae_packed_floats(const ardae_cdae_desc* d);
@@ -193,7 +196,7 @@ typedef struct ardae_model_desc {
   int kind;
   int input_dim, noise_dim, h_dim, z_dim;
   int n_layers; /* --model-n-layers */
-  int act;      /* ARDAE_ACT_SOFTPLUS | ARDAE_ACT_RELU */
+  int act;      /* any ARDAE_ACT_* but NONE; kinds 5 / 6: ARDAE_ACT_ELU */
 } ardae_model_desc;
 size_t ardae_model_param_floats(const ardae_model_desc* d);
 size_t ardae_model_packed_floats(const ardae_model_desc* d);

@@ -292,6 +292,12 @@ def act(name):
         return torch.tanh
     if name == "elu":
         return F.elu
+    if name == "csoftplus":
+        return lambda x: torch.log(torch.exp(x) + 1)
+    if name == "leaky_relu":
+        return lambda x: F.leaky_relu(x, negative_slope=0.2)
+    if name == "swish":
+        return lambda x: x * torch.sigmoid(x)
     raise NotImplementedError(name)
 
 

@@ -391,6 +391,15 @@ def main():
     toy_m = O.ModelCfg("toy", input_dim=2, noise_dim=10, h_dim=64, z_dim=2, n_layers=2, nonlin="relu")
     toy_c = O.CdaeCfg("grad", input_dim=2, context_dim=2, h_dim=64, n_layers=3)
     run_case(net, rutils, "tiny_toy_grad", toy_m, toy_c, tc, B=4, steps=2, dtype=f32, store_full=True)
+    # the other activations of get_nonlinear_func (utils/models.py:14-32): tanh is the DEFAULT of the reference's model / cDAE classes,
+    # relu the default of --model-nonlin / --cdae-nonlin (mlp-grad with a piecewise linear activation: second-order terms vanish)
+    for nm, mk, mnl, ck, cnl in (("tiny_toy_tanh", "toy", "tanh", "grad", "tanh"), ("tiny_mnist_elu", "mnist", "elu", "grad", "elu"),
+                                 ("tiny_mnist_leaky", "mnist", "leaky_relu", "res", "leaky_relu"), ("tiny_toy_relu_relu", "toy", "relu", "grad", "relu"),
+                                 ("tiny_mnist_tanh_res", "mnist", "tanh", "res", "tanh")):
+        m_ = (O.ModelCfg("toy", input_dim=2, noise_dim=10, h_dim=64, z_dim=2, n_layers=2, nonlin=mnl) if mk == "toy"
+              else O.ModelCfg("mnist", input_dim=24, noise_dim=10, h_dim=64, z_dim=8, n_layers=2, nonlin=mnl))
+        c_ = O.CdaeCfg(ck, input_dim=m_.z_dim, context_dim=m_.z_dim, h_dim=64, n_layers=3, nonlin=cnl)
+        run_case(net, rutils, nm, m_, c_, tc, B=4, steps=2, dtype=f32, store_full=True)
     # full-width networks of BASELINE configs #2 / #1 at a small batch; parameters regenerated from the seed
     cfg2_m = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
     cfg2_c = O.CdaeCfg("grad", 32, 32, 256, 3)

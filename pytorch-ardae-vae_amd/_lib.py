@@ -70,7 +70,8 @@ class ModelDesc(ctypes.Structure):
                 ("z_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2, "elu": 3}      # elu: the residual-conv model kinds only
+# utils/models.py:14-32 (get_nonlinear_func); 'csoftplus' = log(exp(x) + 1) is softplus (evaluated in its accurate form); 'swish' is not offered
+ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2, "csoftplus": 2, "elu": 3, "tanh": 4, "leaky_relu": 5}
 LOG_RECORD_FLOATS = 16
 EPI_ACT, EPI_DACT, EPI_CHAIN, EPI_DAE_LOSS = 0, 1, 2, 3
 

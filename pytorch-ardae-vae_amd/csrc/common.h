@@ -46,7 +46,13 @@ void set_last_error(const char* fmt, ...);
 // The saved tensor is always the POST-activation value a = act(pre); first/second derivatives are
 // rebuilt from it:  softplus: s = sigmoid(pre) = 1 - exp(-a),  s' = s(1-s);  relu: s = [a>0], s' = 0.
 // ----------------------------------------------------------------------------------------------
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2, ACT_ELU = 3 };   // ELU: runtime helpers only (elementwise kernels of the residual-conv models)
+// get_nonlinear_func (utils/models.py:14-32): relu, softplus (csoftplus = log(exp(x) + 1) is the same function, evaluated in the accurate form), elu (alpha 1), tanh,
+// leaky_relu (slope 0.2).  swish is not offered: the kernels rebuild derivatives from the saved OUTPUT and x sigmoid(x) is not
+// invertible.  The software-pipelined N-row kernels are instantiated for NONE / RELU / SOFTPLUS (every shipped recipe); the other
+// three run on the generic kernels.
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2, ACT_ELU = 3, ACT_TANH = 4, ACT_LEAKY = 5 };
+constexpr int ACT_LAST = ACT_LEAKY;
+constexpr float LEAKY_SLOPE = 0.2f;
 
 // Both helpers go straight to the hardware exp2 / log2 units (v_exp_f32 / v_log_f32, ~1 ulp; __expf/__logf expand to the
 // denormal-safe sequences, ~3x the instructions, with divergent branches) plus a short series where the direct form would
@@ -131,26 +137,56 @@ template <int ACT>
 __device__ __forceinline__ float act_fwd(float x) {
   if (ACT == ACT_RELU) return fmaxf(x, 0.f);
   if (ACT == ACT_SOFTPLUS) return softplus_f(x);
+  if (ACT == ACT_ELU) return x > 0.f ? x : expm1f(x);
+  if (ACT == ACT_TANH) return tanhf(x);
+  if (ACT == ACT_LEAKY) return x > 0.f ? x : LEAKY_SLOPE * x;
   return x;
 }
 
-// derivative of the activation expressed through the saved post-activation value
+// derivative s of the activation expressed through the saved post-activation value a
+// (elu: a <= 0 means a = exp(x) - 1, s = exp(x) = a + 1; tanh: s = 1 - a^2; leaky: sign(a) = sign(x))
 template <int ACT>
 __device__ __forceinline__ float act_d1(float a) {
   if (ACT == ACT_RELU) return a > 0.f ? 1.f : 0.f;
   if (ACT == ACT_SOFTPLUS) return softplus_d1_from_out(a);
+  if (ACT == ACT_ELU) return a > 0.f ? 1.f : a + 1.f;
+  if (ACT == ACT_TANH) return __builtin_fmaf(-a, a, 1.f);
+  if (ACT == ACT_LEAKY) return a > 0.f ? 1.f : LEAKY_SLOPE;
   return 1.f;
+}
+
+// second derivative over first, s' / s, from the saved output (the forward-mode pass through the score network multiplies a
+// tensor that already carries s by it: EPI_CHAIN).  softplus: 1 - s = exp(-a) (no cancellation); elu: 1 on the exponential branch;
+// tanh: -2a; piecewise linear activations: 0.
+template <int ACT>
+__device__ __forceinline__ float act_ratio(float a) {
+  if (ACT == ACT_SOFTPLUS) return fast_exp(-a);
+  if (ACT == ACT_ELU) return a > 0.f ? 0.f : 1.f;
+  if (ACT == ACT_TANH) return -2.f * a;
+  return 0.f;
 }
 
 // ELU (F.elu, alpha = 1; utils/models.py:17-18, nn.ELU in models/ivae/resconv.py:23-31): x > 0 ? x : exp(x) - 1; its derivative
 // from the saved OUTPUT a: a > 0 ? 1 : a + 1 (= exp(x))
 __device__ __forceinline__ float act_fwd_rt(int act, float x) {
-  if (act == ACT_ELU) return x > 0.f ? x : expm1f(x);
-  return act == ACT_RELU ? act_fwd<ACT_RELU>(x) : act == ACT_SOFTPLUS ? act_fwd<ACT_SOFTPLUS>(x) : x;
+  switch (act) {
+    case ACT_RELU: return act_fwd<ACT_RELU>(x);
+    case ACT_SOFTPLUS: return act_fwd<ACT_SOFTPLUS>(x);
+    case ACT_ELU: return act_fwd<ACT_ELU>(x);
+    case ACT_TANH: return act_fwd<ACT_TANH>(x);
+    case ACT_LEAKY: return act_fwd<ACT_LEAKY>(x);
+    default: return x;
+  }
 }
 __device__ __forceinline__ float act_d1_rt(int act, float a) {
-  if (act == ACT_ELU) return a > 0.f ? 1.f : a + 1.f;
-  return act == ACT_RELU ? act_d1<ACT_RELU>(a) : act == ACT_SOFTPLUS ? act_d1<ACT_SOFTPLUS>(a) : 1.f;
+  switch (act) {
+    case ACT_RELU: return act_d1<ACT_RELU>(a);
+    case ACT_SOFTPLUS: return act_d1<ACT_SOFTPLUS>(a);
+    case ACT_ELU: return act_d1<ACT_ELU>(a);
+    case ACT_TANH: return act_d1<ACT_TANH>(a);
+    case ACT_LEAKY: return act_d1<ACT_LEAKY>(a);
+    default: return 1.f;
+  }
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -92,7 +92,7 @@ __device__ __forceinline__ void epilogue_tr(const LinArgs& a, const f32x16& acc,
       } else if (EPI == EPI_DACT) {
         y[g][e] = v * act_d1<ACT>(sv[g][e]) + qv[g][e];
       } else {
-        const float em = (ACT == ACT_SOFTPLUS) ? fast_exp(-sv[g][e]) : 0.f;   // 1 - s without cancellation
+        const float em = act_ratio<ACT>(sv[g][e]);   // s'/s (softplus: 1 - s without cancellation)
         y[g][e] = v * act_d1<ACT>(sv[g][e]);
         y2[g][e] = v * qv[g][e] * em;
       }
@@ -579,15 +579,15 @@ int validate_linear(const LinArgs& a, int epi) {
   switch (epi) {
     case EPI_ACT:
       ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");
-      ARDAE_CHECK_ARG(a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_SOFTPLUS, "linear: unknown activation %d", a.act);
+      ARDAE_CHECK_ARG(a.act >= ACT_NONE && a.act <= ACT_LAST, "linear: unknown activation %d", a.act);
       break;
     case EPI_DACT:
       ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT needs S");
-      ARDAE_CHECK_ARG(a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_SOFTPLUS, "linear: unknown activation %d", a.act);
+      ARDAE_CHECK_ARG(a.act >= ACT_NONE && a.act <= ACT_LAST, "linear: unknown activation %d", a.act);
       break;
     case EPI_CHAIN:
       ARDAE_CHECK_ARG(a.S && a.R && a.Y2, "linear: EPI_CHAIN needs S, R and Y2");
-      ARDAE_CHECK_ARG(a.act == ACT_SOFTPLUS, "linear: unsupported epilogue/activation combination (epi=%d act=%d)", epi, a.act);
+      ARDAE_CHECK_ARG(a.act > ACT_NONE && a.act <= ACT_LAST, "linear: unsupported epilogue/activation combination (epi=%d act=%d)", epi, a.act);
       break;
     case EPI_DAE_LOSS:
       ARDAE_CHECK_ARG(a.sigma && a.eps, "linear: EPI_DAE_LOSS needs sigma and eps");
@@ -622,7 +622,7 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
     if (epi == EPI_ACT) ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");
     if (epi == EPI_DACT || epi == EPI_CHAIN) ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT/EPI_CHAIN need S");
     if (epi == EPI_CHAIN) ARDAE_CHECK_ARG(a.R && a.Y2, "linear: EPI_CHAIN needs S, R and Y2");
-    if (!(epi == EPI_CHAIN && a.act != ACT_SOFTPLUS)) return launch_linear_wide(a, epi, st);
+    return launch_linear_wide(a, epi, st);
   }
   switch (epi) {
     case EPI_ACT:
@@ -630,16 +630,26 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_NONE) return launch_epi<EPI_ACT, ACT_NONE>(a, st);
       if (a.act == ACT_RELU) return launch_epi<EPI_ACT, ACT_RELU>(a, st);
       if (a.act == ACT_SOFTPLUS) return launch_epi<EPI_ACT, ACT_SOFTPLUS>(a, st);
+      if (a.act == ACT_ELU) return launch_epi<EPI_ACT, ACT_ELU>(a, st);
+      if (a.act == ACT_TANH) return launch_epi<EPI_ACT, ACT_TANH>(a, st);
+      if (a.act == ACT_LEAKY) return launch_epi<EPI_ACT, ACT_LEAKY>(a, st);
       break;
     case EPI_DACT:
       ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT needs S");
       if (a.act == ACT_NONE) return launch_epi<EPI_DACT, ACT_NONE>(a, st);
       if (a.act == ACT_RELU) return launch_epi<EPI_DACT, ACT_RELU>(a, st);
       if (a.act == ACT_SOFTPLUS) return launch_epi<EPI_DACT, ACT_SOFTPLUS>(a, st);
+      if (a.act == ACT_ELU) return launch_epi<EPI_DACT, ACT_ELU>(a, st);
+      if (a.act == ACT_TANH) return launch_epi<EPI_DACT, ACT_TANH>(a, st);
+      if (a.act == ACT_LEAKY) return launch_epi<EPI_DACT, ACT_LEAKY>(a, st);
       break;
     case EPI_CHAIN:
       ARDAE_CHECK_ARG(a.S && a.R && a.Y2, "linear: EPI_CHAIN needs S, R and Y2");
       if (a.act == ACT_SOFTPLUS) return launch_epi<EPI_CHAIN, ACT_SOFTPLUS>(a, st);
+      if (a.act == ACT_RELU) return launch_epi<EPI_CHAIN, ACT_RELU>(a, st);
+      if (a.act == ACT_ELU) return launch_epi<EPI_CHAIN, ACT_ELU>(a, st);
+      if (a.act == ACT_TANH) return launch_epi<EPI_CHAIN, ACT_TANH>(a, st);
+      if (a.act == ACT_LEAKY) return launch_epi<EPI_CHAIN, ACT_LEAKY>(a, st);
       break;
     case EPI_DAE_LOSS:
       ARDAE_CHECK_ARG(a.sigma && a.eps, "linear: EPI_DAE_LOSS needs sigma and eps");

@@ -71,8 +71,8 @@ __device__ __forceinline__ void epilogue_half(const LinArgs& a, const f32x16& ac
     float y2[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      // softplus: s = 1 - exp(-a) and 1 - s = exp(-a) are both formed without cancellation
-      const float em = (ACT == ACT_SOFTPLUS) ? fast_exp(-sv[r]) : 0.f;
+      // s'/s from the saved output (softplus: s = 1 - exp(-a) and 1 - s = exp(-a) are both formed without cancellation)
+      const float em = act_ratio<ACT>(sv[r]);
       y[r] = acc[r] * act_d1<ACT>(sv[r]);
       y2[r] = acc[r] * rv[r] * em;
     }

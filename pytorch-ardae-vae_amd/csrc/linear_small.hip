@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const LinArgs a) {
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float em = (ACT == ACT_SOFTPLUS) ? fast_exp(-o1[i]) : 0.f;   // 1 - s without cancellation
+      const float em = act_ratio<ACT>(o1[i]);   // s'/s (softplus: 1 - s without cancellation)
       if (ok[i]) {
         a.Y[(size_t)rowv[i] * a.ldY + col] = v[i] * act_d1<ACT>(o1[i]);
         a.Y2[(size_t)rowv[i] * a.ldY2 + col] = v[i] * o2[i] * em;
@@ -205,7 +205,7 @@ bool linear_small_eligible(const LinArgs& a, int epi) {
   static const int max_tiles = getenv("ARDAE_SMALL_MAX_TILES") ? atoi(getenv("ARDAE_SMALL_MAX_TILES")) : 512;
   if (!on || epi == EPI_DAE_LOSS || a.colsum != nullptr || a.tile_loss != nullptr) return false;
   if (a.M <= 0 || a.Nout <= 0) return false;
-  if (epi == EPI_CHAIN && a.act != ACT_SOFTPLUS) return false;
+  if (epi == EPI_CHAIN && a.act == ACT_NONE) return false;
   return (int64_t)ceil_div(a.M, 32) * ceil_div(a.Nout, 32) <= max_tiles;
 }
 
@@ -215,14 +215,24 @@ int launch_linear_small(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_NONE) return launch_small<EPI_ACT, ACT_NONE>(a, st);
       if (a.act == ACT_RELU) return launch_small<EPI_ACT, ACT_RELU>(a, st);
       if (a.act == ACT_SOFTPLUS) return launch_small<EPI_ACT, ACT_SOFTPLUS>(a, st);
+      if (a.act == ACT_ELU) return launch_small<EPI_ACT, ACT_ELU>(a, st);
+      if (a.act == ACT_TANH) return launch_small<EPI_ACT, ACT_TANH>(a, st);
+      if (a.act == ACT_LEAKY) return launch_small<EPI_ACT, ACT_LEAKY>(a, st);
       break;
     case EPI_DACT:
       if (a.act == ACT_NONE) return launch_small<EPI_DACT, ACT_NONE>(a, st);
       if (a.act == ACT_RELU) return launch_small<EPI_DACT, ACT_RELU>(a, st);
       if (a.act == ACT_SOFTPLUS) return launch_small<EPI_DACT, ACT_SOFTPLUS>(a, st);
+      if (a.act == ACT_ELU) return launch_small<EPI_DACT, ACT_ELU>(a, st);
+      if (a.act == ACT_TANH) return launch_small<EPI_DACT, ACT_TANH>(a, st);
+      if (a.act == ACT_LEAKY) return launch_small<EPI_DACT, ACT_LEAKY>(a, st);
       break;
     case EPI_CHAIN:
       if (a.act == ACT_SOFTPLUS) return launch_small<EPI_CHAIN, ACT_SOFTPLUS>(a, st);
+      if (a.act == ACT_RELU) return launch_small<EPI_CHAIN, ACT_RELU>(a, st);
+      if (a.act == ACT_ELU) return launch_small<EPI_CHAIN, ACT_ELU>(a, st);
+      if (a.act == ACT_TANH) return launch_small<EPI_CHAIN, ACT_TANH>(a, st);
+      if (a.act == ACT_LEAKY) return launch_small<EPI_CHAIN, ACT_LEAKY>(a, st);
       break;
   }
   ARDAE_CHECK_ARG(false, "linear_small: unsupported epilogue/activation combination (epi=%d act=%d)", epi, a.act);

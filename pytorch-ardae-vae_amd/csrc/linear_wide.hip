@@ -70,6 +70,9 @@ bool linear_wide_eligible(const LinArgs& a, int epi) {
     if ((int64_t)a.src[s].ld * a.M * 4 >= (int64_t)1 << 32) return false;   // 32-bit buffer offsets
   }
   if (epi == EPI_DAE_LOSS) return false;   // Nout = z_dim there (narrow geometry)
+  // instantiated for the activations of the shipped recipes; elu / tanh / leaky_relu layers run on the generic kernel
+  if (a.act != ACT_NONE && a.act != ACT_RELU && a.act != ACT_SOFTPLUS) return false;
+  if (epi == EPI_CHAIN && a.act != ACT_SOFTPLUS) return false;
   if (256 % (a.Nout / wgcols)) return false;   // a workgroup keeps its column panel
   if (epi == EPI_ACT && a.rowbias && (a.rows_per_group <= 0 || a.rows_per_group % WBM)) return false;   // group must be tile-uniform
   if (epi == EPI_ACT && a.rowscale && !a.rowscale_w) return false;

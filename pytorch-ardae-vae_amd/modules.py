@@ -147,8 +147,8 @@ class ConditionalARDAE(FlatParamModule):
             raise NotImplementedError            # reference: graddae/mlp.py:392-393 for unknown types; only gaussian is on the path
         if not (enc_input and enc_ctx):
             raise NotImplementedError("enc_input=enc_ctx=True is the only configuration ivae_ardae.py:583-606 constructs")
-        if nonlinearity not in ("softplus", "relu") or (self._kind == "grad" and nonlinearity != "softplus"):
-            raise NotImplementedError(f"nonlinearity {nonlinearity!r}: the HIP engine implements softplus (and relu for mlp-res)")
+        if nonlinearity not in L.ACT or nonlinearity in ("none", None):
+            raise NotImplementedError(f"nonlinearity {nonlinearity!r}: the HIP engine implements relu, softplus / csoftplus, elu, tanh and leaky_relu")
         self.input_dim, self.h_dim, self.context_dim, self.std = input_dim, h_dim, context_dim, std
         self.num_hidden_layers, self.nonlinearity, self.noise_type = num_hidden_layers, nonlinearity, noise_type
         self.enc_input, self.enc_ctx = enc_input, enc_ctx
@@ -266,7 +266,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
         assert enc_type in self._enc_types               # ivae/mnist.py:224; the other toy encoders are out of scope
         if energy_func is not normal_energy_func:
             raise NotImplementedError("only utils.normal_energy_func is implemented on the HIP path")
-        if nonlinearity not in (("elu",) if self._kind in ("resconv", "auxresconv") else ("softplus", "relu")):
+        if nonlinearity not in (("elu",) if self._kind in ("resconv", "auxresconv") else tuple(k for k in L.ACT if k not in ("none", None))):
             raise NotImplementedError(f"nonlinearity {nonlinearity!r}")
         self.energy_func = energy_func
         self.input_dim, self.noise_dim, self.h_dim, self.z_dim = input_dim, noise_dim, h_dim, z_dim

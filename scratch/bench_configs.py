@@ -68,6 +68,7 @@ for i in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5]:
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     m, c, B, nz, data, shp = cfg(i)
+    nz = int(os.environ.get('CFG_NZ', nz))
     m, c = m.to(dev), c.to(dev)
     updates = shp.pop("updates", 1)
     eng = net.ArdaeEngine(m, c, net.TrainConfig(nz_cdae=nz, cdae_ctx_type=shp.pop("ctx", "lt0"), num_cdae_updates=updates, **shp.pop("tcfg", {})), batch_size=B)

@@ -131,10 +131,12 @@ def test_argument_validation_of_the_step_entry_points():
     # the split backward exists for the MLP models only
     fails(lib.ardae_model_vae_backward_decoder(ctypes.byref(conv), one, one, one, one, 4, 1, 1.0, 1.0, one, big, None), "conv model")
     fails(lib.ardae_model_vae_backward_sampler(ctypes.byref(conv), one, one, one, one, 4, 1, one, 1.0, one, big, one, 0.0, None), "conv model")
-    # unknown network kinds / activations a score network cannot use (mlp-grad needs a twice differentiable activation)
-    bad = L.CdaeDesc(0, 8, 8, 64, 3, 1)
-    assert lib.ardae_cdae_workspace_floats(ctypes.byref(bad), 4, 8, 1) == 0
-    fails(lib.ardae_cdae_pack(ctypes.byref(bad), one, one, None), "twice differentiable")
+    # unknown network kinds / activations (0 = none and anything beyond leaky_relu)
+    for bad_act in (0, 6):
+        bad = L.CdaeDesc(0, 8, 8, 64, 3, bad_act)
+        assert lib.ardae_cdae_workspace_floats(ctypes.byref(bad), 4, 8, 1) == 0
+        fails(lib.ardae_cdae_pack(ctypes.byref(bad), one, one, None), "unknown activation")
+    assert lib.ardae_cdae_workspace_floats(ctypes.byref(L.CdaeDesc(0, 8, 8, 64, 3, 1)), 4, 8, 1) > 0      # relu in mlp-grad: --cdae-nonlin's default
     assert lib.ardae_cdae_param_floats(ctypes.byref(L.CdaeDesc(5, 8, 8, 64, 3, 2))) == 0
     # weight-gradient batches: problem count and shapes
     probs = (L.WgradProblem * 1)()
@@ -185,3 +187,22 @@ def test_host_and_in_step_philox_offsets_are_disjoint():
     assert rng.get_state() == {"seed": 7, "offset": 40}           # the host counter itself (what the engine checkpoint stores)
     rng.manual_seed(7, 40)
     assert rng._next_offset() == rng.HOST_STREAM | 40
+
+
+def test_activation_names_follow_get_nonlinear_func():
+    """utils/models.py:14-32: relu, elu, tanh, softplus, csoftplus (= softplus; evaluated in the accurate form), leaky_relu; swish is refused by the host classes."""
+    import torch
+    import ardae_amd as net
+    assert L.ACT["csoftplus"] == L.ACT["softplus"] == 2 and L.ACT["relu"] == 1
+    assert {L.ACT[k] for k in ("elu", "tanh", "leaky_relu")} == {3, 4, 5}
+    x = torch.linspace(-30, 30, 2001, dtype=torch.float64)
+    from oracle import ardae_oracle as O
+    # log(exp(x) + 1) is softplus; its literal fp32 evaluation only loses the tail below ~1e-7 (1 + e^x rounds to 1)
+    assert torch.allclose(O.act("csoftplus")(x.float()), O.act("softplus")(x.float()), rtol=1e-6, atol=2e-7)
+    with pytest.raises(NotImplementedError):
+        net.MLPGradCARDAE(input_dim=2, context_dim=2, h_dim=16, num_hidden_layers=1, nonlinearity="swish")
+    with pytest.raises(NotImplementedError):
+        net.ToyIPVAE(input_dim=2, noise_dim=2, h_dim=16, z_dim=2, nonlinearity="swish", enc_type="concat")
+    # the reference's class defaults (tanh) construct
+    net.MLPGradCARDAE(input_dim=2, context_dim=2, h_dim=16, num_hidden_layers=1)
+    net.ToyIPVAE(input_dim=2, noise_dim=2, h_dim=16, z_dim=2, enc_type="concat")

@@ -104,6 +104,11 @@ CASES = {
     "tiny_mnist_grad": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8),
     "tiny_mnist_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("res", 8, 8, 64, 3), 8),
     "tiny_toy_grad": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3), 8),
+    "tiny_toy_tanh": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 2, 64, 3, "tanh"), 8),
+    "tiny_mnist_elu": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "elu"), O.CdaeCfg("grad", 8, 8, 64, 3, "elu"), 8),
+    "tiny_mnist_leaky": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "leaky_relu"), O.CdaeCfg("res", 8, 8, 64, 3, "leaky_relu"), 8),
+    "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8),
+    "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8),
 }
 
 

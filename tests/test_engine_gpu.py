@@ -30,6 +30,15 @@ CASES = {
     "resconv_b4_nz8": (O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu"), O.CdaeCfg("res", 32, 32, 64, 2), 8, False),
     "auxresconv_b4_nz8": (O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu"), O.CdaeCfg("res", 32, 450, 64, 2), 8, False),
 }
+# the other activations of get_nonlinear_func: tanh (class default of the reference's models / cDAEs), relu in mlp-grad (the default
+# of --cdae-nonlin), elu, leaky_relu - on the generic kernels
+CASES.update({
+    "tiny_toy_tanh": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 2, 64, 3, "tanh"), 8, True),
+    "tiny_mnist_elu": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "elu"), O.CdaeCfg("grad", 8, 8, 64, 3, "elu"), 8, True),
+    "tiny_mnist_leaky": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "leaky_relu"), O.CdaeCfg("res", 8, 8, 64, 3, "leaky_relu"), 8, True),
+    "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8, True),
+    "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8, True),
+})
 RES_RECIPE = dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)     # run_vae_dbmnist.sh, the two resconv lines
 
 
@@ -187,7 +196,8 @@ def test_engine_step_production_kernels_vs_oracle(kind):
     assert_update_close(model.flat_params().cpu(), before_m, ref_m, "model update")
 
 
-@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad"])
+@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad", "tiny_toy_tanh", "tiny_mnist_elu",
+                                  "tiny_mnist_leaky", "tiny_toy_relu_relu", "tiny_mnist_tanh_res"])
 def test_vae_phase_grads_golden(golden_dir, name):
     mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, name)
     model, cdae = build(mc, cc)

@@ -295,3 +295,53 @@ def test_linear_rejects_bad_args():
     a = L.LinearArgs()
     with pytest.raises(ValueError):
         L.check(L.lib().ardae_linear(ctypes.byref(a), 0, None))
+
+
+# ---- the activations beyond relu / softplus (get_nonlinear_func, utils/models.py:14-32): elu, tanh, leaky_relu(0.2) on the generic
+# ---- kernels - forward, derivative from the saved output, and the second-over-first derivative ratio of EPI_CHAIN
+def _fwd64(act, pre):
+    F = torch.nn.functional
+    return {"elu": F.elu(pre), "tanh": torch.tanh(pre), "leaky_relu": F.leaky_relu(pre, 0.2), "relu": pre.clamp(min=0), "softplus": F.softplus(pre)}[act]
+
+
+def _d1_ratio64(act, pre):
+    """s = act'(pre) and s'/s as float64 functions of the PRE-activation."""
+    x = pre.clone().requires_grad_(True)
+    y = _fwd64(act, x)
+    (s,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    s2 = torch.autograd.grad(s.sum(), x, allow_unused=True)[0] if s.requires_grad else None     # piecewise linear: s is a constant of x
+    s2 = torch.zeros_like(x) if s2 is None else s2
+    return s.detach(), torch.where(s.detach() != 0, s2 / s.detach(), torch.zeros_like(s2))
+
+
+@pytest.mark.parametrize("M,K,Nout", [(200, 100, 256), (64, 256, 256), (4096, 256, 256), (96, 256, 32), (8192, 32, 256)])
+@pytest.mark.parametrize("act", ["elu", "tanh", "leaky_relu"])
+def test_linear_act_more_activations(M, K, Nout, act):
+    g = torch.Generator().manual_seed(M + K + Nout)
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5 * 2; b = torch.randn(Nout, generator=g)
+    w = torch.randn(Nout, generator=g)
+    pre = X.double() @ W.double().T + b.double()
+    Y = torch.full((M, Nout), float("nan"), device="cuda"); Y2 = torch.full((M, Nout), float("nan"), device="cuda")
+    run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], bias=b.cuda(), R=w.cuda(), Y=Y, Y2=Y2)
+    assert relerr(Y, _fwd64(act, pre)) < 2e-5
+    s, _ = _d1_ratio64(act, pre)
+    assert relerr(Y2, -w.double() * s) < 5e-5          # score seed -w (.) act'(a), rebuilt from the saved output
+
+
+@pytest.mark.parametrize("M", [200, 4096])
+@pytest.mark.parametrize("act", ["elu", "tanh", "leaky_relu", "relu"])
+def test_linear_dact_chain_more_activations(M, act):
+    g = torch.Generator().manual_seed(21 + M)
+    K, Nout = 256, 256
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / 16
+    pre = torch.randn(M, Nout, generator=g).double() * 2
+    S = _fwd64(act, pre).float()                            # the saved OUTPUT of the layer
+    s, ratio = _d1_ratio64(act, pre)
+    Q = torch.randn(M, Nout, generator=g); R = torch.randn(M, Nout, generator=g)
+    v = X.double() @ W.double().T
+    Y = torch.empty(M, Nout, device="cuda"); Y2 = torch.empty(M, Nout, device="cuda")
+    run_linear(L.EPI_DACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], S=S.cuda(), Q=Q.cuda(), Y=Y)
+    assert relerr(Y, v * s + Q.double()) < 5e-5
+    run_linear(L.EPI_CHAIN, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], S=S.cuda(), R=R.cuda(), Y=Y, Y2=Y2)
+    assert relerr(Y, v * s) < 5e-5
+    assert relerr(Y2, v * R.double() * ratio) < 5e-5

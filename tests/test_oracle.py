@@ -16,6 +16,13 @@ CASES = {
     # family is pinned against the reference's MNISTAuxIPVAE here; its HIP path is the next row to build
     "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, torch.float32),
     "tiny_auxmnist_grad_f64": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, torch.float64),
+    # the other activations of get_nonlinear_func (utils/models.py:14-32): tanh = the class default of the reference's models and cDAEs,
+    # relu = the default of --cdae-nonlin (mlp-grad: second-order terms vanish), elu, leaky_relu
+    "tiny_toy_tanh": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 2, 64, 3, "tanh"), 8, torch.float32),
+    "tiny_mnist_elu": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "elu"), O.CdaeCfg("grad", 8, 8, 64, 3, "elu"), 8, torch.float32),
+    "tiny_mnist_leaky": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "leaky_relu"), O.CdaeCfg("res", 8, 8, 64, 3, "leaky_relu"), 8, torch.float32),
+    "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8, torch.float32),
+    "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8, torch.float32),
 }
 
 
