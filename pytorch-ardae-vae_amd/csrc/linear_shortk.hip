@@ -79,6 +79,126 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void linear_shortk_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer FUSED with the latent-space layer behind it:  Z[M, N2 <= 32] = act(X W1^T + rowbias (+ b1)) W2^T + b2 - the whole
+// N-row sampler of the mnist-concat model when nobody needs its hidden rows (encode() / forward_hidden() of the cDAE phase run under
+// no_grad: ivae_ardae.py:734-751).  The hidden block of 32 columns a wave has just finished goes through a wave-private LDS tile
+// (accumulator layout -> A-fragment layout) straight into 16 more MFMAs against the matching K slice of W2; the [M, h] hidden tensor
+// (134 MB written + read at config #2) never exists.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ST_LD = 36;   // floats per row of the transpose tile (16-byte aligned rows, 4-bank skew)
+
+template <int ACT, int SK_MAXCH>
+__global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_kernel(const LinArgs a, const float* __restrict__ wp2,
+                                                                                     const float* __restrict__ bias2, float* __restrict__ Z, int ldz, int n2) {
+  __shared__ float tile[4][32 * ST_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int row0 = (blockIdx.x * 4 + wave) * 32;
+  const int K = a.src[0].K, nch = (K + 7) >> 3;
+  const int h = a.Nout, nblk = h >> 5, nch2 = h >> 3;
+
+  const float* xr = a.src[0].x + (size_t)(row0 + l31) * a.src[0].ld + 4 * hh;
+  f32x4 av[SK_MAXCH];
+#pragma unroll
+  for (int c = 0; c < SK_MAXCH; ++c) {
+    av[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < nch && 8 * c + 4 * hh + 4 <= K) av[c] = *reinterpret_cast<const f32x4*>(xr + 8 * c);
+  }
+  const float* bp = a.src[0].wp + lane * 4;
+  const float* bp2 = wp2 + lane * 4;
+  const size_t bstride = (size_t)nch * 256;
+  const bool rb_uniform = a.rowbias && (a.rows_per_group % 32) == 0;
+  const float* rbrow = a.rowbias ? a.rowbias + (size_t)(row0 / a.rows_per_group) * a.rowbias_ld : nullptr;
+  float* T = tile[wave];
+
+  f32x16 zacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zacc[r] = 0.f;
+  f32x4 b0[SK_MAXCH], b1[SK_MAXCH];
+  auto load_b = [&](f32x4 (&b)[SK_MAXCH], int nb) {
+#pragma unroll
+    for (int c = 0; c < SK_MAXCH; ++c)
+      if (c < nch) b[c] = *reinterpret_cast<const f32x4*>(bp + (size_t)nb * bstride + (size_t)c * 256);
+  };
+  auto block = [&](const f32x4 (&b)[SK_MAXCH], int nb) {
+    f32x4 w2[4];
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) w2[c2] = *reinterpret_cast<const f32x4*>(bp2 + (size_t)(4 * nb + c2) * 256);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < SK_MAXCH; ++c)
+      if (c < nch) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][q], b[c][q], acc, 0, 0, 0);
+      }
+    const int col = nb * 32 + l31;
+    float pre = a.bias ? a.bias[col] : 0.f;
+    if (rb_uniform) pre += rbrow[col];
+    // hidden block: accumulator layout (lane = column, registers = rows) -> tile[row][column]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      float v = acc[r] + pre;
+      if (a.rowbias && !rb_uniform) v += a.rowbias[(size_t)((row0 + rl) / a.rows_per_group) * a.rowbias_ld + col];
+      T[rl * ST_LD + l31] = act_fwd<ACT>(v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ... and back as A fragments (lane = row, four consecutive k): 16 MFMAs against W2[:, 32 nb .. 32 nb + 31]
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(T + l31 * ST_LD + 8 * c2 + 4 * hh);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[q], w2[c2][q], zacc, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();     // the tile is rewritten by the next block
+  };
+  (void)nch2;
+  load_b(b0, 0);
+  for (int nb = 0; nb < nblk; nb += 2) {
+    if (nb + 1 < nblk) load_b(b1, nb + 1);
+    block(b0, nb);
+    if (nb + 1 >= nblk) break;
+    if (nb + 2 < nblk) load_b(b0, nb + 2);
+    block(b1, nb + 1);
+  }
+  if (l31 < n2) {
+    const float bz = bias2 ? bias2[l31] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rowu = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      Z[(size_t)rowu * ldz + l31] = zacc[r] + bz;
+    }
+  }
+}
+
+template <int ACT, int MAXCH>
+int launch_tail_ch(const LinArgs& a, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st) {
+  if (g_prof_enabled) {
+    char name[64];
+    snprintf(name, sizeof(name), "sampler_tail_kernel<%d, %d>", ACT, MAXCH);
+    const double K = a.src[0].K;
+    prof_begin(st, name, 2.0 * a.M * ((double)a.Nout * K + (double)a.Nout * n2), 4.0 * ((double)a.M * K + (double)a.M * n2 + K * a.Nout + (double)a.Nout * n2));
+  }
+  hipLaunchKernelGGL((sampler_tail_kernel<ACT, MAXCH>), dim3(a.M / 128), dim3(256), 0, st, a, wp2, bias2, Z, ldz, n2);
+  prof_end(st);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int ACT>
+int launch_tail(const LinArgs& a, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st) {
+  const int nch = (a.src[0].K + 7) >> 3;
+  if (nch <= 8) return launch_tail_ch<ACT, 8>(a, wp2, bias2, Z, ldz, n2, st);
+  if (nch <= 13) return launch_tail_ch<ACT, 13>(a, wp2, bias2, Z, ldz, n2, st);
+  return launch_tail_ch<ACT, 16>(a, wp2, bias2, Z, ldz, n2, st);
+}
+
 template <int ACT, int MAXCH>
 int launch_shortk_ch(const LinArgs& a, hipStream_t st) {
   if (g_prof_enabled) {
@@ -115,6 +235,23 @@ bool linear_shortk_eligible(const LinArgs& a, int epi) {
   if (a.rowscale || a.Y2 || a.colsum || !a.Y) return false;
   if (a.rowbias && a.rows_per_group <= 0) return false;
   return a.act == ACT_NONE || a.act == ACT_RELU || a.act == ACT_SOFTPLUS;
+}
+
+// `first` is the short-K layer as launch_linear would get it (its Y is ignored), followed by Z = hidden . W2^T + b2 with N2 <= 32
+// columns.  ARDAE_SAMPLER_TAIL=0: off.
+bool sampler_tail_eligible(const LinArgs& first, int n2) {
+  static const bool on = !(getenv("ARDAE_SAMPLER_TAIL") && atoi(getenv("ARDAE_SAMPLER_TAIL")) == 0);
+  if (!on || n2 < 1 || n2 > 32) return false;
+  LinArgs a = first;
+  if (!a.Y) a.Y = const_cast<float*>(a.src[0].x);   // the single-layer rule wants an output pointer; unused here
+  return linear_shortk_eligible(a, EPI_ACT) && (a.Nout % 64) == 0;   // blocks are walked in pairs
+}
+
+int launch_sampler_tail(const LinArgs& first, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st) {
+  ARDAE_CHECK_ARG(sampler_tail_eligible(first, n2) && wp2 && Z && ldz >= n2, "sampler tail: shape not eligible");
+  if (first.act == ACT_RELU) return launch_tail<ACT_RELU>(first, wp2, bias2, Z, ldz, n2, st);
+  if (first.act == ACT_SOFTPLUS) return launch_tail<ACT_SOFTPLUS>(first, wp2, bias2, Z, ldz, n2, st);
+  return launch_tail<ACT_NONE>(first, wp2, bias2, Z, ldz, n2, st);
 }
 
 int launch_linear_shortk(const LinArgs& a, int epi, hipStream_t st) {

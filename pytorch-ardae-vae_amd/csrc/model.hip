@@ -206,10 +206,19 @@ int encode_trunk(const ModelLayout& P, const ModelPacked& K, const float* params
 }
 
 // sampler stack on R = B*nz rows: layer 0 takes the per-image rb plus its noise part, the last layer writes zdst [R, zd]
+// keep_hidden = false (encode / forward_hidden calls, which run under no_grad in the reference): the hidden rows t[] need not exist
 int encode_stack(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* noise,
-                 int B, int nz, const float* rb, const std::vector<float*>& t, float* zdst, hipStream_t st) {
+                 int B, int nz, const float* rb, const std::vector<float*>& t, float* zdst, bool keep_hidden, hipStream_t st) {
   const int R = B * nz, h = P.h, act = P.act;
   const size_t ns = P.stack.size();
+  if (!keep_hidden && ns == 2 && P.stack_noise[0] && !P.stack_noise[1] && P.stack[0].out == h) {
+    // noise -> h -> z with nothing else reading the hidden rows: one launch (linear_shortk.hip::sampler_tail_kernel)
+    LinArgs A{}; A.M = R; A.Nout = h; A.act = act; A.nsrc = 1;
+    A.rowbias = rb; A.rowbias_ld = h; A.rows_per_group = nz;
+    A.src[0].x = noise; A.src[0].ld = P.nd; A.src[0].K = P.nd; A.src[0].wp = packed + K.sn_f[0];
+    if (sampler_tail_eligible(A, P.stack[1].out))
+      return launch_sampler_tail(A, packed + K.sh_f[1], params + P.stack[1].b, zdst, P.stack[1].out, P.stack[1].out, st);
+  }
   for (size_t i = 0; i < ns; ++i) {
     const bool last = i + 1 == ns;
     const int out = P.stack[i].out;
@@ -232,9 +241,9 @@ int encode_stack(const ModelLayout& P, const ModelPacked& K, const float* params
 
 // sampler forward: fills W.e, W.rb, W.t, W.z (and copies z to z_out when given)
 int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* x,
-               const float* noise, int B, int nz, ModelWs& W, float* z_out, hipStream_t st) {
+               const float* noise, int B, int nz, ModelWs& W, float* z_out, bool keep_hidden, hipStream_t st) {
   ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
-  ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, W.z, st));
+  ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, W.z, keep_hidden, st));
   if (z_out) {
     ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
@@ -346,7 +355,7 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
     nz_ptr = zero;
   }
   ARDAE_CHECK_ARG(ws.ok, "model_encode: internal workspace accounting error");
-  ARDAE_TRY(encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, st));
+  ARDAE_TRY(encode_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, z_out, false, st));
   return 0;
 }
 
@@ -376,9 +385,9 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
   if (phase != 2) {
     ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * P.nd * sizeof(float), st));
     ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
-    ARDAE_TRY(encode_stack(P, K, params, packed, zero, B, 1, W.rb, t0, z0_out, st));    // encode(x, std=0): the draw is multiplied by 0
+    ARDAE_TRY(encode_stack(P, K, params, packed, zero, B, 1, W.rb, t0, z0_out, false, st));    // encode(x, std=0): the draw is multiplied by 0
   }
-  if (phase != 1) ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, st));   // forward_hidden(x, nz); W.rb from phase 1
+  if (phase != 1) ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, false, st));   // forward_hidden(x, nz); W.rb from phase 1
   return 0;
 }
 
@@ -463,7 +472,7 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   carve(P, ws, B, nz, 1, W);
   ARDAE_CHECK_ARG(ws.ok, "model_vae_forward: internal workspace accounting error");
   const int R = B * nz, h = P.h, act = P.act;
-  ARDAE_TRY(encode_fwd(P, K, params, packed, x, noise, B, nz, W, z_out, st));
+  ARDAE_TRY(encode_fwd(P, K, params, packed, x, noise, B, nz, W, z_out, true, st));
   for (size_t l = 1; l <= P.dec.size(); ++l) {
     LinArgs A{}; A.bias = params + P.dec[l - 1].b; A.Y = W.dcd[l]; A.ldY = h;
     ARDAE_TRY(lin1(EPI_ACT, act, R, h, l == 1 ? W.z : W.dcd[l - 1], l == 1 ? P.zd : h, P.dec[l - 1].in, packed + K.dec_f[l - 1], A, st));

@@ -717,3 +717,24 @@ def test_iwae_logprob_golden_resconv(golden_dir, name, kind, h):
     got = model.logprob(torch.tensor(fx["x"]).float().cuda(), sample_size=k, enc_noise=enc, prop_noise=torch.tensor(fx["prop_noise"]).float().cuda())
     ref = float(fx["logprob"])
     assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
+
+
+@pytest.mark.parametrize("B,nz,nonlin", [(128, 256, "softplus"), (64, 625, "relu"), (256, 128, "softplus")])
+def test_nrow_sampler_fused_tail_vs_oracle(B, nz, nonlin):
+    """forward_hidden(x, nz) on >= 32768 rows: the mnist-concat sampler's two N-row layers (noise -> h -> z) run as ONE launch that keeps
+    the hidden rows on chip (linear_shortk.hip::sampler_tail_kernel); against the float64 oracle at config #2's widths, per-image row
+    bias groups of nz rows (625: not a multiple of the 32-row wave tile)."""
+    mc = O.ModelCfg("mnist", 784, 100, 256, 32, 2, nonlin)
+    torch.manual_seed(3)
+    pm = O.init_params(O.model_param_spec(mc), 7, O.model_init_special(mc))
+    model, _ = build(mc, O.CdaeCfg("grad", 32, 32, 64, 2))
+    model.load_state_dict(pm)
+    model = model.to("cuda")
+    x = (torch.rand(B, 784) < 0.2).float()
+    noise = torch.randn(B * nz, mc.noise_dim)
+    z = model.forward_hidden(x.cuda(), nz=nz, noise=noise.cuda())
+    pm64 = {k: v.double() for k, v in pm.items()}
+    ref = O.encode(mc, pm64, x.double(), noise.double(), nz)
+    assert z.shape == (B, nz, mc.z_dim)
+    assert rel_l2(z.reshape(B * nz, -1), ref.reshape(B * nz, -1).float()) < 2e-5
+    assert float((z.reshape(B * nz, -1).cpu() - ref.reshape(B * nz, -1).float()).abs().max()) < 5e-4
