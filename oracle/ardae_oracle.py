@@ -86,7 +86,8 @@ class TrainCfg:
     m_beta1: float = 0.5
     d_lr: float = 1e-4
     d_momentum: float = 0.5
-    ctx_type: str = "lt0"        # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens)
+    ctx_type: str = "lt0"        # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens) | "data"
+    ctx_center: bool = True      # ctx_type "data": 2x - 1 when 'mnist' is in the dataset's name (ivae_ardae.py:731-734), x itself otherwise
 
 
 # --------------------------------------------------------------------------- #
@@ -474,8 +475,12 @@ def zero_noise(c: ModelCfg, rows, like):
 
 
 def cdae_context(c: ModelCfg, tc, p, x):
-    """--cdae-ctx-type (ivae_ardae.py:729-741): lt0 -> encode(x, std=0) [B, z]; hidden1a -> cat(h0, h) of the std=0 pass [B, 2h]."""
+    """--cdae-ctx-type (ivae_ardae.py:729-741): data -> the (centred) image [B, D]; lt0 -> encode(x, std=0) [B, z]; hidden1a -> cat(h0, h) of the
+    std=0 pass [B, 2h]."""
     B = x.size(0)
+    if tc.ctx_type == "data":           # the flattened image itself (ivae_ardae.py:730-734,809-813)
+        xf = x.reshape(B, -1)
+        return 2 * xf - 1 if tc.ctx_center else xf
     if tc.ctx_type == "lt0":
         return encode(c, p, x, zero_noise(c, B, x), 1).reshape(B, c.z_dim)
     if tc.ctx_type == "hidden1a":

@@ -100,6 +100,10 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
     B = x_cdae.size(0)
     if tc.ctx_type == "hidden1a":   # ivae_ardae.py:737-739
         context = model.encode.forward_hidden(x_cdae, std=0).detach().unsqueeze(1)
+    elif tc.ctx_type == "data":     # ivae_ardae.py:730-734
+        context = x_cdae.unsqueeze(1)
+        if tc.ctx_center:
+            context = (2 * context - 1).view(B, 1, -1)
     else:
         context = model.encode(x_cdae, std=0).detach()
     latent_mean = model.encode(x_cdae, std=0).detach()
@@ -125,6 +129,10 @@ def ref_step(rutils, model, cdae, m_opt, c_opt, tc, x_cdae, x_vae, seed):
     mloss.backward(retain_graph=True)
     if tc.ctx_type == "hidden1a":   # ivae_ardae.py:815-817
         context = model.encode.forward_hidden(x_vae, std=0).detach().unsqueeze(1)
+    elif tc.ctx_type == "data":     # ivae_ardae.py:809-813
+        context = x_vae.unsqueeze(1)
+        if tc.ctx_center:
+            context = (2 * context - 1).view(B, 1, -1)
     else:
         context = model.encode(x_vae, std=0).detach()
     latent_mean = model.encode(x_vae, std=0).detach()
@@ -160,7 +168,8 @@ def replay_noise(mc, tc, B_c, B_v, seed, dtype):
         n["eps"] = torch.randn(B_c * tc.nz_cdae * tc.nstd, mc.z_dim, dtype=dtype)
         n["vae"], n["vae_z"] = fwd(B_v, tc.nz_model)
         return {k: v.to(dtype) for k, v in n.items()}
-    torch.randn(B_c, mc.noise_dim)                       # context encode (x0)
+    if tc.ctx_type != "data":
+        torch.randn(B_c, mc.noise_dim)                   # context encode (x0); --cdae-ctx-type data takes the image: no draw
     torch.randn(B_c, mc.noise_dim)                       # latent_mean encode (x0)
     n = {}
     n["sampler"] = torch.randn(B_c * tc.nz_cdae, mc.noise_dim)
@@ -400,6 +409,11 @@ def main():
               else O.ModelCfg("mnist", input_dim=24, noise_dim=10, h_dim=64, z_dim=8, n_layers=2, nonlin=mnl))
         c_ = O.CdaeCfg(ck, input_dim=m_.z_dim, context_dim=m_.z_dim, h_dim=64, n_layers=3, nonlin=cnl)
         run_case(net, rutils, nm, m_, c_, tc, B=4, steps=2, dtype=f32, store_full=True)
+    # --cdae-ctx-type data: the (centred) image itself is the context (ivae_ardae.py:730-734,809-813)
+    run_case(net, rutils, "tiny_mnist_ctxdata", tiny_m, O.CdaeCfg("grad", input_dim=8, context_dim=24, h_dim=64, n_layers=3),
+             O.TrainCfg(nz_cdae=8, ctx_type="data"), B=4, steps=2, dtype=f32, store_full=True)
+    run_case(net, rutils, "tiny_toy_ctxdata", toy_m, O.CdaeCfg("res", input_dim=2, context_dim=2, h_dim=64, n_layers=3),
+             O.TrainCfg(nz_cdae=8, ctx_type="data", ctx_center=False), B=4, steps=2, dtype=f32, store_full=True)
     # full-width networks of BASELINE configs #2 / #1 at a small batch; parameters regenerated from the seed
     cfg2_m = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
     cfg2_c = O.CdaeCfg("grad", 32, 32, 256, 3)

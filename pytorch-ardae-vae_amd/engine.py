@@ -29,7 +29,8 @@ class TrainConfig:
     m_beta1: float = 0.5
     d_lr: float = 1e-4            # --d-lr, RMSprop momentum d_momentum
     d_momentum: float = 0.5
-    cdae_ctx_type: str = "lt0"    # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens)
+    cdae_ctx_type: str = "lt0"    # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens) | "data"
+    ctx_data_center: bool = True  # "data": the image as 2x - 1 when 'mnist' is in --dataset (ivae_ardae.py:731-734,810-813), x itself otherwise
 
 
 def annealing_func(val_init, val_fin, val_annealing, step):
@@ -68,12 +69,13 @@ class ArdaeEngine:
         B, nzc, nzm = self.B, cfg.nz_cdae, cfg.nz_model
         N = B * nzc
         z, nd = model.z_dim, model._noise_width          # floats per row of a sampler draw (aux models: [eps0 | eps])
-        if cfg.cdae_ctx_type not in ("lt0", "hidden1a"):
+        if cfg.cdae_ctx_type not in ("lt0", "hidden1a", "data"):
             raise NotImplementedError(f"cdae_ctx_type {cfg.cdae_ctx_type!r}")          # ivae_ardae.py:743-744
         if cfg.cdae_ctx_type == "hidden1a" and not model.hidden_dim:
             raise NotImplementedError("hidden1a is the aux models' context (ivae_ardae.py:572-580)")
         self.hidden_ctx = cfg.cdae_ctx_type == "hidden1a"
-        ctx_dim = model.hidden_dim if self.hidden_ctx else z
+        self.data_ctx = cfg.cdae_ctx_type == "data"
+        ctx_dim = model.hidden_dim if self.hidden_ctx else int(model.input_dim) if self.data_ctx else z
         if int(cdae.context_dim) != ctx_dim:
             raise ValueError(f"cdae.context_dim = {cdae.context_dim}, but the {cfg.cdae_ctx_type} context has {ctx_dim} columns")
         f = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
@@ -90,7 +92,9 @@ class ArdaeEngine:
         self.xbar, self.sigma, self.std_b = f(N, z), f(N), f(B)
         self.noise_v, self.zv, self.z0v, self.u, self.g = f(B * nzm, nd), f(B * nzm, z), f(B, z), f(B * nzm, z), f(B * nzm, z)
         self.sigma0 = torch.zeros(B * nzm, device=self.dev)
-        self.ctx_c, self.ctx_v = (f(B, ctx_dim), f(B, ctx_dim)) if self.hidden_ctx else (self.z0, self.z0v)
+        self.ctx_c, self.ctx_v = (f(B, ctx_dim), f(B, ctx_dim)) if (self.hidden_ctx or self.data_ctx) else (self.z0, self.z0v)
+        if self.data_ctx:      # 2x - 1 = 2 (x - 1/2) through ardae_center_scale; uncentred: x - 0
+            self._ctx_half = torch.full((B, ctx_dim), 0.5 if cfg.ctx_data_center else 0.0, device=self.dev)
         self.loss_c, self.losses_m = f(1), f(3)
         self.grads_c = torch.zeros_like(cdae._flat)
         self.grads_m = torch.zeros_like(model._flat)
@@ -260,6 +264,8 @@ class ArdaeEngine:
             if drawn is not None and not noise:
                 torch.cuda.current_stream().wait_event(drawn)
             pair(0)
+        if self.data_ctx:
+            self._data_context(x, self.ctx_c)
         L.check(lib.ardae_latent_perturb(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, z, cfg.std_scale, cfg.delta,
                                          L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb")
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
@@ -270,6 +276,12 @@ class ArdaeEngine:
             L.check(lib.ardae_rmsprop_step(L.ptr(self.cdae._flat), L.ptr(self.grads_c), L.ptr(self.sq_c), L.ptr(self.buf_c), self.n_c,
                                            cfg.d_lr, 0.99, 1e-8, cfg.d_momentum, st), "ardae_rmsprop_step")
             self._pack_cdae()
+
+    def _data_context(self, x, out):
+        """--cdae-ctx-type data: the flattened image, centred to 2x - 1 for the MNIST family (ivae_ardae.py:730-734,809-813)."""
+        D = int(self.model.input_dim)
+        L.check(self.lib.ardae_center_scale(L.ptr(x), L.ptr(self._ctx_half), self.B, 1, D, 2.0 if self.cfg.ctx_data_center else 1.0, L.ptr(out),
+                                            L.stream_ptr()), "ardae_center_scale")
 
     def vae_forward_part(self, x, noise=None, beta=None, draw=None):
         """ivae_ardae.py:781-827: everything of the VAE update that does not involve the cDAE (forward, ELBO pieces, z0, u)."""
@@ -285,6 +297,8 @@ class ArdaeEngine:
             self._hidden(x, self.z0v, self.ctx_v, self.ws_small_v)
         else:
             self._encode(x, None, 1, self.z0v, self.ws_small_v)
+        if self.data_ctx:
+            self._data_context(x, self.ctx_v)
         L.check(lib.ardae_center_scale(L.ptr(self.zv), L.ptr(self.z0v), B, nz, self.model.z_dim, cfg.std_scale, L.ptr(self.u), st))
         if self.split_backward:
             # model_loss.backward() through the decoder down to dL/dz (ivae_ardae.py:804) needs nothing from the cDAE either

@@ -39,6 +39,11 @@ CASES.update({
     "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8, True),
     "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8, True),
 })
+# --cdae-ctx-type data (ivae_ardae.py:730-734,809-813): the image itself (centred for the MNIST family) is the cDAE's context
+CASES.update({
+    "tiny_mnist_ctxdata": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 24, 64, 3), 8, True),
+    "tiny_toy_ctxdata": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("res", 2, 2, 64, 3), 8, True),
+})
 RES_RECIPE = dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)     # run_vae_dbmnist.sh, the two resconv lines
 
 
@@ -106,9 +111,14 @@ def noise_of(fx, t, dev):
     return {k: v.to(dev).contiguous() for k, v in n.items()}
 
 
-def train_config(mc, nz, **kw):
+CTX_DATA = {"tiny_mnist_ctxdata": True, "tiny_toy_ctxdata": False}      # --cdae-ctx-type data fixtures: centred (2x - 1) or not
+
+
+def train_config(mc, nz, name=None, **kw):
     if mc.kind in ("resconv", "auxresconv"):
         kw = dict(RES_RECIPE, **kw)
+    if name in CTX_DATA:
+        return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="data", ctx_data_center=CTX_DATA[name], **kw)
     return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a" if mc.kind in O.AUX_KINDS else "lt0", **kw)
 
 
@@ -121,7 +131,7 @@ def test_engine_trajectory_golden(golden_dir, name):
     model.load_state_dict(pm); cdae.load_state_dict(pc)
     model, cdae = model.to("cuda"), cdae.to("cuda")
     B, steps = int(fx["meta_B"]), int(fx["meta_steps"])
-    eng = net.ArdaeEngine(model, cdae, train_config(mc, nz), batch_size=B)
+    eng = net.ArdaeEngine(model, cdae, train_config(mc, nz, name), batch_size=B)
     for t in range(steps):
         pre = f"s{t}/"
         xc, xv = torch.tensor(fx[pre + "x_cdae"]).cuda(), torch.tensor(fx[pre + "x_vae"]).cuda()

@@ -23,7 +23,11 @@ CASES = {
     "tiny_mnist_leaky": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "leaky_relu"), O.CdaeCfg("res", 8, 8, 64, 3, "leaky_relu"), 8, torch.float32),
     "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8, torch.float32),
     "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8, torch.float32),
+    # --cdae-ctx-type data: the image itself as context (centred for the MNIST family)
+    "tiny_mnist_ctxdata": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 24, 64, 3), 8, torch.float32),
+    "tiny_toy_ctxdata": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("res", 2, 2, 64, 3), 8, torch.float32),
 }
+CTX_DATA = {"tiny_mnist_ctxdata": True, "tiny_toy_ctxdata": False}
 
 
 def rel_l2(a, b):
@@ -35,6 +39,8 @@ def test_oracle_step_matches_reference_fixture(golden_dir, name):
     mc, cc, nz, dt = CASES[name]
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     tc = O.TrainCfg(nz_cdae=nz, ctx_type="hidden1a" if mc.kind == "auxmnist" else "lt0")
+    if name in CTX_DATA:
+        tc = O.TrainCfg(nz_cdae=nz, ctx_type="data", ctx_center=CTX_DATA[name])
     tol = 2e-4 if dt == torch.float32 else 1e-9    # another CPU/BLAS than the one that wrote the fixture: fp32 noise x 1e4 (std_scale)
     pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
     pc = {n: torch.tensor(fx["pc/" + n]) for n, _ in O.cdae_param_spec(cc)}
