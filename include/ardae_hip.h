@@ -139,6 +139,8 @@ int ardae_adam_ref_step_dev(float* p, const float* g, float* exp_avg, float* exp
 /* torch.optim.RMSprop(lr, momentum) as built at ivae_ardae.py:625-626 (alpha .99, eps 1e-8, not centred) */
 int ardae_rmsprop_step(float* p, const float* g, float* square_avg, float* momentum_buffer, int64_t n, double lr,
                        double alpha, double eps, double momentum, void* stream);
+/* torch.optim.SGD as ivae_ardae.py:546-547 (model) / :613-614 (cDAE) construct it - lr only: p -= lr g */
+int ardae_sgd_step(float* p, const float* g, int64_t n, double lr, void* stream);
 
 /* ---- K4-K6: conditional AR-DAE (models/graddae/mlp.py:341-483, models/resdae/mlp.py:286-413) -----------------
  * Parameters live in ONE flat fp32 buffer in the reference's named_parameters() order

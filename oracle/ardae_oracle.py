@@ -86,6 +86,9 @@ class TrainCfg:
     m_beta1: float = 0.5
     d_lr: float = 1e-4
     d_momentum: float = 0.5
+    m_optimizer: str = "adam"    # --m-optimizer / --d-optimizer: sgd | adam | amsgrad | rmsprop (ivae_ardae.py:545-556,612-622); the shipped
+    d_optimizer: str = "rmsprop" # recipes pass adam / rmsprop (argparse's own default for --d-optimizer is adam)
+    d_beta1: float = 0.5         # --d-beta1 (cDAE Adam / amsgrad)
     ctx_type: str = "lt0"        # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens) | "data"
     ctx_center: bool = True      # ctx_type "data": 2x - 1 when 'mnist' is in the dataset's name (ivae_ardae.py:731-734), x itself otherwise
 
@@ -585,9 +588,9 @@ def latent_stats(latent, latent_mean, std_scale, delta):
 # --------------------------------------------------------------------------- #
 # optimisers
 # --------------------------------------------------------------------------- #
-def adam_ref_step(params, grads, state, lr, beta1, beta2=0.999, eps=1e-8):
-    """Vendored old-style Adam: eps added BEFORE the bias correction (utils/optim.py:102-106).
-    Tensors whose grad is None are skipped and keep no state."""
+def adam_ref_step(params, grads, state, lr, beta1, beta2=0.999, eps=1e-8, amsgrad=False):
+    """Vendored old-style Adam: eps added BEFORE the bias correction (utils/optim.py:102-106); amsgrad: the running maximum of
+    exp_avg_sq normalises (:96-100).  Tensors whose grad is None are skipped and keep no state."""
     for name, w in params.items():
         g = grads.get(name)
         if g is None:
@@ -598,7 +601,10 @@ def adam_ref_step(params, grads, state, lr, beta1, beta2=0.999, eps=1e-8):
         bc2 = 1 - beta2 ** st["step"]
         st["exp_avg"].mul_(beta1).add_(g, alpha=1 - beta1)
         st["exp_avg_sq"].mul_(beta2).addcmul_(g, g, value=1 - beta2)
-        denom = (st["exp_avg_sq"].sqrt() + eps) / math.sqrt(bc2)
+        v = st["exp_avg_sq"]
+        if amsgrad:
+            v = st["max_exp_avg_sq"] = torch.maximum(st.get("max_exp_avg_sq", torch.zeros_like(w)), st["exp_avg_sq"])
+        denom = (v.sqrt() + eps) / math.sqrt(bc2)
         w.addcdiv_(st["exp_avg"], denom, value=-lr / bc1)
 
 
@@ -617,6 +623,25 @@ def rmsprop_step(params, grads, state, lr, momentum, alpha=0.99, eps=1e-8):
             w.add_(st["momentum_buffer"], alpha=-lr)
         else:
             w.addcdiv_(g, avg, value=-lr)
+
+
+def sgd_step(params, grads, lr):
+    """torch.optim.SGD(lr) as ivae_ardae.py:546-547,613-614 construct it; grad None -> skipped."""
+    for name, w in params.items():
+        if grads.get(name) is not None:
+            w.add_(grads[name], alpha=-lr)
+
+
+def optimizer_step(kind, params, grads, state, lr, beta1, momentum):
+    """--m-optimizer / --d-optimizer (ivae_ardae.py:545-556,612-622): sgd | adam | amsgrad | rmsprop."""
+    if kind == "sgd":
+        sgd_step(params, grads, lr)
+    elif kind in ("adam", "amsgrad"):
+        adam_ref_step(params, grads, state, lr, beta1, amsgrad=kind == "amsgrad")
+    elif kind == "rmsprop":
+        rmsprop_step(params, grads, state, lr, momentum)
+    else:
+        raise NotImplementedError(kind)
 
 
 # --------------------------------------------------------------------------- #
@@ -693,10 +718,10 @@ def train_step(mc, cc, tc, pm, pc, st_m, st_c, x_cdae, x_vae, noise):
     """One iteration of ivae_ardae.py:707-846 with num_cdae_updates=1.  Mutates pm/pc/states."""
     closs, gc, std = cdae_update_grads(mc, cc, tc, pm, pc, x_cdae, noise)
     with torch.no_grad():
-        rmsprop_step(pc, gc, st_c, tc.d_lr, tc.d_momentum)
+        optimizer_step(tc.d_optimizer, pc, gc, st_c, tc.d_lr, tc.d_beta1, tc.d_momentum)
     mloss, rec, pri, g, gm = vae_update_grads(mc, cc, tc, pm, pc, x_vae, noise)
-    with torch.no_grad():
-        adam_ref_step(pm, gm, st_m, tc.m_lr, tc.m_beta1)
+    with torch.no_grad():      # the model's RMSprop takes --d-momentum too (ivae_ardae.py:553: momentum=opt.d_momentum)
+        optimizer_step(tc.m_optimizer, pm, gm, st_m, tc.m_lr, tc.m_beta1, tc.d_momentum)
     return {"cdae_loss": closs, "std_mean": std.mean(), "std_max": std.max(), "std_min": std.min(),
             "model_loss": mloss, "recon": rec, "prior": pri}
 

@@ -200,8 +200,14 @@ def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0
     pc = O.init_params(O.cdae_param_spec(cc), pseed + 1, None, dtype)
     # tame the N(0,1) head so fp32 comparisons are meaningful at tiny nz as well (values still O(1..10))
     model, cdae = build_reference(net, mc, cc, pm, pc, dtype)
-    m_opt = rutils.Adam(model.parameters(), lr=tc.m_lr, betas=(tc.m_beta1, 0.999))
-    c_opt = torch.optim.RMSprop(cdae.parameters(), lr=tc.d_lr, momentum=tc.d_momentum)
+    def make_opt(kind, params, lr, beta1):     # ivae_ardae.py:545-556 (model), :612-622 (cDAE); the model's RMSprop takes d_momentum too (:553)
+        if kind == "sgd":
+            return torch.optim.SGD(params, lr=lr)
+        if kind in ("adam", "amsgrad"):
+            return rutils.Adam(params, lr=lr, betas=(beta1, 0.999), amsgrad=kind == "amsgrad")
+        return torch.optim.RMSprop(params, lr=lr, momentum=tc.d_momentum)
+    m_opt = make_opt(tc.m_optimizer, model.parameters(), tc.m_lr, tc.m_beta1)
+    c_opt = make_opt(tc.d_optimizer, list(cdae.parameters()), tc.d_lr, tc.d_beta1)
     st_m, st_c = {}, {}
     fx = {"meta_B": np.int64(B), "meta_steps": np.int64(steps), "meta_pseed": np.int64(pseed)}
     if store_full:
@@ -226,7 +232,7 @@ def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0
             else:
                 errs["gc/" + n_] = rel_l2(gc[n_], g_)
         with torch.no_grad():
-            O.rmsprop_step(pc, gc, st_c, tc.d_lr, tc.d_momentum)
+            O.optimizer_step(tc.d_optimizer, pc, gc, st_c, tc.d_lr, tc.d_beta1, tc.d_momentum)
         for n_, p_ in ref["cdae_params_after"].items():
             errs["pc/" + n_] = rel_l2(pc[n_], p_)
         mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, tc, pm, pc, xv, noise)
@@ -237,7 +243,7 @@ def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0
         for n_, g_ in ref["model_grads"].items():
             errs["gm/" + n_] = rel_l2(gm[n_], g_)
         with torch.no_grad():
-            O.adam_ref_step(pm, gm, st_m, tc.m_lr, tc.m_beta1)
+            O.optimizer_step(tc.m_optimizer, pm, gm, st_m, tc.m_lr, tc.m_beta1, tc.d_momentum)
         for n_, p_ in ref["model_params_after"].items():
             errs["pm/" + n_] = rel_l2(pm[n_], p_)
         bad = {k: v for k, v in errs.items() if not (v <= tol)}
@@ -327,8 +333,14 @@ def run_ckpt_case(net, rutils, name, mc, cc, tc, B, k_steps, dtype=torch.float32
     pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc), dtype)
     pc = O.init_params(O.cdae_param_spec(cc), 1, None, dtype)
     model, cdae = build_reference(net, mc, cc, pm, pc, dtype)
-    m_opt = rutils.Adam(model.parameters(), lr=tc.m_lr, betas=(tc.m_beta1, 0.999))
-    c_opt = torch.optim.RMSprop(cdae.parameters(), lr=tc.d_lr, momentum=tc.d_momentum)
+    def make_opt(kind, params, lr, beta1):     # ivae_ardae.py:545-556 (model), :612-622 (cDAE); the model's RMSprop takes d_momentum too (:553)
+        if kind == "sgd":
+            return torch.optim.SGD(params, lr=lr)
+        if kind in ("adam", "amsgrad"):
+            return rutils.Adam(params, lr=lr, betas=(beta1, 0.999), amsgrad=kind == "amsgrad")
+        return torch.optim.RMSprop(params, lr=lr, momentum=tc.d_momentum)
+    m_opt = make_opt(tc.m_optimizer, model.parameters(), tc.m_lr, tc.m_beta1)
+    c_opt = make_opt(tc.d_optimizer, list(cdae.parameters()), tc.d_lr, tc.d_beta1)
     for t in range(k_steps):
         ref_step(rutils, model, cdae, m_opt, c_opt, tc, synth_x(mc, B, 1000 + 2 * t).to(dtype), synth_x(mc, B, 1001 + 2 * t).to(dtype), 4242 + t)
     fx = {"meta_B": np.int64(B), "meta_k": np.int64(k_steps)}
@@ -414,6 +426,12 @@ def main():
              O.TrainCfg(nz_cdae=8, ctx_type="data"), B=4, steps=2, dtype=f32, store_full=True)
     run_case(net, rutils, "tiny_toy_ctxdata", toy_m, O.CdaeCfg("res", input_dim=2, context_dim=2, h_dim=64, n_layers=3),
              O.TrainCfg(nz_cdae=8, ctx_type="data", ctx_center=False), B=4, steps=2, dtype=f32, store_full=True)
+    # --m-optimizer / --d-optimizer beyond the recipes' adam / rmsprop pair (ivae_ardae.py:545-556,612-622): argparse's own default pair
+    # (adam, adam), amsgrad + sgd, and rmsprop for the model (which takes --d-momentum, :553) with amsgrad for the cDAE; 3 steps each
+    for nm, mo, do in (("tiny_mnist_opt_adam_adam", "adam", "adam"), ("tiny_mnist_opt_amsgrad_sgd", "amsgrad", "sgd"),
+                       ("tiny_mnist_opt_rmsprop_amsgrad", "rmsprop", "amsgrad"), ("tiny_mnist_opt_sgd_rmsprop", "sgd", "rmsprop")):
+        run_case(net, rutils, nm, tiny_m, tiny_c, O.TrainCfg(nz_cdae=8, m_optimizer=mo, d_optimizer=do, d_beta1=0.7, m_lr=2e-4, d_lr=3e-4),
+                 B=4, steps=3, dtype=f32, store_full=True)
     # full-width networks of BASELINE configs #2 / #1 at a small batch; parameters regenerated from the seed
     cfg2_m = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
     cfg2_c = O.CdaeCfg("grad", 32, 32, 256, 3)

@@ -100,6 +100,7 @@ EXPORTS = {
     "ardae_adam_ref_step_dev": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 3 + [ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_adam_ref_step": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_int, ctypes.c_void_p]),
     "ardae_rmsprop_step": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_double] * 4 + [ctypes.c_void_p]),
+    "ardae_sgd_step": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_double, ctypes.c_void_p]),
     "ardae_cdae_param_floats": (ctypes.c_size_t, [ctypes.POINTER(CdaeDesc)]),
     "ardae_cdae_packed_floats": (ctypes.c_size_t, [ctypes.POINTER(CdaeDesc)]),
     "ardae_cdae_workspace_floats": (ctypes.c_size_t, [ctypes.POINTER(CdaeDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int]),

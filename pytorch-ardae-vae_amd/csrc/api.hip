@@ -79,5 +79,9 @@ int ardae_rmsprop_step(float* p, const float* g, float* square_avg, float* momen
                        double alpha, double eps, double momentum, void* stream) {
   return launch_rmsprop(p, g, square_avg, momentum_buffer, n, lr, alpha, eps, momentum, (hipStream_t)stream);
 }
+/* torch.optim.SGD as constructed at ivae_ardae.py:546-547,613-614 (no momentum, no weight decay): p -= lr g */
+int ardae_sgd_step(float* p, const float* g, int64_t n, double lr, void* stream) {
+  return launch_axpy(g, n, (float)-lr, p, (hipStream_t)stream);
+}
 
 }  // extern "C"

@@ -29,6 +29,9 @@ class TrainConfig:
     m_beta1: float = 0.5
     d_lr: float = 1e-4            # --d-lr, RMSprop momentum d_momentum
     d_momentum: float = 0.5
+    m_optimizer: str = "adam"     # --m-optimizer / --d-optimizer: sgd | adam | amsgrad | rmsprop (ivae_ardae.py:545-556,612-622); the shipped
+    d_optimizer: str = "rmsprop"  # recipes pass adam / rmsprop.  The model's RMSprop takes d_momentum, as the reference's does (:553)
+    d_beta1: float = 0.5          # --d-beta1 (cDAE Adam / amsgrad)
     cdae_ctx_type: str = "lt0"    # --cdae-ctx-type: "lt0" (context = encode(x, std=0)) | "hidden1a" (aux models: encoder hiddens) | "data"
     ctx_data_center: bool = True  # "data": the image as 2x - 1 when 'mnist' is in --dataset (ivae_ardae.py:731-734,810-813), x itself otherwise
 
@@ -38,6 +41,64 @@ def annealing_func(val_init, val_fin, val_annealing, step):
     if val_annealing is None:
         return float(val_fin)
     return float(val_init + (val_fin - val_init) / float(val_annealing) * float(min(val_annealing, step)))
+
+
+class _FlatOpt:
+    """One network's optimiser on its flat parameter / gradient buffers: torch.optim.SGD(lr), the reference's vendored Adam (amsgrad
+    optional; utils/optim.py:49-108) or torch.optim.RMSprop(momentum) - the four choices of --m-optimizer / --d-optimizer.  `n`: floats
+    that receive gradients (the cDAE's trailing neglogprob.fc.bias does not and keeps no state).  Adam's t and bias corrections live in a
+    32-byte device block (`ardae_step_state_advance`) so that a captured step can be replayed."""
+    KINDS = ("sgd", "adam", "amsgrad", "rmsprop")
+
+    def __init__(self, kind, flat, n, lr, beta1, momentum, state=None):
+        if kind not in self.KINDS:
+            raise NotImplementedError(f"unknown optimizer: {kind}")                     # ivae_ardae.py:555-556,621-622
+        self.kind, self.flat, self.n, self.lr, self.beta1, self.momentum = kind, flat, int(n), float(lr), float(beta1), float(momentum)
+        z = lambda: torch.zeros_like(flat)
+        self.a = None if kind == "sgd" else z()                                         # exp_avg | square_avg
+        self.b = None if kind == "sgd" else z()                                         # exp_avg_sq | momentum_buffer
+        self.c = z() if kind == "amsgrad" else None                                     # max_exp_avg_sq
+        self.steps = 0
+        self.state = state if state is not None else torch.zeros(4, dtype=torch.int64, device=flat.device)
+
+    @property
+    def adam(self):
+        return self.kind in ("adam", "amsgrad")
+
+    def advance(self, lib, rng_inc=0):
+        L.check(lib.ardae_step_state_advance(ctypes.c_void_p(self.state.data_ptr()), ctypes.c_uint64(rng_inc), self.lr, self.beta1, 0.999,
+                                             L.stream_ptr()), "ardae_step_state_advance")
+
+    def apply(self, lib, grads, in_step):
+        st, p, g = L.stream_ptr(), L.ptr(self.flat), L.ptr(grads)
+        if self.kind == "sgd":
+            L.check(lib.ardae_sgd_step(p, g, self.n, self.lr, st), "ardae_sgd_step")
+        elif self.kind == "rmsprop":
+            L.check(lib.ardae_rmsprop_step(p, g, L.ptr(self.a), L.ptr(self.b), self.n, self.lr, 0.99, 1e-8, self.momentum, st), "ardae_rmsprop_step")
+        elif in_step:      # t and the bias corrections come from the device block (advanced inside the step)
+            L.check(lib.ardae_adam_ref_step_dev(p, g, L.ptr(self.a), L.ptr(self.b), L.ptr(self.c) if self.c is not None else None, self.n,
+                                                self.beta1, 0.999, 1e-8, ctypes.c_void_p(self.state.data_ptr()), st), "ardae_adam_ref_step_dev")
+        else:
+            L.check(lib.ardae_adam_ref_step(p, g, L.ptr(self.a), L.ptr(self.b), L.ptr(self.c) if self.c is not None else None, self.n,
+                                            self.lr, self.beta1, 0.999, 1e-8, self.steps + 1, st), "ardae_adam_ref_step")
+
+    # torch.optim.Optimizer.state_dict() pieces (per-parameter views of the flat buffers)
+    def state_names(self):
+        return {"sgd": (), "adam": ("exp_avg", "exp_avg_sq"), "amsgrad": ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"),
+                "rmsprop": ("square_avg", "momentum_buffer")}[self.kind]
+
+    def buffers(self):
+        return [t for t in (self.a, self.b, self.c) if t is not None]
+
+    def param_group(self, nparams):
+        if self.kind == "sgd":
+            g = {"lr": self.lr, "momentum": 0, "dampening": 0, "weight_decay": 0, "nesterov": False}
+        elif self.adam:
+            g = {"lr": self.lr, "betas": (self.beta1, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": self.kind == "amsgrad"}
+        else:
+            g = {"lr": self.lr, "momentum": self.momentum, "alpha": 0.99, "eps": 1e-8, "centered": False, "weight_decay": 0}
+        g["params"] = list(range(nparams))
+        return g
 
 
 class ArdaeEngine:
@@ -100,11 +161,12 @@ class ArdaeEngine:
         self.grads_m = torch.zeros_like(model._flat)
         # optimiser state (flat; the cDAE's last tensor, neglogprob.fc.bias, gets no gradient in the reference and is skipped)
         self.n_c = cdae._flat.numel() - (1 if cdae._kind == "grad" else 0)
-        self.sq_c, self.buf_c = torch.zeros_like(cdae._flat), torch.zeros_like(cdae._flat)
-        self.m_m, self.v_m = torch.zeros_like(model._flat), torch.zeros_like(model._flat)
         self.step_count = 0
-        # device-resident step state + graph bookkeeping
+        # device-resident step state (Philox base offset + the model optimiser's Adam block) + graph bookkeeping
         self.state = torch.zeros(4, dtype=torch.int64, device=self.dev)
+        # --m-optimizer / --d-optimizer (ivae_ardae.py:545-556,612-622); the model's RMSprop is built with d_momentum there (:553)
+        self.opt_m = _FlatOpt(cfg.m_optimizer, model._flat, model._flat.numel(), cfg.m_lr, cfg.m_beta1, cfg.d_momentum, state=self.state)
+        self.opt_c = _FlatOpt(cfg.d_optimizer, cdae._flat, self.n_c, cfg.d_lr, cfg.d_beta1, cfg.d_momentum)
         self.use_graph = bool(graph) and os.environ.get("ARDAE_GRAPH", "1") != "0"
         self._graph, self._graph_key, self._xc, self._xv = None, None, None, None      # _xc: list of static batch buffers
         self._capture = None          # segmented capture in progress (world > 1): see _allreduce_mean
@@ -273,8 +335,11 @@ class ArdaeEngine:
                                           L.ptr(self.loss_c), L.ptr(self.grads_c), None, st), "ardae_cdae_loss_grads")
         self._allreduce_mean(self.grads_c[:self.n_c])
         if apply_update:
-            L.check(lib.ardae_rmsprop_step(L.ptr(self.cdae._flat), L.ptr(self.grads_c), L.ptr(self.sq_c), L.ptr(self.buf_c), self.n_c,
-                                           cfg.d_lr, 0.99, 1e-8, cfg.d_momentum, st), "ardae_rmsprop_step")
+            if self._in_step and self.opt_c.adam:
+                self.opt_c.advance(lib)           # the cDAE's own Adam block: t advances once per cDAE update
+            self.opt_c.apply(lib, self.grads_c, self._in_step)
+            if not self._in_step:
+                self.opt_c.steps += 1
             self._pack_cdae()
 
     def _data_context(self, x, out):
@@ -330,15 +395,10 @@ class ArdaeEngine:
                                                  0.0, st), "ardae_model_vae_backward")
         self._allreduce_mean(self.grads_m)
         if apply_update:
-            if self._in_step:      # t and the bias corrections come from the device step state (advanced by step())
-                L.check(lib.ardae_adam_ref_step_dev(L.ptr(self.model._flat), L.ptr(self.grads_m), L.ptr(self.m_m), L.ptr(self.v_m), None,
-                                                    self.model._flat.numel(), cfg.m_beta1, 0.999, 1e-8, ctypes.c_void_p(self.state.data_ptr()), st),
-                        "ardae_adam_ref_step_dev")
-            else:
+            self.opt_m.apply(lib, self.grads_m, self._in_step)   # in a step: t and the bias corrections come from the device step state
+            if not self._in_step:
                 self.step_count += 1
-                L.check(lib.ardae_adam_ref_step(L.ptr(self.model._flat), L.ptr(self.grads_m), L.ptr(self.m_m), L.ptr(self.v_m), None,
-                                                self.model._flat.numel(), cfg.m_lr, cfg.m_beta1, 0.999, 1e-8, self.step_count, st),
-                        "ardae_adam_ref_step")
+                self.opt_m.steps = self.step_count
             self._pack_model()
 
     def vae_phase(self, x, noise=None, beta=None, apply_update=True):
@@ -351,8 +411,7 @@ class ArdaeEngine:
         cfg = self.cfg
         self._in_step, self._draws = True, 0
         try:
-            L.check(self.lib.ardae_step_state_advance(ctypes.c_void_p(self.state.data_ptr()), ctypes.c_uint64(self.RNG_STRIDE), cfg.m_lr, cfg.m_beta1, 0.999,
-                                                      L.stream_ptr()), "ardae_step_state_advance")
+            self.opt_m.advance(self.lib, self.RNG_STRIDE)       # Philox base offset += stride, model optimiser's t += 1
             vae_draw = self.RNG_STRIDE - 1            # the VAE sampler's noise keeps its own offset whatever the launch order
             # injected noise: one dict for everything, or a list with one dict per cDAE update (the last one also holds "vae")
             nlist = list(noise) if isinstance(noise, (list, tuple)) else [noise] * len(xs)
@@ -448,10 +507,15 @@ class ArdaeEngine:
                 else:
                     self._graph, self._graph_key = g, key
                     self._replay()
-            self.step_count += 1
+            self._count_step(len(xs))
             return
         self._step_body(xs, x_vae, noise, beta)
+        self._count_step(len(xs))
+
+    def _count_step(self, n_cdae_updates):
         self.step_count += 1
+        self.opt_m.steps = self.step_count
+        self.opt_c.steps += n_cdae_updates
 
     # ------------------------------------------------------------------------------------------------------------
     # Checkpoints in the reference's format (ivae_ardae.py:931-950,1120-1139; utils/msc.py:67-93): one dict per network with
@@ -467,60 +531,67 @@ class ArdaeEngine:
             off += k
         return out
 
+    def _opt_state(self, module, opt):
+        """torch.optim state_dict()['state'] of one network: {param index: {'step', <buffers of the optimiser>}}; parameters without
+        gradients (the cDAE's trailing bias) and optimisers without state (SGD) contribute nothing."""
+        if not opt.steps or opt.kind == "sgd":
+            return {}
+        views = [self._per_param(module, t, opt.n) for t in opt.buffers()]
+        names = opt.state_names()
+        out = {}
+        for i in range(len(views[0])):
+            if views[0][i] is not None:
+                out[i] = dict({"step": opt.steps}, **{nm: v[i].clone() for nm, v in zip(names, views)})
+        return out
+
     def model_checkpoint(self):
-        cfg = self.cfg
-        m, v = self._per_param(self.model, self.m_m, self.m_m.numel()), self._per_param(self.model, self.v_m, self.v_m.numel())
-        state = {i: {"step": self.step_count, "exp_avg": m[i].clone(), "exp_avg_sq": v[i].clone()} for i in range(len(m))} if self.step_count else {}
+        nparams = len(list(self.model.named_parameters()))
         return {"state_dict": {k: t.clone() for k, t in self.model.state_dict().items()},
-                "optimizer": {"state": state,
-                              "param_groups": [{"lr": cfg.m_lr, "betas": (cfg.m_beta1, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
-                                                "params": list(range(len(m)))}]},
-                "engine": {"step_count": self.step_count, "rng_seed": rng.get_state()["seed"], "rng_host_offset": rng.get_state()["offset"],
-                           "step_state": self.state.cpu().clone()}}
+                "optimizer": {"state": self._opt_state(self.model, self.opt_m), "param_groups": [self.opt_m.param_group(nparams)]},
+                "engine": {"step_count": self.step_count, "cdae_steps": self.opt_c.steps, "rng_seed": rng.get_state()["seed"],
+                           "rng_host_offset": rng.get_state()["offset"], "step_state": self.state.cpu().clone()}}
 
     def cdae_checkpoint(self):
-        cfg = self.cfg
-        sq, buf = self._per_param(self.cdae, self.sq_c, self.n_c), self._per_param(self.cdae, self.buf_c, self.n_c)
-        state = {}
-        if self.step_count:
-            for i in range(len(sq)):
-                if sq[i] is not None:   # neglogprob.fc.bias gets no gradient in the reference: no state (graddae/mlp.py:437)
-                    state[i] = {"step": self.step_count * cfg.num_cdae_updates, "square_avg": sq[i].clone(), "momentum_buffer": buf[i].clone()}
+        nparams = len(list(self.cdae.named_parameters()))
         return {"state_dict": {k: t.clone() for k, t in self.cdae.state_dict().items()},
-                "optimizer": {"state": state,
-                              "param_groups": [{"lr": cfg.d_lr, "momentum": cfg.d_momentum, "alpha": 0.99, "eps": 1e-8, "centered": False,
-                                                "weight_decay": 0, "params": list(range(len(sq)))}]}}
+                "optimizer": {"state": self._opt_state(self.cdae, self.opt_c), "param_groups": [self.opt_c.param_group(nparams)]}}
+
+    def _load_opt_state(self, module, opt, state, what):
+        for t in opt.buffers():
+            t.zero_()
+        steps = {int(st["step"]) for st in state.values()}
+        if len(steps) > 1:
+            raise ValueError(f"the fused engine keeps one step count per network ({what}: {sorted(steps)})")
+        names = opt.state_names()
+        if state and not all(nm in next(iter(state.values())) for nm in names[:1]):
+            raise ValueError(f"{what}: the checkpoint's optimiser state does not belong to {opt.kind!r} (engine built with TrainConfig."
+                             f"{'m' if opt is self.opt_m else 'd'}_optimizer={opt.kind!r})")
+        with torch.no_grad():
+            for nm, buf in zip(names, opt.buffers()):
+                for i, t in enumerate(self._per_param(module, buf, opt.n)):
+                    if t is not None and i in state and state[i].get(nm) is not None:
+                        t.copy_(state[i][nm])
+        return steps.pop() if steps else 0
 
     def load_checkpoints(self, model_ckpt, cdae_ckpt):
         """Inverse of model_checkpoint() / cdae_checkpoint(); also accepts files written by the reference loop."""
         self.model.load_state_dict(model_ckpt["state_dict"])
         self.cdae.load_state_dict(cdae_ckpt["state_dict"])
-        mst, cst = model_ckpt["optimizer"]["state"], cdae_ckpt["optimizer"]["state"]
-        steps = {int(s["step"]) for s in mst.values()}
-        if len(steps) > 1:
-            raise ValueError("the fused engine keeps one Adam step count for all parameters")
-        self.m_m.zero_(); self.v_m.zero_(); self.sq_c.zero_(); self.buf_c.zero_()
-        with torch.no_grad():
-            for i, t in enumerate(self._per_param(self.model, self.m_m, self.m_m.numel())):
-                if i in mst:
-                    t.copy_(mst[i]["exp_avg"])
-            for i, t in enumerate(self._per_param(self.model, self.v_m, self.v_m.numel())):
-                if i in mst:
-                    t.copy_(mst[i]["exp_avg_sq"])
-            for i, t in enumerate(self._per_param(self.cdae, self.sq_c, self.n_c)):
-                if t is not None and i in cst:
-                    t.copy_(cst[i]["square_avg"])
-            for i, t in enumerate(self._per_param(self.cdae, self.buf_c, self.n_c)):
-                if t is not None and i in cst and cst[i].get("momentum_buffer") is not None:
-                    t.copy_(cst[i]["momentum_buffer"])
-        self.step_count = steps.pop() if steps else 0
         eng = model_ckpt.get("engine")
+        m_steps = self._load_opt_state(self.model, self.opt_m, model_ckpt["optimizer"]["state"], "model checkpoint")
+        c_steps = self._load_opt_state(self.cdae, self.opt_c, cdae_ckpt["optimizer"]["state"], "cdae checkpoint")
+        # optimisers without per-parameter state (SGD) carry no step count: the engine's own record, if the file has one
+        self.step_count = m_steps if (m_steps or eng is None) else int(eng["step_count"])
+        self.opt_m.steps = self.step_count
+        self.opt_c.steps = c_steps if (c_steps or eng is None) else int(eng.get("cdae_steps", 0))
         if eng is not None:     # written by this engine: continue the same noise stream
             rng.manual_seed(eng["rng_seed"], eng.get("rng_host_offset", rng.get_state()["offset"]))
             self.state.copy_(eng["step_state"].to(self.dev))
-        else:                   # written by the reference / the module path: only Adam's t matters
+        else:                   # written by the reference / the module path: only the optimisers' t matters
             self.state.zero_()
         self.state[1] = self.step_count
+        self.opt_c.state.zero_()
+        self.opt_c.state[1] = self.opt_c.steps
         self._graph = None      # parameters were rewritten outside of the captured step
         self.repack()
 

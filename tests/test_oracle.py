@@ -28,6 +28,35 @@ CASES = {
     "tiny_toy_ctxdata": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("res", 2, 2, 64, 3), 8, torch.float32),
 }
 CTX_DATA = {"tiny_mnist_ctxdata": True, "tiny_toy_ctxdata": False}
+# --m-optimizer / --d-optimizer pairs beyond the recipes' (adam, rmsprop): the oracle's optimisers against the reference's over three steps
+OPT_PAIRS = {"tiny_mnist_opt_adam_adam": ("adam", "adam"), "tiny_mnist_opt_amsgrad_sgd": ("amsgrad", "sgd"),
+             "tiny_mnist_opt_rmsprop_amsgrad": ("rmsprop", "amsgrad"), "tiny_mnist_opt_sgd_rmsprop": ("sgd", "rmsprop")}
+
+
+@pytest.mark.parametrize("name", list(OPT_PAIRS))
+def test_oracle_optimizer_pairs_match_reference_fixture(golden_dir, name):
+    mc, cc = O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3)
+    tc = O.TrainCfg(nz_cdae=8, m_optimizer=OPT_PAIRS[name][0], d_optimizer=OPT_PAIRS[name][1], d_beta1=0.7, m_lr=2e-4, d_lr=3e-4)
+    fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
+    pc = {n: torch.tensor(fx["pc/" + n]) for n, _ in O.cdae_param_spec(cc)}
+    st_m, st_c = {}, {}
+    for t in range(int(fx["meta_steps"])):
+        pre = f"s{t}/"
+        # the reference's own gradients: this test is about the update rules and their state across steps
+        gc = {n: (None if pre + "cdae_grads/" + n + "/none" in fx else torch.tensor(fx[pre + "cdae_grads/" + n])) for n, _ in O.cdae_param_spec(cc)}
+        gm = {n: torch.tensor(fx[pre + "model_grads/" + n]) for n, _ in O.model_param_spec(mc)}
+        with torch.no_grad():
+            O.optimizer_step(tc.d_optimizer, pc, gc, st_c, tc.d_lr, tc.d_beta1, tc.d_momentum)
+            O.optimizer_step(tc.m_optimizer, pm, gm, st_m, tc.m_lr, tc.m_beta1, tc.d_momentum)
+        for n, _ in O.cdae_param_spec(cc):
+            ref = torch.tensor(fx[pre + "cdae_params_after/" + n])
+            assert torch.allclose(pc[n], ref, rtol=0, atol=2e-7 + 1e-3 * tc.d_lr), (n, t)
+            pc[n] = ref.clone()
+        for n, _ in O.model_param_spec(mc):
+            ref = torch.tensor(fx[pre + "model_params_after/" + n])
+            assert torch.allclose(pm[n], ref, rtol=0, atol=2e-7 + 1e-3 * tc.m_lr), (n, t)
+            pm[n] = ref.clone()
 
 
 def rel_l2(a, b):
