@@ -111,6 +111,10 @@ int ardae_wgrad_batch(const ardae_wgrad_problem* problems, int nproblems, void* 
  * sigma[b,i] = std_b*xi[b,i]; xbar = u + sigma*eps.   latent [B,nz,z], z0 [B,z], xi [B*nz], eps [B*nz,z]            */
 int ardae_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int z,
                          float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream);
+/* --train-nstd-cdae > 1 (ivae_ardae.py:759-767): every one of the nz sample rows is used nstd times, each with its own sigma and eps;
+ * the statistics are those of the nz samples.  xi [B*nz*nstd], eps / xbar [B*nz*nstd, z], sigma [B*nz*nstd]; row (b, i, j) <- latent[b, i] */
+int ardae_latent_perturb_nstd(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int nstd, int z,
+                              float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream);
 /* u = s (z - z0[b])  (ivae_ardae.py:827) */
 int ardae_center_scale(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float* u, void* stream);
 /* Philox4x32-10 counter RNG (replaces torch.randn at ivae/mnist.py:73, ivae_ardae.py:761, graddae/mlp.py:22) */

@@ -432,6 +432,8 @@ def main():
                        ("tiny_mnist_opt_rmsprop_amsgrad", "rmsprop", "amsgrad"), ("tiny_mnist_opt_sgd_rmsprop", "sgd", "rmsprop")):
         run_case(net, rutils, nm, tiny_m, tiny_c, O.TrainCfg(nz_cdae=8, m_optimizer=mo, d_optimizer=do, d_beta1=0.7, m_lr=2e-4, d_lr=3e-4),
                  B=4, steps=3, dtype=f32, store_full=True)
+    # --train-nstd-cdae 3: every sample row meets three noise levels (ivae_ardae.py:759-767)
+    run_case(net, rutils, "tiny_mnist_nstd3", tiny_m, tiny_c, O.TrainCfg(nz_cdae=8, nstd=3), B=4, steps=2, dtype=f32, store_full=True)
     # full-width networks of BASELINE configs #2 / #1 at a small batch; parameters regenerated from the seed
     cfg2_m = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
     cfg2_c = O.CdaeCfg("grad", 32, 32, 256, 3)

@@ -44,7 +44,11 @@ int ardae_wgrad_batch(const ardae_wgrad_problem* problems, int nproblems, void* 
 
 int ardae_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int z,
                          float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream) {
-  return launch_latent_perturb(latent, z0, xi, eps, B, nz, z, std_scale, delta, xbar, sigma, std_b, (hipStream_t)stream);
+  return launch_latent_perturb(latent, z0, xi, eps, B, nz, 1, z, std_scale, delta, xbar, sigma, std_b, (hipStream_t)stream);
+}
+int ardae_latent_perturb_nstd(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int nstd, int z,
+                              float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream) {
+  return launch_latent_perturb(latent, z0, xi, eps, B, nz, nstd, z, std_scale, delta, xbar, sigma, std_b, (hipStream_t)stream);
 }
 int ardae_center_scale(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float* u, void* stream) {
   return launch_center_scale(latent, z0, B, nz, z, std_scale, u, (hipStream_t)stream);

@@ -8,7 +8,7 @@ namespace ardae {
 // ivae_ardae.py:753-761 + models/graddae/mlp.py:21-23:
 //   u = s (z - z0[b]);  std_b = delta * mean_d( std_unbiased_over_nz(u[:, d]) );
 //   sigma[b, i] = std_b * xi[b, i];  xbar = u + sigma * eps
-int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int zd,
+int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int nstd, int zd,
                           float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st);
 // u = s (z - z0[b]) only (VAE phase, sigma = 0: ivae_ardae.py:827)
 int launch_center_scale(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float* u,

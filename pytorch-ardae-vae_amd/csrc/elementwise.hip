@@ -100,7 +100,7 @@ __global__ void bernoulli_kernel(const float* __restrict__ p, int64_t rows, int 
 // one workgroup per image; thread (rg, d): d = t % zp, rg = t / zp
 __global__ __launch_bounds__(256) void latent_perturb_kernel(const float* __restrict__ latent, const float* __restrict__ z0,
                                                              const float* __restrict__ xi, const float* __restrict__ eps, int nz,
-                                                             int zd, int zp, float std_scale, float delta,
+                                                             int nstd, int zd, int zp, float std_scale, float delta,
                                                              float* __restrict__ xbar, float* __restrict__ sigma,
                                                              float* __restrict__ std_b) {
   __shared__ float red[256];
@@ -146,12 +146,13 @@ __global__ __launch_bounds__(256) void latent_perturb_kernel(const float* __rest
   __syncthreads();
   const float sb = red[0];
   if (t == 0) std_b[b] = sb;
-  // perturb
-  for (int e = t; e < nz * zd; e += 256) {
+  // perturb: every sample row is used nstd times (--train-nstd-cdae, ivae_ardae.py:759-767), each with its own sigma and eps
+  const int nrow = nz * nstd;
+  for (int e = t; e < nrow * zd; e += 256) {
     const int r = e / zd, dd = e - r * zd;
-    const size_t row = (size_t)b * nz + r;
+    const size_t row = (size_t)b * nrow + r;
     const float sg = sb * xi[row];
-    const float u = std_scale * (lat[e] - z0[(size_t)b * zd + dd]);
+    const float u = std_scale * (lat[(size_t)(r / nstd) * zd + dd] - z0[(size_t)b * zd + dd]);
     xbar[row * zd + dd] = u + sg * eps[row * zd + dd];
     if (dd == 0) sigma[row] = sg;
   }
@@ -416,14 +417,15 @@ inline int grid_for(int64_t n, int cap = 4096) {
 
 }  // namespace
 
-int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int zd,
+int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int nstd, int zd,
                           float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st) {
   ARDAE_CHECK_ARG(latent && z0 && xi && eps && xbar && sigma && std_b, "latent_perturb: null pointer");
-  ARDAE_CHECK_ARG(B > 0 && nz >= 2 && zd >= 1 && zd <= 256, "latent_perturb: need B>0, nz>=2 (unbiased std), 1<=z<=256 (B=%d nz=%d z=%d)", B, nz, zd);
+  ARDAE_CHECK_ARG(B > 0 && nz >= 2 && nstd >= 1 && zd >= 1 && zd <= 256,
+                  "latent_perturb: need B>0, nz>=2 (unbiased std), nstd>=1, 1<=z<=256 (B=%d nz=%d nstd=%d z=%d)", B, nz, nstd, zd);
   int zp = 1;
   while (zp < zd) zp <<= 1;
   const int64_t per_image = (int64_t)nz * zd;
-  const bool reg_ok = zp == zd && zd <= 256 && per_image >= 256 * 4;
+  const bool reg_ok = nstd == 1 && zp == zd && zd <= 256 && per_image >= 256 * 4;
 #define ARDAE_LP_REG(NV_)                                                                                                          \
   hipLaunchKernelGGL(latent_perturb_reg_kernel<NV_>, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, std_scale, delta, xbar, \
                      sigma, std_b)
@@ -433,7 +435,7 @@ int launch_latent_perturb(const float* latent, const float* z0, const float* xi,
   else if (reg_ok && per_image <= 256 * 64) ARDAE_LP_REG(64);
   else if (reg_ok && per_image <= 256 * 96) ARDAE_LP_REG(96);       // nz_cdae 625 of the shipped recipes: 79 values per thread
   else
-    hipLaunchKernelGGL(latent_perturb_kernel, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, zp, std_scale, delta, xbar,
+    hipLaunchKernelGGL(latent_perturb_kernel, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, nstd, zd, zp, std_scale, delta, xbar,
                        sigma, std_b);
 #undef ARDAE_LP_REG
   ARDAE_LAUNCH_CHECK();

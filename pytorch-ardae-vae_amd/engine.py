@@ -22,6 +22,7 @@ class TrainConfig:
     delta: float = 0.1            # --delta
     std_scale: float = 1e4        # --std-scale
     nz_cdae: int = 256            # --train-nz-cdae
+    nstd_cdae: int = 1            # --train-nstd-cdae: noise levels (sigma, eps pairs) per sample row of the cDAE update
     nz_model: int = 1             # --train-nz-model
     num_cdae_updates: int = 1     # --num-cdae-updates
     beta: float = 1.0             # --beta-fin (no annealing in the shipped recipes)
@@ -141,7 +142,8 @@ class ArdaeEngine:
             raise ValueError(f"cdae.context_dim = {cdae.context_dim}, but the {cfg.cdae_ctx_type} context has {ctx_dim} columns")
         f = lambda *s: torch.empty(*s, device=self.dev, dtype=torch.float32)
         lib = self.lib
-        ws_floats = max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, nzc, 1),
+        S = nzc * int(cfg.nstd_cdae)            # rows per image of the cDAE update (ivae_ardae.py:759-767)
+        ws_floats = max(lib.ardae_cdae_workspace_floats(ctypes.byref(cd), B, S, 1),
                         lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzc, 3))
         self.ws = f(ws_floats)
         self.ws_vae = f(lib.ardae_model_workspace_floats(ctypes.byref(md), B, nzm, 1))
@@ -149,8 +151,8 @@ class ArdaeEngine:
                               lib.ardae_model_workspace_floats(ctypes.byref(md), B, 1, 0)))
         self.ws_small_v = f(lib.ardae_model_workspace_floats(ctypes.byref(md), B, 1, 0))   # VAE-side encode(std=0): may run beside the cDAE phase
         self.z0, self.latent = f(B, z), f(N, z)
-        self.noise_s, self.xi, self.eps = f(N, nd), f(N), f(N, z)
-        self.xbar, self.sigma, self.std_b = f(N, z), f(N), f(B)
+        self.noise_s, self.xi, self.eps = f(N, nd), f(B * S), f(B * S, z)
+        self.xbar, self.sigma, self.std_b = f(B * S, z), f(B * S), f(B)
         self.noise_v, self.zv, self.z0v, self.u, self.g = f(B * nzm, nd), f(B * nzm, z), f(B, z), f(B * nzm, z), f(B * nzm, z)
         self.sigma0 = torch.zeros(B * nzm, device=self.dev)
         self.ctx_c, self.ctx_v = (f(B, ctx_dim), f(B, ctx_dim)) if (self.hidden_ctx or self.data_ctx) else (self.z0, self.z0v)
@@ -328,10 +330,11 @@ class ArdaeEngine:
             pair(0)
         if self.data_ctx:
             self._data_context(x, self.ctx_c)
-        L.check(lib.ardae_latent_perturb(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, z, cfg.std_scale, cfg.delta,
-                                         L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb")
+        nstd = int(cfg.nstd_cdae)
+        L.check(lib.ardae_latent_perturb_nstd(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, nstd, z, cfg.std_scale, cfg.delta,
+                                              L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb_nstd")
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
-                                          L.ptr(self.sigma), L.ptr(eps), L.ptr(self.ctx_c), B, nz, L.ptr(self.ws), self.ws.numel(),
+                                          L.ptr(self.sigma), L.ptr(eps), L.ptr(self.ctx_c), B, nz * nstd, L.ptr(self.ws), self.ws.numel(),
                                           L.ptr(self.loss_c), L.ptr(self.grads_c), None, st), "ardae_cdae_loss_grads")
         self._allreduce_mean(self.grads_c[:self.n_c])
         if apply_update:

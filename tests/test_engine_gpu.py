@@ -46,6 +46,7 @@ CASES.update({
 })
 CASES.update({nm: (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, True)
               for nm in ("tiny_mnist_opt_adam_adam", "tiny_mnist_opt_amsgrad_sgd", "tiny_mnist_opt_rmsprop_amsgrad", "tiny_mnist_opt_sgd_rmsprop")})
+CASES["tiny_mnist_nstd3"] = (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, True)
 RES_RECIPE = dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)     # run_vae_dbmnist.sh, the two resconv lines
 
 
@@ -131,6 +132,8 @@ def train_config(mc, nz, name=None, **kw):
         kw = dict(RES_RECIPE, **kw)
     if name in CTX_DATA:
         return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="data", ctx_data_center=CTX_DATA[name], **kw)
+    if name == "tiny_mnist_nstd3":          # --train-nstd-cdae 3
+        return net.TrainConfig(nz_cdae=nz, nstd_cdae=3, **kw)
     if name in OPT_PAIRS:
         return net.TrainConfig(nz_cdae=nz, m_optimizer=OPT_PAIRS[name][0], d_optimizer=OPT_PAIRS[name][1], **dict(OPT_KW, **kw))
     return net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a" if mc.kind in O.AUX_KINDS else "lt0", **kw)
@@ -817,3 +820,27 @@ def test_checkpoint_roundtrip_other_optimizers(tmp_path, m_opt, d_opt):
 def build_cuda(mc, cc):
     model, cdae = build(mc, cc)
     return model.to("cuda"), cdae.to("cuda")
+
+
+@pytest.mark.parametrize("B,nz,nstd,z", [(4, 8, 3, 8), (6, 256, 2, 32), (3, 625, 4, 32), (5, 16, 5, 2)])
+def test_latent_perturb_nstd_kernel(B, nz, nstd, z):
+    """--train-nstd-cdae > 1 (ivae_ardae.py:759-767): statistics over the nz samples, every sample row used nstd times with its own
+    sigma and eps - row (b, i, j) <- latent[b, i]."""
+    import ctypes
+    from ardae_amd import _lib as L
+    g = torch.Generator().manual_seed(B + nz + nstd + z)
+    z0 = torch.randn(B, z, generator=g)
+    latent = z0[:, None, :] + 0.05 * torch.randn(B, nz, z, generator=g)
+    xi, eps = torch.randn(B, nz * nstd, 1, generator=g), torch.randn(B * nz * nstd, z, generator=g)
+    u, std = O.latent_stats(latent, z0.view(B, 1, z), 1e4, 0.1)
+    u_exp = u.unsqueeze(2).expand(B, nz, nstd, z).reshape(B * nz * nstd, z)
+    sigma_ref = (std * xi).reshape(-1)
+    xbar_ref = u_exp + sigma_ref[:, None] * eps
+    d = lambda t: t.contiguous().cuda()
+    N = B * nz * nstd
+    xbar, sigma, std_b = torch.empty(N, z, device="cuda"), torch.empty(N, device="cuda"), torch.empty(B, device="cuda")
+    lat_d, z0_d, xi_d, eps_d = d(latent), d(z0), d(xi.reshape(-1)), d(eps)          # keep the device copies alive across the call
+    L.check(L.lib().ardae_latent_perturb_nstd(L.ptr(lat_d), L.ptr(z0_d), L.ptr(xi_d), L.ptr(eps_d), B, nz, nstd, z, 1e4, 0.1,
+                                              L.ptr(xbar), L.ptr(sigma), L.ptr(std_b), L.stream_ptr()), "ardae_latent_perturb_nstd")
+    torch.cuda.synchronize()
+    assert rel_l2(std_b, std.reshape(-1)) < 1e-5 and rel_l2(sigma, sigma_ref) < 1e-5 and rel_l2(xbar, xbar_ref) < 1e-5

@@ -27,6 +27,7 @@ CASES = {
     "tiny_mnist_ctxdata": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 24, 64, 3), 8, torch.float32),
     "tiny_toy_ctxdata": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("res", 2, 2, 64, 3), 8, torch.float32),
 }
+CASES["tiny_mnist_nstd3"] = (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, torch.float32)   # --train-nstd-cdae 3
 CTX_DATA = {"tiny_mnist_ctxdata": True, "tiny_toy_ctxdata": False}
 # --m-optimizer / --d-optimizer pairs beyond the recipes' (adam, rmsprop): the oracle's optimisers against the reference's over three steps
 OPT_PAIRS = {"tiny_mnist_opt_adam_adam": ("adam", "adam"), "tiny_mnist_opt_amsgrad_sgd": ("amsgrad", "sgd"),
@@ -70,6 +71,8 @@ def test_oracle_step_matches_reference_fixture(golden_dir, name):
     tc = O.TrainCfg(nz_cdae=nz, ctx_type="hidden1a" if mc.kind == "auxmnist" else "lt0")
     if name in CTX_DATA:
         tc = O.TrainCfg(nz_cdae=nz, ctx_type="data", ctx_center=CTX_DATA[name])
+    if name == "tiny_mnist_nstd3":
+        tc = O.TrainCfg(nz_cdae=nz, nstd=3)
     tol = 2e-4 if dt == torch.float32 else 1e-9    # another CPU/BLAS than the one that wrote the fixture: fp32 noise x 1e4 (std_scale)
     pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
     pc = {n: torch.tensor(fx["pc/" + n]) for n, _ in O.cdae_param_spec(cc)}
