@@ -103,7 +103,9 @@ __global__ void im2col3_kernel(const float* __restrict__ x, int H, int W, int C,
 }
 
 // transpose of im2col3 as a gather: dx[b][h][w][c] = sum_{kh,kw: (h+1-kh) % s == 0, oh = (h+1-kh)/s in range} dcols[(b,oh,ow)][c*9+kh*3+kw]
-__global__ void col2im3_kernel(const float* __restrict__ dcols, int H, int W, int C, int OH, int OW, int s, float* __restrict__ dx, int64_t total) {
+// mulS: multiply by act'(S[e]) on the way out (the activation in front of the convolution: one launch less per block)
+__global__ void col2im3_kernel(const float* __restrict__ dcols, int H, int W, int C, int OH, int OW, int s, float* __restrict__ dx, int64_t total,
+                               const float* __restrict__ mulS, int act) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int c = (int)(e % C);
@@ -126,7 +128,7 @@ __global__ void col2im3_kernel(const float* __restrict__ dcols, int H, int W, in
       v += dcols[((b * OH + oh) * OW + ow) * (int64_t)(C * 9) + c * 9 + kh * 3 + kw];
     }
   }
-  dx[e] = v;
+  dx[e] = mulS ? v * act_d1_rt(act, mulS[e]) : v;
 }
 
 __global__ void act_inplace_kernel(float* __restrict__ x, int act, int64_t n) {
@@ -373,8 +375,8 @@ int blk_fwd(const Blk& b, const BlkPk& k, const float* params, const float* pack
   }
   {
     LinArgs A{}; A.bias = params + b.a.bias; A.Y = u.hmid; A.ldY = b.Cout;
-    ARDAE_TRY(lin1(EPI_ACT, b.conv ? ACT_NONE : ACT_RELU, R, b.Cout, cx, b.a.I, b.a.I, packed + k.a.f, A, st));
-    if (b.conv) RES_LAUNCH(act_inplace_kernel, (int64_t)R * b.Cout, u.hmid, (int)ACT_ELU, (int64_t)R * b.Cout);
+    // conv blocks: ELU as the epilogue activation (their Cout <= 32 columns run on the generic kernel either way)
+    ARDAE_TRY(lin1(EPI_ACT, b.conv ? ACT_ELU : ACT_RELU, R, b.Cout, cx, b.a.I, b.a.I, packed + k.a.f, A, st));
   }
   const float* ch = u.hmid;
   if (b.conv) {
@@ -382,8 +384,11 @@ int blk_fwd(const Blk& b, const BlkPk& k, const float* params, const float* pack
     ch = u.colsh;
   }
   LinArgs A{}; A.bias = packed + k.bsum; A.Y = u.out; A.ldY = b.Cout;
-  ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, b.Cout, ch, b.h.I, b.h.I, packed + k.h.f, cx, b.a.I, b.s.I, packed + k.s.f, A, st));
-  if (act_out != ACT_NONE) RES_LAUNCH(act_inplace_kernel, (int64_t)R * b.Cout, u.out, act_out, (int64_t)R * b.Cout);
+  // the activation behind a conv block rides in the epilogue too; linear blocks keep it apart (their h-wide N-row products stay
+  // eligible for the software-pipelined kernel, which is not instantiated for ELU)
+  const int act_epi = b.conv ? act_out : ACT_NONE;
+  ARDAE_TRY(lin2(EPI_ACT, act_epi, R, b.Cout, ch, b.h.I, b.h.I, packed + k.h.f, cx, b.a.I, b.s.I, packed + k.s.f, A, st));
+  if (act_out != act_epi) RES_LAUNCH(act_inplace_kernel, (int64_t)R * b.Cout, u.out, act_out, (int64_t)R * b.Cout);
   return 0;
 }
 
@@ -445,8 +450,7 @@ int blk_bwd(const Blk& b, const BlkPk& k, const float* packed, const float* x, i
   if (b.conv) {
     LinArgs A{}; A.Y = sc.dcols; A.ldY = b.h.I;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, b.h.I, g, b.Cout, b.Cout, packed + k.h.b, A, st));
-    RES_LAUNCH(col2im3_kernel, nout, sc.dcols, b.Hout, b.Hout, b.Cout, b.Hout, b.Hout, 1, sc.dh, nout);
-    RES_LAUNCH(mul_dact_kernel, nout, sc.dh, u.hmid, (int)ACT_ELU, sc.dh, nout);
+    RES_LAUNCH(col2im3_kernel, nout, sc.dcols, b.Hout, b.Hout, b.Cout, b.Hout, b.Hout, 1, sc.dh, nout, (const float*)u.hmid, (int)ACT_ELU);
   } else {
     LinArgs A{}; A.S = u.hmid; A.ldS = b.Cout; A.Y = sc.dh; A.ldY = b.Cout;
     ARDAE_TRY(lin1(EPI_DACT, ACT_RELU, R, b.Cout, g, b.Cout, b.Cout, packed + k.h.b, A, st));
@@ -464,7 +468,7 @@ int blk_bwd(const Blk& b, const BlkPk& k, const float* packed, const float* x, i
     LinArgs A{}; A.Y = sc.dcols; A.ldY = b.a.I;
     ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, b.a.I, g, b.Cout, b.Cout, packed + k.s.b, sc.dh, b.Cout, b.Cout, packed + k.a.b, A, st));
     const int64_t nin = (int64_t)images * b.Hin * b.Hin * b.Cin;
-    RES_LAUNCH(col2im3_kernel, nin, sc.dcols, b.Hin, b.Hin, b.Cin, b.Hout, b.Hout, b.stride, d_x, nin);
+    RES_LAUNCH(col2im3_kernel, nin, sc.dcols, b.Hin, b.Hin, b.Cin, b.Hout, b.Hout, b.stride, d_x, nin, (const float*)nullptr, 0);
   } else {
     LinArgs A{}; A.Y = d_x; A.ldY = b.a.I;
     ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, b.a.I, g, b.Cout, b.Cout, packed + k.s.b, sc.dh, b.Cout, b.Cout, packed + k.a.b, A, st));
