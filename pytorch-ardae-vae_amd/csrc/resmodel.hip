@@ -31,23 +31,34 @@ size_t al64(size_t n) { return (n + 63) & ~size_t(63); }
 
 // ------------------------------------------------------------------------------------------------ kernels
 // weff[o][:] = scale[o] * dir[o][:] * inv,  inv = norm ? 1 / ||dir[o][:]|| : 1   (one workgroup per output row)
-__global__ __launch_bounds__(256) void wn_compose_kernel(const float* __restrict__ dir, const float* __restrict__ scale, int I, int norm,
-                                                         float* __restrict__ weff, float* __restrict__ inv_out) {
+// all operators of a model in ONE launch (a re-pack follows every optimiser step: ~50 launches of a few us each otherwise):
+// grid (max O, items); item = one weight-normalised operator, or (dir == nullptr) a bias sum  out[i] = a[i] + b[i]
+constexpr int WNC_MAX = 64;
+struct WnComposeItem { const float* dir; const float* scale; float* weff; float* inv; int O, I, norm; };
+struct WnComposeBatch { int n; WnComposeItem it[WNC_MAX]; };
+__global__ __launch_bounds__(256) void wn_compose_batch_kernel(const WnComposeBatch b) {
   __shared__ float red[256];
+  const WnComposeItem& w = b.it[blockIdx.y];
   const int o = blockIdx.x, t = threadIdx.x;
-  const float* d = dir + (size_t)o * I;
+  if (w.dir == nullptr) {       // bias sum: scale = a, inv = b (inputs), weff = out, O entries
+    const int i = o * 256 + t;
+    if (i < w.O) w.weff[i] = w.scale[i] + w.inv[i];
+    return;
+  }
+  if (o >= w.O) return;
+  const float* d = w.dir + (size_t)o * w.I;
   float s = 0.f;
-  for (int i = t; i < I; i += 256) s += d[i] * d[i];
+  for (int i = t; i < w.I; i += 256) s += d[i] * d[i];
   red[t] = s;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) {
     if (t < k) red[t] += red[t + k];
     __syncthreads();
   }
-  const float inv = norm ? 1.f / sqrtf(red[0]) : 1.f;
-  const float f = scale[o] * inv;
-  for (int i = t; i < I; i += 256) weff[(size_t)o * I + i] = f * d[i];
-  if (t == 0) inv_out[o] = inv;
+  const float inv = w.norm ? 1.f / sqrtf(red[0]) : 1.f;
+  const float f = w.scale[o] * inv;
+  for (int i = t; i < w.I; i += 256) w.weff[(size_t)o * w.I + i] = f * d[i];
+  if (t == 0) w.inv[o] = inv;
 }
 
 // dL/dW [O, I] -> dL/ddir, dL/dscale (and the bias gradients, plain copies) for up to WNB_MAX operators in one launch
@@ -139,10 +150,6 @@ __global__ void act_inplace_kernel(float* __restrict__ x, int act, int64_t n) {
 __global__ void mul_dact_kernel(const float* __restrict__ x, const float* __restrict__ S, int act, float* __restrict__ y, int64_t n) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) y[e] = x[e] * act_d1_rt(act, S[e]);
-}
-__global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int n) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) y[e] = a[e] + b[e];
 }
 
 // bilinear x2 upsampling, align_corners=True (nn.Upsample in models/vae/resconv.py:96-106), NHWC; src = o (IH-1)/(OH-1)
@@ -663,16 +670,17 @@ int res_model_pack(const ardae_model_desc& d, const float* params, float* packed
   const ResLayout P(d);
   const ResPacked K(P);
   std::vector<PackItem> items;
+  std::vector<WnComposeItem> comp;
   auto wn = [&](const WN& w, const WNPk& k) -> int {
-    hipLaunchKernelGGL(wn_compose_kernel, dim3(w.O), dim3(256), 0, st, params + w.dir, params + w.scale, w.I, w.norm ? 1 : 0, packed + k.weff, packed + k.inv);
-    ARDAE_LAUNCH_CHECK();
+    comp.push_back(WnComposeItem{params + w.dir, params + w.scale, packed + k.weff, packed + k.inv, w.O, w.I, w.norm ? 1 : 0});
     items.push_back(PackItem{packed + k.weff, w.I, w.O, w.I, 0, packed + k.f});
     items.push_back(PackItem{packed + k.weff, w.I, w.I, w.O, 1, packed + k.b});
     return 0;
   };
   auto blk = [&](const Blk& b, const BlkPk& k, int split) -> int {
     ARDAE_TRY(wn(b.a, k.a)); ARDAE_TRY(wn(b.h, k.h)); ARDAE_TRY(wn(b.s, k.s));
-    RES_LAUNCH(vec_add_kernel, b.Cout, params + b.h.bias, params + b.s.bias, packed + k.bsum, b.Cout);
+    // bsum = b_h + b_s rides in the same launch (dir == nullptr: scale / inv are the two inputs; the inputs are never written)
+    comp.push_back(WnComposeItem{nullptr, params + b.h.bias, packed + k.bsum, const_cast<float*>(params + b.s.bias), b.Cout, 0, 0});
     if (split) {
       const int nn = b.a.I - split;
       items.push_back(PackItem{packed + k.a.weff, b.a.I, b.a.O, split, 0, packed + k.a_fi});
@@ -698,6 +706,17 @@ int res_model_pack(const ardae_model_desc& d, const float* params, float* packed
   if (P.kind == 5) { ARDAE_TRY(blk(P.fc0, K.fc0, P.cdim)); ARDAE_TRY(blk(P.fc1, K.fc1, 0)); }
   else { lin(P.mu0, K.mu0, 0); lin(P.lv0, K.lv0, 0); lin(P.efc, K.efc, P.cdim); lin(P.mu, K.mu, 0); lin(P.lv, K.lv, 0); }
   for (size_t i = 0; i < P.dec.size(); ++i) ARDAE_TRY(blk(P.dec[i], K.dec[i], 0));
+  for (size_t i0 = 0; i0 < comp.size(); i0 += WNC_MAX) {
+    WnComposeBatch cb;
+    cb.n = (int)std::min<size_t>(WNC_MAX, comp.size() - i0);
+    int maxo = 1;
+    for (int i = 0; i < cb.n; ++i) {
+      cb.it[i] = comp[i0 + i];
+      maxo = std::max(maxo, cb.it[i].dir ? cb.it[i].O : ceil_div(cb.it[i].O, 256));
+    }
+    hipLaunchKernelGGL(wn_compose_batch_kernel, dim3(maxo, cb.n), dim3(256), 0, st, cb);
+    ARDAE_LAUNCH_CHECK();
+  }
   return launch_pack_batch(items.data(), (int)items.size(), st);
 }
 
