@@ -203,7 +203,10 @@ typedef struct ardae_model_desc {
   int input_dim, noise_dim, h_dim, z_dim;
   int n_layers; /* --model-n-layers */
   int act;      /* any ARDAE_ACT_* but NONE; kinds 5 / 6: ARDAE_ACT_ELU */
+  int flags;    /* kinds 5 / 6: ARDAE_MODEL_NO_CENTER = do_center False (--model resconv-res / auxresconv: the trunk sees x, not 2x - 1;
+                 * ivae/resconv.py:131-132, vae/auxresconv.py:56-58); 0 elsewhere */
 } ardae_model_desc;
+enum { ARDAE_MODEL_NO_CENTER = 1 };
 size_t ardae_model_param_floats(const ardae_model_desc* d);
 size_t ardae_model_packed_floats(const ardae_model_desc* d);
 /* mode 0: encode only; mode 1: vae_forward + vae_backward; mode 2: decode only (B = rows, nz = 1); mode 3: encode_pair */

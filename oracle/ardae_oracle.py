@@ -59,6 +59,7 @@ class ModelCfg:
     z_dim: int = 32
     n_layers: int = 2            # --model-n-layers
     nonlin: str = "softplus"
+    do_center: bool = True       # residual-conv kinds: the trunk sees 2x - 1 (--model resconvct-res / auxresconvct) or x (resconv-res / auxresconv)
 
 
 @dataclass
@@ -351,7 +352,8 @@ def resconv_trunk(c, p, x):
     """The per-image trunk both families share (ivae/resconv.py:81-96, vae/auxresconv.py:36-63; do_center=True):
     28 -> 14 -> 14 -> 7 -> 7 -> 4, flatten (NCHW), ResLinear 512 -> c_dim, ELU after every block."""
     tp = "encode.inp_encode." if c.kind == "resconv" else "encode.inp_encode.enc."
-    h = (2 * x.reshape(x.size(0), 784) - 1).view(-1, 1, 28, 28)
+    h = x.reshape(x.size(0), 784)
+    h = (2 * h - 1 if c.do_center else h).view(-1, 1, 28, 28)
     for i, st in zip((0, 2, 4, 6, 8), (2, 1, 2, 1, 2)):
         h = F.elu(res_conv(p, f"{tp}{i}.", h, st, F.elu))
     return F.elu(res_linear(p, f"{tp}11.", h.reshape(h.size(0), 512), True))

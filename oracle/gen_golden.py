@@ -67,10 +67,10 @@ def build_reference(net, mc, cc, pm, pc, dtype):
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "resconv":   # ivae_ardae.py:359-370 (--model resconvct-res)
         model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
-                                 noise_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=True, enc_type="res-wn-mlp")
+                                 noise_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type="res-wn-mlp")
     elif mc.kind == "auxresconv":   # ivae_ardae.py:493-505 (--model auxresconvct)
         model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim,
-                                         nonlinearity=mc.nonlin, do_center=True)
+                                         nonlinearity=mc.nonlin, do_center=mc.do_center)
     elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
                                num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
@@ -473,6 +473,11 @@ def main():
     ares_t = O.TrainCfg(nz_cdae=8, std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9, ctx_type="hidden1a")
     run_case(net, rutils, "auxresconv_b4_nz8_f64", ares_m, ares_c, ares_t, B=4, steps=1, dtype=f64, store_full=False)
     run_case(net, rutils, "auxresconv_b4_nz8", ares_m, ares_c, ares_t, B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    # --model resconv-res / auxresconv (ivae_ardae.py:347-358,479-492): the same families with do_center=False (the trunk sees x, not 2x - 1)
+    run_case(net, rutils, "resconv_nocenter_b4_nz8", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", do_center=False), res_c, res_t,
+             B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    run_case(net, rutils, "auxresconv_nocenter_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False), ares_c, ares_t,
+             B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
     run_iwae_case(net, "iwae_resconv", res_m, B=2, k=64, dtype=f64, store_params=False)
     run_iwae_case(net, "iwae_auxresconv", ares_m, B=2, k=64, dtype=f64, store_params=False)
     # reference-written checkpoint (model / cDAE state_dict + utils.Adam / torch.optim.RMSprop state_dict) and the step after it

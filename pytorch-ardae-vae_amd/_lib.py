@@ -67,7 +67,10 @@ class ProfileEntry(ctypes.Structure):
 
 class ModelDesc(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("input_dim", ctypes.c_int), ("noise_dim", ctypes.c_int), ("h_dim", ctypes.c_int),
-                ("z_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int)]
+                ("z_dim", ctypes.c_int), ("n_layers", ctypes.c_int), ("act", ctypes.c_int), ("flags", ctypes.c_int)]
+
+
+MODEL_NO_CENTER = 1      # ardae_model_desc.flags (residual-conv kinds: do_center=False)
 
 
 # utils/models.py:14-32 (get_nonlinear_func); 'csoftplus' = log(exp(x) + 1) is softplus (evaluated in its accurate form); 'swish' is not offered

@@ -247,12 +247,14 @@ struct Blk { WN a, h, s; bool conv; int Cin, Cout, stride, Hin, Hout; };        
 
 struct ResLayout {
   int kind, nd, zd, cdim, hdim;
+  bool center;                   // do_center: the trunk sees 2x - 1 (desc.flags without ARDAE_MODEL_NO_CENTER)
   std::vector<Blk> trunk, dec;   // trunk: 5 conv + ResLinear(512 -> cdim); dec: 2 ResLinear + 5 conv
   Blk fc0, fc1;                  // kind 5: encode.fc.layers.0 (cdim + nd -> hdim), encode.fc.fc (hdim -> zd), un-normalised
   Lin mu0, lv0, efc, mu, lv;     // kind 6: aux_encode.reparam.{mean,logvar}_fn, encode.fc.0, encode.reparam.{mean,logvar}_fn
   size_t total = 0;
 
-  explicit ResLayout(const ardae_model_desc& d) : kind(d.kind), nd(d.noise_dim), zd(d.z_dim), cdim(d.kind == 5 ? 512 : d.h_dim), hdim(d.h_dim) {
+  explicit ResLayout(const ardae_model_desc& d)
+      : kind(d.kind), nd(d.noise_dim), zd(d.z_dim), cdim(d.kind == 5 ? 512 : d.h_dim), hdim(d.h_dim), center(!(d.flags & ARDAE_MODEL_NO_CENTER)) {
     size_t off = 0;
     auto wn = [&](int O, int I, bool norm) {
       WN w; w.O = O; w.I = I; w.norm = norm;
@@ -569,7 +571,8 @@ size_t res_workspace(const ResLayout& P, int B, int nz, int mode) {
 
 // ------------------------------------------------------------------------------------------------ forward pieces
 int trunk_fwd(const ResLayout& P, const ResPacked& K, const float* params, const float* packed, const float* x, int B, ResWs& W, hipStream_t st) {
-  ARDAE_TRY(launch_affine(x, (int64_t)B * 784, 2.f, -1.f, W.x2, st));       // do_center (ivae/resconv.py:131-132)
+  if (P.center) ARDAE_TRY(launch_affine(x, (int64_t)B * 784, 2.f, -1.f, W.x2, st));       // do_center (ivae/resconv.py:131-132)
+  else ARDAE_TRY(launch_affine(x, (int64_t)B * 784, 1.f, 0.f, W.x2, st));
   const float* cur = W.x2;
   for (size_t i = 0; i < 5; ++i) {
     ARDAE_TRY(blk_fwd(P.trunk[i], K.trunk[i], params, packed, cur, B, ACT_ELU, W.tb[i], st));

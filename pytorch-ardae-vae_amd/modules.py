@@ -272,7 +272,8 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self.input_dim, self.noise_dim, self.h_dim, self.z_dim = input_dim, noise_dim, h_dim, z_dim
         self.latent_dim = z_dim
         self.nonlinearity, self.num_hidden_layers, self.init, self.enc_type = nonlinearity, num_hidden_layers, init, enc_type
-        self._desc = L.ModelDesc(KIND_IDS[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, L.ACT[nonlinearity])
+        flags = L.MODEL_NO_CENTER if self._kind in ("resconv", "auxresconv") and not getattr(self, "do_center", True) else 0
+        self._desc = L.ModelDesc(KIND_IDS[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, L.ACT[nonlinearity], flags)
         # floats per row of a sampler draw: the aux models take two draws per call, laid out side by side [eps0 | eps]
         self._noise_width = noise_dim + z_dim if self._kind in AUX_KINDS else noise_dim
         # columns of the `hidden1a` cDAE context (ivae_ardae.py:572-580): cat(h0, h) for the MLP / conv aux models, h alone for auxresconv
@@ -518,17 +519,17 @@ class MNISTConvAuxIPVAE(ImplicitPosteriorVAE):
 
 
 class ResConvIPVAE(ImplicitPosteriorVAE):
-    """models/ivae/resconv.py::ImplicitPosteriorVAE as `--model resconvct-res` builds it (ivae_ardae.py:359-370; the shipped "implicit
-    resconv" recipe): weight-normalised residual-conv trunk and decoder, ResMLP sampler head, ELU, 28x28x1, c_dim 512."""
+    """models/ivae/resconv.py::ImplicitPosteriorVAE as `--model resconvct-res` (do_center=True; ivae_ardae.py:359-370, the shipped "implicit
+    resconv" recipe) and `--model resconv-res` (do_center=False, :347-358) build it: weight-normalised residual-conv trunk and decoder, ResMLP sampler head, ELU, 28x28x1, c_dim 512."""
     _kind = "resconv"
 
     def __init__(self, energy_func=normal_energy_func, input_height=28, input_channels=1, z_dim=32, noise_dim=100, c_dim=512, h_dim=800,
                  num_hidden_layers=1, nonlinearity="elu", do_center=False, do_m5bias=False, enc_noise=False, enc_type="mlp"):
         if input_height != 28 or input_channels != 1:
             raise AssertionError("input_height == 28 and input_channels == 1")           # ivae/resconv.py:218-219
-        if not do_center or enc_type != "res-wn-mlp" or enc_noise or do_m5bias or c_dim != 512 or num_hidden_layers != 1:
-            raise NotImplementedError("the HIP engine builds ResConvIPVAE as --model resconvct-res does: do_center=True, "
-                                      "enc_type='res-wn-mlp', c_dim=512, one ResMLP layer, no enc_noise / do_m5bias")
+        if enc_type != "res-wn-mlp" or enc_noise or do_m5bias or c_dim != 512 or num_hidden_layers != 1:
+            raise NotImplementedError("the HIP engine builds ResConvIPVAE as --model resconvct-res / resconv-res do: enc_type='res-wn-mlp', "
+                                      "c_dim=512, one ResMLP layer, no enc_noise / do_m5bias (do_center either way)")
         self.input_height, self.input_channels, self.c_dim = input_height, input_channels, c_dim
         self.do_center, self.do_m5bias, self.enc_noise = do_center, do_m5bias, enc_noise
         super().__init__(energy_func, 784, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, "none", "concat")
@@ -544,9 +545,9 @@ class MNISTResConvAuxIPVAE(ImplicitPosteriorVAE):
     def __init__(self, energy_func=normal_energy_func, input_height=28, input_channels=1, z0_dim=100, z_dim=32, c_dim=450, nonlinearity="elu",
                  do_center=False, do_m5bias=False):
         assert input_height == 28 and input_channels == 1 and nonlinearity == "elu"     # ivae/auxresconv.py:67-69
-        if not do_center or do_m5bias:
-            raise NotImplementedError("the HIP engine builds MNISTResConvAuxIPVAE as --model auxresconvct does (do_center=True, no do_m5bias)")
-        self.input_height, self.input_channels, self.z0_dim, self.c_dim, self.do_center, self.do_m5bias = input_height, input_channels, z0_dim, c_dim, True, False
+        if do_m5bias:
+            raise NotImplementedError("the HIP engine builds MNISTResConvAuxIPVAE as --model auxresconvct / auxresconv do (no do_m5bias; do_center either way)")
+        self.input_height, self.input_channels, self.z0_dim, self.c_dim, self.do_center, self.do_m5bias = input_height, input_channels, z0_dim, c_dim, bool(do_center), False
         super().__init__(energy_func, 784, z0_dim, c_dim, z_dim, nonlinearity, 1, "none", "concat")
 
 

@@ -47,16 +47,19 @@ CASES.update({
 CASES.update({nm: (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, True)
               for nm in ("tiny_mnist_opt_adam_adam", "tiny_mnist_opt_amsgrad_sgd", "tiny_mnist_opt_rmsprop_amsgrad", "tiny_mnist_opt_sgd_rmsprop")})
 CASES["tiny_mnist_nstd3"] = (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3), 8, True)
+# --model resconv-res / auxresconv: do_center=False (ivae_ardae.py:347-358,479-492)
+CASES["resconv_nocenter_b4_nz8"] = (O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 32, 64, 2), 8, False)
+CASES["auxresconv_nocenter_b4_nz8"] = (O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 450, 64, 2), 8, False)
 RES_RECIPE = dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)     # run_vae_dbmnist.sh, the two resconv lines
 
 
 def build(mc, cc):
     if mc.kind == "resconv":
         model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers, noise_dim=mc.noise_dim,
-                                 nonlinearity=mc.nonlin, do_center=True, enc_type="res-wn-mlp")
+                                 nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type="res-wn-mlp")
     elif mc.kind == "auxresconv":
         model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim, nonlinearity=mc.nonlin,
-                                         do_center=True)
+                                         do_center=mc.do_center)
     elif mc.kind == "auxconv":
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "auxmnist":

@@ -105,6 +105,9 @@ def test_oracle_step_matches_reference_fixture(golden_dir, name):
     # weight-normalised residual-conv families of the shipped "implicit resconv" / "hierarchical resconv" recipes
     ("resconv_b4_nz8", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu"), O.CdaeCfg("res", 32, 32, 64, 2), "lt0"),
     ("auxresconv_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu"), O.CdaeCfg("res", 32, 450, 64, 2), "hidden1a"),
+    # --model resconv-res / auxresconv: the same families with do_center=False
+    ("resconv_nocenter_b4_nz8", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 32, 64, 2), "lt0"),
+    ("auxresconv_nocenter_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 450, 64, 2), "hidden1a"),
 ])
 def test_oracle_step_matches_reference_summaries(golden_dir, name, mc, cc, ctx):
     """Fixtures that hold summaries only (parameters regenerated from the seed): losses, latent statistics and the norm / sum /
