@@ -666,7 +666,8 @@ int launch_wide(const LinArgs& a, hipStream_t st) {
   const int grid = wide_grid(ntiles, ncp);
   if (g_prof_enabled) {
     char name[96];
-    snprintf(name, sizeof(name), "linear_wide_kernel<%d, %d, %d, %d, %d, %d, %d>", NCH, NP, NJ, EPI, ACT, (int)F1, (int)F2);
+    // spelled as rocprofv3 demangles the instantiation: bench.py joins this log with profiles/pmc_summary.json by name
+    snprintf(name, sizeof(name), "linear_wide_kernel<%d, %d, %d, %d, %d, %s, %s>", NCH, NP, NJ, EPI, ACT, F1 ? "true" : "false", F2 ? "true" : "false");
     double ksum = 0;
     for (int s = 0; s < a.nsrc; ++s) ksum += a.src[s].K;
     double tensors = 1.0 + (a.Y2 ? 1 : 0) + ((EPI == EPI_DACT || EPI == EPI_CHAIN) ? 1 : 0) + ((EPI == EPI_CHAIN) ? 1 : 0) +
