@@ -47,69 +47,10 @@ struct Geo {
   static constexpr int LDS_FLOATS = 2 * BM * LDW;   // double-buffered K panels
 };
 
-// Vectorised epilogue for the TRANSPOSED accumulator (TR kernels compute D = W_frag . X_frag^T, i.e. MFMA operand order
-// swapped): lane l holds output row m = l&31 and, per register group g = r>>2, the four CONSECUTIVE columns
-// n = 8g + 4(l>>5) + (r&3) - so every operand / result moves as one float4 per lane (4x fewer memory instructions than
-// the dword epilogue of the row-major accumulator).  On gfx950 a v_mfma_f32_32x32x2_f32 stream keeps its SIMD's issue
-// port nearly saturated, so every non-MFMA instruction of ANY wave on that SIMD costs matrix time: instruction count,
-// not memory overlap, is what this kernel optimises.  Full tiles only (the dispatcher guarantees M % BM == 0, Nout % 64 == 0).
-template <int EPI, int ACT>
-__device__ __forceinline__ void epilogue_tr(const LinArgs& a, const f32x16& acc, int m, int nbase) {
-  f32x4 sv[4], qv[4], y[4], y2[4];
-  const size_t mrow = (size_t)m;
-  if (EPI == EPI_DACT || EPI == EPI_CHAIN) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const f32x4*>(a.S + mrow * a.ldS + nbase + 8 * g);
-    if (EPI == EPI_CHAIN) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) qv[g] = *reinterpret_cast<const f32x4*>(a.R + mrow * a.ldR + nbase + 8 * g);
-    } else if (a.Q) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) qv[g] = *reinterpret_cast<const f32x4*>(a.Q + mrow * a.ldQ + nbase + 8 * g);
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) qv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  } else {   // EPI_ACT
-    const float rs = a.rowscale ? a.rowscale[m] : 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 pre = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nbase + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.rowbias) pre += *reinterpret_cast<const f32x4*>(a.rowbias + (size_t)(m / a.rows_per_group) * a.rowbias_ld + nbase + 8 * g);
-      if (a.rowscale) pre += rs * *reinterpret_cast<const f32x4*>(a.rowscale_w + nbase + 8 * g);
-      sv[g] = pre;
-      qv[g] = a.Y2 ? *reinterpret_cast<const f32x4*>(a.R + nbase + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};   // w of the score seed
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float v = acc[4 * g + e];
-      if (EPI == EPI_ACT) {
-        y[g][e] = act_fwd<ACT>(v + sv[g][e]);
-        y2[g][e] = -qv[g][e] * act_d1<ACT>(y[g][e]);
-      } else if (EPI == EPI_DACT) {
-        y[g][e] = v * act_d1<ACT>(sv[g][e]) + qv[g][e];
-      } else {
-        const float em = act_ratio<ACT>(sv[g][e]);   // s'/s (softplus: 1 - s without cancellation)
-        y[g][e] = v * act_d1<ACT>(sv[g][e]);
-        y2[g][e] = v * qv[g][e] * em;
-      }
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.Y + mrow * a.ldY + nbase + 8 * g) = y[g];
-  if (EPI == EPI_CHAIN || (EPI == EPI_ACT && a.Y2)) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.Y2 + mrow * a.ldY2 + nbase + 8 * g) = y2[g];
-  }
-}
-
 // One output tile (bx = row tile, by = column panel of a grid that has nby column panels).  `lds` holds
 // Geo::LDS_FLOATS floats, `red` four.  linear_kernel runs one tile per workgroup (
 // consecutive layers for a fixed set of rows.
-template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, bool TR>
+template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT>
 __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, int nby, float* lds, float* red) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
   constexpr int BM = G::BM, LDW = G::LDW;
@@ -214,7 +155,7 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
   // Small-M geometry with 256-wide panels (per-image layers): the launch is latency, not throughput - put ALL 32 weight
   // fragments of a full panel in flight at once (128 registers), for the first panel even before the activations are
   // staged, instead of one L2 round trip per 8-deep chunk.
-  constexpr bool ALLB = TM == 1 && TN == 1 && KPANEL == 256 && !TR;
+  constexpr bool ALLB = TM == 1 && TN == 1 && KPANEL == 256;
   f32x4 ball[ALLB ? 32 : 1];
   bool ball_valid = false;
   auto load_all_b = [&](const Panel& p) {
@@ -294,8 +235,7 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(be[j][q], av[i][q], acc[i][j], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], be[j][q], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], be[j][q], acc[i][j], 0, 0, 0);
         const int kn = min(kc + 2, nch - 1);
 #pragma unroll
         for (int j = 0; j < TN; ++j) be[j] = *reinterpret_cast<const f32x4*>(bptr[j] + (size_t)kn * 256);
@@ -307,8 +247,7 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bo[j][q], av[i][q], acc[i][j], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bo[j][q], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bo[j][q], acc[i][j], 0, 0, 0);
       }
       if (kc < nch) {   // odd tail (be holds chunk kc)
 #pragma unroll
@@ -319,8 +258,7 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(be[j][q], av[i][q], acc[i][j], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], be[j][q], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], be[j][q], acc[i][j], 0, 0, 0);
       }
     }
     if (!has_next) break;
@@ -353,15 +291,7 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
     return;
   }
 #endif
-  if (TR) {
-    if (wave_active) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          epilogue_tr<(EPI == EPI_DAE_LOSS ? EPI_ACT : EPI), ACT>(a, acc[i][j], row0 + (wm * TM + i) * 32 + l31, (nb0 + j) * 32 + 4 * hh);
-    }
-  } else if (wave_active) {
+  if (wave_active) {
     const bool full = rows_full && (nb0 + TN) * 32 <= a.Nout;   // wave-uniform: no masks, no clamps
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -400,7 +330,7 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
   }
 }
 
-template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB, bool TR>
+template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB>
 __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
 #ifdef ARDAE_DBG_LDSPAD
@@ -409,7 +339,7 @@ __global__ __launch_bounds__(256, MINB) void linear_kernel(const LinArgs a) {
   __shared__ float lds[G::LDS_FLOATS];
 #endif
   __shared__ float red[4];
-  linear_tile<TM, TN, WM, WN, KPANEL, EPI, ACT, TR>(a, blockIdx.x, blockIdx.y, gridDim.y, lds, red);
+  linear_tile<TM, TN, WM, WN, KPANEL, EPI, ACT>(a, blockIdx.x, blockIdx.y, gridDim.y, lds, red);
 }
 
 // M[n][k] -> packed[nb][kc][lane][j], n = nb*32 + (lane&31), k = kc*8 + 4*(lane>>5) + j
@@ -463,13 +393,13 @@ __global__ void pack_batch_kernel(const PackBatchDev b) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB, bool TR = false>
+template <int TM, int TN, int WM, int WN, int KPANEL, int EPI, int ACT, int MINB>
 int launch_geo(const LinArgs& a, hipStream_t st) {
   using G = Geo<TM, TN, WM, WN, KPANEL>;
   dim3 grid(ceil_div(a.M, G::BM), ceil_div(a.Nout, G::BN));
   if (g_prof_enabled) {
     char name[96];
-    snprintf(name, sizeof(name), "linear_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", TM, TN, WM, WN, KPANEL, EPI, ACT, MINB, TR ? "true" : "false");
+    snprintf(name, sizeof(name), "linear_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", TM, TN, WM, WN, KPANEL, EPI, ACT, MINB);
     double ksum = 0;
     for (int s = 0; s < a.nsrc; ++s) ksum += a.src[s].K;
     // algorithmic bytes: X read once, Y (+Y2) written once, S/R/Q read once, weights once
@@ -477,7 +407,7 @@ int launch_geo(const LinArgs& a, hipStream_t st) {
                      ((EPI == EPI_DACT && a.Q) ? 1 : 0);
     prof_begin(st, name, 2.0 * a.M * (double)a.Nout * ksum, 4.0 * ((double)a.M * ksum + tensors * a.M * (double)a.Nout + ksum * a.Nout));
   }
-  hipLaunchKernelGGL((linear_kernel<TM, TN, WM, WN, KPANEL, EPI, ACT, MINB, TR>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((linear_kernel<TM, TN, WM, WN, KPANEL, EPI, ACT, MINB>), grid, dim3(256), 0, st, a);
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;
@@ -491,27 +421,6 @@ int pick_geometry(int M, int nout) {
   return 2;
 }
 
-bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-// float4 epilogue on the transposed accumulator: full tiles and 16-byte aligned operands only
-bool tr_eligible(const LinArgs& a, int epi) {
-  // opt-in (ARDAE_TR=1): 4x fewer epilogue memory instructions, but each touches 32 rows x 32 B - measured slower than the
-  // dword epilogue whose instructions cover two full 128-B lines (CHAIN 56 vs 69 TFLOP/s in the full step)
-  static const bool on = getenv("ARDAE_TR") != nullptr;
-  if (!on || a.colsum != nullptr || (a.M & 63) || (a.Nout & 63)) return false;
-  if ((a.ldY & 3) || !al16(a.Y) || (a.Y2 && ((a.ldY2 & 3) || !al16(a.Y2)))) return false;
-  if (epi == EPI_ACT) {
-    if (a.bias && !al16(a.bias)) return false;
-    if (a.rowbias && ((a.rowbias_ld & 3) || !al16(a.rowbias))) return false;
-    if (a.rowscale && !al16(a.rowscale_w)) return false;
-    if (a.Y2 && !al16(a.R)) return false;
-    return true;
-  }
-  if ((a.ldS & 3) || !al16(a.S)) return false;
-  if (epi == EPI_CHAIN) return !(a.ldR & 3) && al16(a.R);
-  return !a.Q || (!(a.ldQ & 3) && al16(a.Q));
-}
-
 template <int EPI, int ACT>
 int launch_epi(const LinArgs& a, hipStream_t st) {
   switch (pick_geometry(a.M, a.Nout)) {
@@ -521,7 +430,6 @@ int launch_epi(const LinArgs& a, hipStream_t st) {
     case 1:
       return launch_geo<1, 1, 1, 4, SMALLM_KPANEL, EPI, ACT, SMALLM_MINB>(a, st);
     default:
-      if (EPI != EPI_DAE_LOSS && tr_eligible(a, EPI)) return launch_geo<2, 2, 1, 4, WIDE_KPANEL, EPI, ACT, WIDE_MINB, true>(a, st);
       return launch_geo<2, 2, 1, 4, WIDE_KPANEL, EPI, ACT, WIDE_MINB>(a, st);
   }
 }

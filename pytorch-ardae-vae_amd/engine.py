@@ -311,8 +311,8 @@ class ArdaeEngine:
             L.check(lib.ardae_model_encode_pair(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(ns), B, nz,
                                                 L.ptr(self.ws), self.ws.numel(), L.ptr(self.z0), L.ptr(self.latent), phase, st),
                     "ardae_model_encode_pair")
-        # (opt-in, ARDAE_PAIR_SPLIT=1: under HIP-graph replay the extra mid-chain cross-stream edge cost 0.22 ms per step on
-        # MI355X / ROCm 7.2, while eager launches gained 0.02 - so the default waits for the draws up front)
+        # (waiting for the draws in the MIDDLE of the pair - per-image trunk first - was measured: under HIP-graph replay the extra
+        # cross-stream edge cost 0.22 ms per step on MI355X / ROCm 7.2; the wait sits in front of the pair)
         if self.hidden_ctx:
             # aux models: hidden = model.encode.forward_hidden(x, std=0) and latent_mean = model.encode(x, std=0) are ONE std = 0 pass
             # (ivae_ardae.py:737-739,748), then the N-row pass
@@ -320,10 +320,6 @@ class ArdaeEngine:
                 torch.cuda.current_stream().wait_event(drawn)
             self._hidden(x, self.z0, self.ctx_c, self.ws_small)
             self._encode(x, ns, nz, self.latent, self.ws)
-        elif drawn is not None and not noise and os.environ.get("ARDAE_PAIR_SPLIT", "0") == "1":
-            pair(1)
-            torch.cuda.current_stream().wait_event(drawn)
-            pair(2)
         else:
             if drawn is not None and not noise:
                 torch.cuda.current_stream().wait_event(drawn)
@@ -424,7 +420,7 @@ class ArdaeEngine:
                 self._side.wait_stream(main)
                 drawn = None
                 with torch.cuda.stream(self._side):
-                    if noise is None and len(xs) == 1 and os.environ.get("ARDAE_SIDE_RNG", "1") != "0":
+                    if noise is None and len(xs) == 1:
                         # the cDAE update's three draws need nothing but the step state: they run beside the sampler trunk
                         self._normal(self.noise_s, 0); self._normal(self.xi, 1); self._normal(self.eps, 2)
                         self._draws = 3
