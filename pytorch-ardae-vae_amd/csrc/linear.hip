@@ -278,19 +278,6 @@ __device__ __forceinline__ void linear_tile(const LinArgs& a, int bx, int by, in
 #endif
   // ------------------------------------------------------------------ epilogue
   float loss_part = 0.f;
-#ifdef ARDAE_DBG_NOEPI
-  {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-    if (s == 12345.678f) a.Y[tid] = s;
-    return;
-  }
-#endif
   if (wave_active) {
     const bool full = rows_full && (nb0 + TN) * 32 <= a.Nout;   // wave-uniform: no masks, no clamps
 #pragma unroll

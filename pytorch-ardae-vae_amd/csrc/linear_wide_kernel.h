@@ -620,21 +620,8 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
                  : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(acc[0][0]), "+v"(acc[0][NJ - 1]), "+v"(acc[1][0]), "+v"(acc[1][NJ - 1])
                  :
                  : "memory");
-#ifdef ARDAE_DBG_NOEPI
-    {
-      float sum = rb[0];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
-      if (sum == 12345.678f) a.Y[tid] = sum;
-    }
-#else
     epi.template run<0, !SC::DEFER>(acc, l0, l1, rb, lane, row0, colw, tr);
     if (SC::DEFER) prev_row0 = row0;
-#endif
 #ifdef ARDAE_STAMPS
     t_e += __builtin_amdgcn_s_memtime() - T1;
 #endif
@@ -642,9 +629,7 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   // the first tile has no predecessor whose stores could ride in its K loop: its own copy of the tile body
   do_tile(std::true_type{});
   for (tile += rts; tile < nrt; tile += rts) do_tile(std::false_type{});
-#ifndef ARDAE_DBG_NOEPI
   if (SC::DEFER && prev_row0 >= 0) epi.store_all(l0, l1, prev_row0, colw);
-#endif
   // the last panel prefetched a (dummy) next panel: drain before the registers die
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef ARDAE_STAMPS
