@@ -555,7 +555,18 @@ class ArdaeEngine:
         return {"state_dict": {k: t.clone() for k, t in self.cdae.state_dict().items()},
                 "optimizer": {"state": self._opt_state(self.cdae, self.opt_c), "param_groups": [self.opt_c.param_group(nparams)]}}
 
-    def _load_opt_state(self, module, opt, state, what):
+    @staticmethod
+    def _kind_of_group(group):
+        """Which optimiser wrote this torch.optim param_group (utils.Adam / torch.optim.RMSprop / torch.optim.SGD layouts)."""
+        if "betas" in group:
+            return "amsgrad" if group.get("amsgrad") else "adam"
+        return "rmsprop" if "alpha" in group else "sgd"
+
+    def _load_opt_state(self, module, opt, state, what, groups=None):
+        if groups:
+            wrote = self._kind_of_group(groups[0])
+            if wrote != opt.kind:
+                raise ValueError(f"{what}: written by optimiser {wrote!r}, but this engine was built with {opt.kind!r} for that network")
         for t in opt.buffers():
             t.zero_()
         steps = {int(st["step"]) for st in state.values()}
@@ -577,8 +588,10 @@ class ArdaeEngine:
         self.model.load_state_dict(model_ckpt["state_dict"])
         self.cdae.load_state_dict(cdae_ckpt["state_dict"])
         eng = model_ckpt.get("engine")
-        m_steps = self._load_opt_state(self.model, self.opt_m, model_ckpt["optimizer"]["state"], "model checkpoint")
-        c_steps = self._load_opt_state(self.cdae, self.opt_c, cdae_ckpt["optimizer"]["state"], "cdae checkpoint")
+        m_steps = self._load_opt_state(self.model, self.opt_m, model_ckpt["optimizer"]["state"], "model checkpoint",
+                                       model_ckpt["optimizer"].get("param_groups"))
+        c_steps = self._load_opt_state(self.cdae, self.opt_c, cdae_ckpt["optimizer"]["state"], "cdae checkpoint",
+                                       cdae_ckpt["optimizer"].get("param_groups"))
         # optimisers without per-parameter state (SGD) carry no step count: the engine's own record, if the file has one
         self.step_count = m_steps if (m_steps or eng is None) else int(eng["step_count"])
         self.opt_m.steps = self.step_count

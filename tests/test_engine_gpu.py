@@ -813,11 +813,10 @@ def test_checkpoint_roundtrip_other_optimizers(tmp_path, m_opt, d_opt):
     assert eng_b.step_count == 4 and eng_b.opt_c.steps == 8
     eng_b.step(xs[8], xs[9])
     assert torch.equal(model_b.flat_params(), want_m) and torch.equal(cdae_b.flat_params(), want_c)
-    # a checkpoint of another optimiser is refused, not silently reinterpreted
-    if m_opt != "sgd":
-        other = net.ArdaeEngine(*build_cuda(mc, cc), net.TrainConfig(nz_cdae=16, m_optimizer="rmsprop" if m_opt != "rmsprop" else "adam", d_optimizer=d_opt), batch_size=B)
-        with pytest.raises(ValueError):
-            other.load_checkpoints(mck2, cck2)
+    # a checkpoint of another optimiser is refused, not silently reinterpreted (SGD's empty state included: param_groups tell)
+    other = net.ArdaeEngine(*build_cuda(mc, cc), net.TrainConfig(nz_cdae=16, m_optimizer="rmsprop" if m_opt != "rmsprop" else "adam", d_optimizer=d_opt), batch_size=B)
+    with pytest.raises(ValueError):
+        other.load_checkpoints(mck2, cck2)
 
 
 def build_cuda(mc, cc):
