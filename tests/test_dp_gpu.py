@@ -79,14 +79,14 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def _steps(per_rank_batch, lo, hi, graph, nsteps=5):
+def _steps(per_rank_batch, lo, hi, graph, nsteps=5, **cfg):
     """nsteps full train steps (own Philox noise, fresh images per step) on images [lo, hi) of each global batch; returns the
     flat parameters and whether the engine ended up replaying captured graphs."""
     import ardae_amd as net
     dev = torch.device("cuda", 0)
     model, cdae = _build(dev)
     net.manual_seed(99)
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=per_rank_batch, graph=graph)
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ, **cfg), batch_size=per_rank_batch, graph=graph)
     g = torch.Generator().manual_seed(21)
     for _ in range(nsteps):
         x1 = torch.bernoulli(torch.full((B, MC.input_dim), 0.3), generator=g)
@@ -130,6 +130,35 @@ def test_two_rank_segmented_graph_replay_equals_eager(tmp_path):
         err = (upd - want).abs() / (want.abs() + 1e-12)
         assert float(err.median()) < 1e-2, name
         assert float((upd - want).norm() / want.norm()) < 0.1, name
+
+
+TWO_UPDATES = dict(num_cdae_updates=2, m_optimizer="amsgrad", d_optimizer="adam", d_beta1=0.6)
+
+
+def _worker_steps2(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from ardae_amd import dist
+    lo, hi = dist.shard_rows(B)
+    pm_e, pc_e, _ = _steps(hi - lo, lo, hi, graph=False, **TWO_UPDATES)
+    pm_g, pc_g, g_g = _steps(hi - lo, lo, hi, graph=True, **TWO_UPDATES)
+    if rank == 0:
+        torch.save({"pm_eager": pm_e, "pc_eager": pc_e, "pm_graph": pm_g, "pc_graph": pc_g,
+                    "segments": [("allreduce" if torch.is_tensor(i) else "graph") for i in g_g] if isinstance(g_g, list) else None}, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_replay_with_two_cdae_updates_and_adam_pair(tmp_path):
+    """--num-cdae-updates 2 (the shipped residual-conv recipes) on two ranks: three gradient all-reduces per step, so the step
+    replays as FOUR graphs; with Adam on both networks each keeps its own device-resident step count (the cDAE's advances twice
+    per step).  Replayed == eager bit for bit."""
+    out = str(tmp_path / "dp_steps2.pt")
+    mp.spawn(_worker_steps2, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert got["segments"] == ["graph", "allreduce", "graph", "allreduce", "graph", "allreduce", "graph"]
+    assert torch.equal(got["pm_graph"], got["pm_eager"]) and torch.equal(got["pc_graph"], got["pc_eager"])
+    assert torch.isfinite(got["pm_graph"]).all() and torch.isfinite(got["pc_graph"]).all()
 
 
 def _free_port():
