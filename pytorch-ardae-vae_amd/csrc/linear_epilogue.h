@@ -28,8 +28,20 @@ __device__ __forceinline__ void epilogue_half(const LinArgs& a, const f32x16& ac
 #pragma unroll
     for (int r = 0; r < 8; ++r) rb[r] = 0.f, rs[r] = 0.f;
     if (a.rowbias) {
+      if (a.rows_per_group >= 32) {
+        // a 32-row block meets at most two images: ONE division per block, then a compare per row (an integer division per
+        // element - ~35 vector-ALU instructions each - cost the nz_cdae 625 recipes a quarter of this kernel's time)
+        const int blk0 = rbase & ~31;
+        const int g0 = blk0 / a.rows_per_group;
+        const int split = (g0 + 1) * a.rows_per_group;                       // first row of the next image
+        const float rbA = a.rowbias[(size_t)g0 * a.rowbias_ld + col];
+        const float rbB = (split < blk0 + 32 && split < a.M) ? a.rowbias[(size_t)(g0 + 1) * a.rowbias_ld + col] : rbA;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) rb[r] = a.rowbias[(size_t)(rowv[r] / a.rows_per_group) * a.rowbias_ld + col];
+        for (int r = 0; r < 8; ++r) rb[r] = rowv[r] < split ? rbA : rbB;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rb[r] = a.rowbias[(size_t)(rowv[r] / a.rows_per_group) * a.rowbias_ld + col];
+      }
     }
     if (a.rowscale) {
 #pragma unroll

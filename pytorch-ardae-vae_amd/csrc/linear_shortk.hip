@@ -34,9 +34,14 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void linear_shortk_ke
   const int nblk = a.Nout >> 5;
   const float* bp = a.src[0].wp + lane * 4;
   const size_t bstride = (size_t)nch * 256;          // floats per column block of the packed image
-  // the 32 rows of a wave share one image when the groups are multiples of 32 rows: one row-bias value per column
-  const bool rb_uniform = a.rowbias && (a.rows_per_group % 32) == 0;
-  const float* rbrow = a.rowbias ? a.rowbias + (size_t)(row0 / a.rows_per_group) * a.rowbias_ld : nullptr;
+  // Groups of >= 32 rows: the 32 rows of a wave belong to at most two images - rows [0, split) to the first (split >= 32: all of
+  // them), the rest to the next one: two row-bias values per column and a compare per element instead of a division per element
+  // (nz_cdae 625 of the shipped recipes: the per-element form made this kernel 3x slower than at nz_cdae 256).
+  const bool rb_two = a.rowbias && a.rows_per_group >= 32;
+  const int g0 = a.rowbias ? row0 / a.rows_per_group : 0;
+  const int split = rb_two ? (g0 + 1) * a.rows_per_group - row0 : 32;
+  const float* rbrow = a.rowbias ? a.rowbias + (size_t)g0 * a.rowbias_ld : nullptr;
+  const float* rbrow1 = (rb_two && split < 32) ? rbrow + a.rowbias_ld : rbrow;
 
   f32x4 b0[SK_MAXCH], b1[SK_MAXCH];
   auto load_b = [&](f32x4 (&b)[SK_MAXCH], int nb) {
@@ -55,15 +60,15 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void linear_shortk_ke
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][q], b[c][q], acc, 0, 0, 0);
       }
     const int col = nb * 32 + l31;
-    float pre = a.bias ? a.bias[col] : 0.f;
-    if (rb_uniform) pre += rbrow[col];
+    const float bcolv = a.bias ? a.bias[col] : 0.f;
+    const float pre = bcolv + (rb_two ? rbrow[col] : 0.f), pre1 = bcolv + (rb_two ? rbrow1[col] : 0.f);
     // stores in the scalar-base form: the row base is uniform (SALU arithmetic), the lane adds one 32-bit byte offset
     const unsigned voff = (unsigned)((4 * hh * a.ldY + l31) * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rowu = row0 + (r & 3) + 8 * (r >> 2);       // + 4 hh is in voff
-      float v = acc[r] + pre;
-      if (a.rowbias && !rb_uniform) v += a.rowbias[(size_t)((rowu + 4 * hh) / a.rows_per_group) * a.rowbias_ld + col];
+      float v = acc[r] + (((r & 3) + 8 * (r >> 2) + 4 * hh) < split ? pre : pre1);
+      if (a.rowbias && !rb_two) v += a.rowbias[(size_t)((rowu + 4 * hh) / a.rows_per_group) * a.rowbias_ld + col];
       char* sb = reinterpret_cast<char*>(a.Y + (size_t)rowu * a.ldY + nb * 32);
       *reinterpret_cast<float*>(sb + voff) = act_fwd<ACT>(v);
     }
@@ -108,8 +113,11 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_ker
   const float* bp = a.src[0].wp + lane * 4;
   const float* bp2 = wp2 + lane * 4;
   const size_t bstride = (size_t)nch * 256;
-  const bool rb_uniform = a.rowbias && (a.rows_per_group % 32) == 0;
-  const float* rbrow = a.rowbias ? a.rowbias + (size_t)(row0 / a.rows_per_group) * a.rowbias_ld : nullptr;
+  const bool rb_two = a.rowbias && a.rows_per_group >= 32;      // see linear_shortk_kernel: at most two images per wave
+  const int g0 = a.rowbias ? row0 / a.rows_per_group : 0;
+  const int split = rb_two ? (g0 + 1) * a.rows_per_group - row0 : 32;
+  const float* rbrow = a.rowbias ? a.rowbias + (size_t)g0 * a.rowbias_ld : nullptr;
+  const float* rbrow1 = (rb_two && split < 32) ? rbrow + a.rowbias_ld : rbrow;
   float* T = tile[wave];
 
   f32x16 zacc;
@@ -135,14 +143,14 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_ker
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][q], b[c][q], acc, 0, 0, 0);
       }
     const int col = nb * 32 + l31;
-    float pre = a.bias ? a.bias[col] : 0.f;
-    if (rb_uniform) pre += rbrow[col];
+    const float bcolv = a.bias ? a.bias[col] : 0.f;
+    const float pre = bcolv + (rb_two ? rbrow[col] : 0.f), pre1 = bcolv + (rb_two ? rbrow1[col] : 0.f);
     // hidden block: accumulator layout (lane = column, registers = rows) -> tile[row][column]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      float v = acc[r] + pre;
-      if (a.rowbias && !rb_uniform) v += a.rowbias[(size_t)((row0 + rl) / a.rows_per_group) * a.rowbias_ld + col];
+      float v = acc[r] + (rl < split ? pre : pre1);
+      if (a.rowbias && !rb_two) v += a.rowbias[(size_t)((row0 + rl) / a.rows_per_group) * a.rowbias_ld + col];
       T[rl * ST_LD + l31] = act_fwd<ACT>(v);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

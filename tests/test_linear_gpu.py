@@ -345,3 +345,18 @@ def test_linear_dact_chain_more_activations(M, act):
     run_linear(L.EPI_CHAIN, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], S=S.cuda(), R=R.cuda(), Y=Y, Y2=Y2)
     assert relerr(Y, v * s) < 5e-5
     assert relerr(Y2, v * R.double() * ratio) < 5e-5
+
+
+@pytest.mark.parametrize("M,K,Nout,rpg", [(80000, 100, 256, 625),      # short-K kernel, groups of 625 rows (the shipped recipes' nz_cdae)
+                                          (4000, 64, 96, 40), (4096, 256, 256, 100), (8192, 512, 512, 625), (640, 256, 64, 33), (300, 37, 40, 7)])
+def test_linear_rowbias_groups_not_tile_aligned(M, K, Nout, rpg):
+    """Per-image row bias with groups that are no multiple of the 32-row blocks / 64-row tiles: a block meets two images (one division
+    per block + a compare per row for groups of >= 32 rows, the per-element form below that)."""
+    g = torch.Generator().manual_seed(M + K + rpg)
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5; b = torch.randn(Nout, generator=g)
+    ngroups = (M + rpg - 1) // rpg
+    rb = torch.randn(ngroups, Nout, generator=g) * 2
+    pre = X.double() @ W.double().T + b.double() + rb.double().repeat_interleave(rpg, 0)[:M]
+    Y = torch.full((M, Nout), float("nan"), device="cuda")
+    run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT["softplus"], bias=b.cuda(), rowbias=rb.cuda(), rows_per_group=rpg, Y=Y)
+    assert relerr(Y, torch.nn.functional.softplus(pre)) < 2e-5
