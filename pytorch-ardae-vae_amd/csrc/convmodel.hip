@@ -580,8 +580,9 @@ size_t aux_workspace(const AuxConvLayout& P, int B, int nz, int mode) {
   return t;
 }
 
+// keep_hidden = false (forward-only encodes of the cDAE phase): the [R, 800] hidden rows need not exist
 int aux_sampler_fwd(const AuxConvLayout& P, const AuxConvPacked& K, const float* params, const float* packed, const float* x, const float* noise,
-                    int B, int nz, AuxConvWs& W, hipStream_t st) {
+                    int B, int nz, AuxConvWs& W, bool keep_hidden, hipStream_t st) {
   const int R = B * nz, act = P.act, ldn = P.nd + P.zd;
   ARDAE_TRY(launch_affine(x, (int64_t)B * 784, 2.f, -1.f, W.D.x2, st));
   ARDAE_TRY(trunk_fwd(P.aconv, K.aconv_f, params, packed, W.D.x2, W.acols, W.ahcv, W.ainp, B, act, st));
@@ -595,6 +596,14 @@ int aux_sampler_fwd(const AuxConvLayout& P, const AuxConvPacked& K, const float*
   ARDAE_TRY(trunk_fwd(P.econv, K.econv_f, params, packed, W.D.x2, W.ecols, W.ehcv, W.einp, B, act, st));
   { LinArgs A{}; A.bias = params + P.efc.b; A.Y = W.rb; A.ldY = 800;               // image half of the encoder's fc, once per image
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, 800, W.einp, 512, 512, packed + K.efci_f, A, st)); }
+  if (!keep_hidden) {    // z0 -> 800 -> (mean | logvar) in one launch, hidden rows on chip (linear_shortk.hip::sampler_tail_kernel)
+    LinArgs A{}; A.M = R; A.Nout = 800; A.act = act; A.nsrc = 1; A.rowbias = W.rb; A.rowbias_ld = 800; A.rows_per_group = nz;
+    A.src[0].x = W.z0; A.src[0].ld = P.nd; A.src[0].K = P.nd; A.src[0].wp = packed + K.efcn_f;
+    if (sampler_tail_eligible(A, P.zd)) {
+      ARDAE_TRY(launch_sampler_tail(A, packed + K.mean_f, params + P.mean.b, W.mu, P.zd, P.zd, st, packed + K.logvar_f, params + P.logvar.b, W.lv, P.zd));
+      return launch_reparam_fwd(W.mu, W.lv, noise + P.nd, ldn, R, P.zd, 1, W.D.z, st);
+    }
+  }
   { LinArgs A{}; A.rowbias = W.rb; A.rowbias_ld = 800; A.rows_per_group = nz; A.Y = W.D.t1; A.ldY = 800;
     ARDAE_TRY(lin1(EPI_ACT, act, R, 800, W.z0, P.nd, P.nd, packed + K.efcn_f, A, st)); }
   { LinArgs A{}; A.bias = params + P.mean.b; A.Y = W.mu; A.ldY = P.zd;
@@ -648,7 +657,7 @@ int auxconv_model_encode(const ardae_model_desc& d, const float* params, const f
     ARDAE_HIP(hipMemsetAsync(W.zero, 0, (size_t)B * nz * (P.nd + P.zd) * sizeof(float), st));
     nptr = W.zero;
   }
-  ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, nptr, B, nz, W, st));
+  ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, nptr, B, nz, W, hidden_out != nullptr, st));
   if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.D.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (hidden_out) {
     ARDAE_CHECK_ARG(nz == 1, "auxconv_model_encode: the hidden context is defined for nz == 1");
@@ -680,7 +689,7 @@ int auxconv_model_vae_forward(const ardae_model_desc& d, const float* params, co
   aux_carve(P, ws, B, nz, 1, W);
   ARDAE_CHECK_ARG(ws.ok, "auxconv_model_vae_forward: workspace too small");
   const int R = B * nz;
-  ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, noise, B, nz, W, st));
+  ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, noise, B, nz, W, true, st));
   ARDAE_HIP(hipMemcpyAsync(z_out, W.D.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
   ARDAE_TRY(conv_decode_fwd(P.dec, K.dec, params, packed, W.D.z, R, W.D, st));
   ARDAE_TRY(launch_vae_loss(0, W.D.logit, nullptr, x, W.D.z, R, nz, 784, P.zd, beta, 0, 0.f, nullptr, W.D.rec_row, W.D.pri_row, nullptr, nullptr, nullptr, st));

@@ -44,7 +44,8 @@ bool linear_shortk_eligible(const LinArgs& a, int epi);
 int launch_linear_shortk(const LinArgs& a, int epi, hipStream_t st);
 // that layer fused with the latent-space layer behind it (N2 <= 32 columns): the hidden rows never reach memory
 bool sampler_tail_eligible(const LinArgs& first, int n2);
-int launch_sampler_tail(const LinArgs& first, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st);
+int launch_sampler_tail(const LinArgs& first, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st,
+                        const float* wp2b = nullptr, const float* bias2b = nullptr, float* Zb = nullptr, int ldzb = 0);   // second head (mean | logvar)
 // software-pipelined 64 x 256 kernel (linear_wide.hip): full tiles, K % 32 == 0
 bool linear_wide_eligible(const LinArgs& a, int epi);
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);

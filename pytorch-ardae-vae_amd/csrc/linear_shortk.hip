@@ -93,9 +93,12 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void linear_shortk_ke
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int ST_LD = 36;   // floats per row of the transpose tile (16-byte aligned rows, 4-bank skew)
 
-template <int ACT, int SK_MAXCH>
-__global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_kernel(const LinArgs a, const float* __restrict__ wp2,
-                                                                                     const float* __restrict__ bias2, float* __restrict__ Z, int ldz, int n2) {
+// NOUT2 = 2: two heads of <= 32 columns each behind the same hidden layer (mean | logvar of the hierarchical conv sampler,
+// ivae/auxconv.py) - the second set of accumulators and weight fragments takes the kernel to one workgroup per CU.
+struct TailOut { const float* wp; const float* bias; float* Z; int ldz; };
+
+template <int ACT, int SK_MAXCH, int NOUT2>
+__global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void sampler_tail_kernel(const LinArgs a, const TailOut o0, const TailOut o1, int n2) {
   __shared__ float tile[4][32 * ST_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_ker
     if (c < nch && 8 * c + 4 * hh + 4 <= K) av[c] = *reinterpret_cast<const f32x4*>(xr + 8 * c);
   }
   const float* bp = a.src[0].wp + lane * 4;
-  const float* bp2 = wp2 + lane * 4;
+  const float* bp2[2] = {o0.wp + lane * 4, (NOUT2 > 1 ? o1.wp : o0.wp) + lane * 4};
   const size_t bstride = (size_t)nch * 256;
   const bool rb_two = a.rowbias && a.rows_per_group >= 32;      // see linear_shortk_kernel: at most two images per wave
   const int g0 = a.rowbias ? row0 / a.rows_per_group : 0;
@@ -120,9 +123,11 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_ker
   const float* rbrow1 = (rb_two && split < 32) ? rbrow + a.rowbias_ld : rbrow;
   float* T = tile[wave];
 
-  f32x16 zacc;
+  f32x16 zacc[NOUT2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) zacc[r] = 0.f;
+  for (int o = 0; o < NOUT2; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zacc[o][r] = 0.f;
   f32x4 b0[SK_MAXCH], b1[SK_MAXCH];
   auto load_b = [&](f32x4 (&b)[SK_MAXCH], int nb) {
 #pragma unroll
@@ -130,9 +135,11 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_ker
       if (c < nch) b[c] = *reinterpret_cast<const f32x4*>(bp + (size_t)nb * bstride + (size_t)c * 256);
   };
   auto block = [&](const f32x4 (&b)[SK_MAXCH], int nb) {
-    f32x4 w2[4];
+    f32x4 w2[NOUT2][4];
 #pragma unroll
-    for (int c2 = 0; c2 < 4; ++c2) w2[c2] = *reinterpret_cast<const f32x4*>(bp2 + (size_t)(4 * nb + c2) * 256);
+    for (int o = 0; o < NOUT2; ++o)
+#pragma unroll
+      for (int c2 = 0; c2 < 4; ++c2) w2[o][c2] = *reinterpret_cast<const f32x4*>(bp2[o] + (size_t)(4 * nb + c2) * 256);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -161,7 +168,9 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_ker
     for (int c2 = 0; c2 < 4; ++c2) {
       const f32x4 ha = *reinterpret_cast<const f32x4*>(T + l31 * ST_LD + 8 * c2 + 4 * hh);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[q], w2[c2][q], zacc, 0, 0, 0);
+      for (int o = 0; o < NOUT2; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zacc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[q], w2[o][c2][q], zacc[o], 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();     // the tile is rewritten by the next block
@@ -176,35 +185,43 @@ __global__ __launch_bounds__(256, (SK_MAXCH > 13 ? 1 : 2)) void sampler_tail_ker
     block(b1, nb + 1);
   }
   if (l31 < n2) {
-    const float bz = bias2 ? bias2[l31] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rowu = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Z[(size_t)rowu * ldz + l31] = zacc[r] + bz;
+    for (int o = 0; o < NOUT2; ++o) {
+      const TailOut& out = o == 0 ? o0 : o1;
+      const float bz = out.bias ? out.bias[l31] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowu = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        out.Z[(size_t)rowu * out.ldz + l31] = zacc[o][r] + bz;
+      }
     }
   }
 }
 
-template <int ACT, int MAXCH>
-int launch_tail_ch(const LinArgs& a, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st) {
+template <int ACT, int MAXCH, int NOUT2>
+int launch_tail_ch(const LinArgs& a, const TailOut& o0, const TailOut& o1, int n2, hipStream_t st) {
   if (g_prof_enabled) {
     char name[64];
-    snprintf(name, sizeof(name), "sampler_tail_kernel<%d, %d>", ACT, MAXCH);
-    const double K = a.src[0].K;
-    prof_begin(st, name, 2.0 * a.M * ((double)a.Nout * K + (double)a.Nout * n2), 4.0 * ((double)a.M * K + (double)a.M * n2 + K * a.Nout + (double)a.Nout * n2));
+    snprintf(name, sizeof(name), "sampler_tail_kernel<%d, %d, %d>", ACT, MAXCH, NOUT2);
+    const double K = a.src[0].K, nc = (double)n2 * NOUT2;
+    prof_begin(st, name, 2.0 * a.M * ((double)a.Nout * K + (double)a.Nout * nc), 4.0 * ((double)a.M * K + (double)a.M * nc + K * a.Nout + (double)a.Nout * nc));
   }
-  hipLaunchKernelGGL((sampler_tail_kernel<ACT, MAXCH>), dim3(a.M / 128), dim3(256), 0, st, a, wp2, bias2, Z, ldz, n2);
+  hipLaunchKernelGGL((sampler_tail_kernel<ACT, MAXCH, NOUT2>), dim3(a.M / 128), dim3(256), 0, st, a, o0, o1, n2);
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
 
 template <int ACT>
-int launch_tail(const LinArgs& a, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st) {
+int launch_tail(const LinArgs& a, const TailOut& o0, const TailOut& o1, int n2, hipStream_t st) {
   const int nch = (a.src[0].K + 7) >> 3;
-  if (nch <= 8) return launch_tail_ch<ACT, 8>(a, wp2, bias2, Z, ldz, n2, st);
-  if (nch <= 13) return launch_tail_ch<ACT, 13>(a, wp2, bias2, Z, ldz, n2, st);
-  return launch_tail_ch<ACT, 16>(a, wp2, bias2, Z, ldz, n2, st);
+  if (o1.wp) {
+    if (nch <= 13) return launch_tail_ch<ACT, 13, 2>(a, o0, o1, n2, st);
+    return launch_tail_ch<ACT, 16, 2>(a, o0, o1, n2, st);
+  }
+  if (nch <= 8) return launch_tail_ch<ACT, 8, 1>(a, o0, o1, n2, st);
+  if (nch <= 13) return launch_tail_ch<ACT, 13, 1>(a, o0, o1, n2, st);
+  return launch_tail_ch<ACT, 16, 1>(a, o0, o1, n2, st);
 }
 
 template <int ACT, int MAXCH>
@@ -252,14 +269,17 @@ bool sampler_tail_eligible(const LinArgs& first, int n2) {
   if (!on || n2 < 1 || n2 > 32) return false;
   LinArgs a = first;
   if (!a.Y) a.Y = const_cast<float*>(a.src[0].x);   // the single-layer rule wants an output pointer; unused here
-  return linear_shortk_eligible(a, EPI_ACT) && (a.Nout % 64) == 0;   // blocks are walked in pairs
+  return linear_shortk_eligible(a, EPI_ACT);
 }
 
-int launch_sampler_tail(const LinArgs& first, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st) {
-  ARDAE_CHECK_ARG(sampler_tail_eligible(first, n2) && wp2 && Z && ldz >= n2, "sampler tail: shape not eligible");
-  if (first.act == ACT_RELU) return launch_tail<ACT_RELU>(first, wp2, bias2, Z, ldz, n2, st);
-  if (first.act == ACT_SOFTPLUS) return launch_tail<ACT_SOFTPLUS>(first, wp2, bias2, Z, ldz, n2, st);
-  return launch_tail<ACT_NONE>(first, wp2, bias2, Z, ldz, n2, st);
+// wp2b / bias2b / Zb: an optional second head of n2 columns behind the same hidden layer (nullptr: one head)
+int launch_sampler_tail(const LinArgs& first, const float* wp2, const float* bias2, float* Z, int ldz, int n2, hipStream_t st,
+                        const float* wp2b, const float* bias2b, float* Zb, int ldzb) {
+  ARDAE_CHECK_ARG(sampler_tail_eligible(first, n2) && wp2 && Z && ldz >= n2 && (!wp2b || (Zb && ldzb >= n2)), "sampler tail: shape not eligible");
+  const TailOut o0{wp2, bias2, Z, ldz}, o1{wp2b, bias2b, Zb, ldzb};
+  if (first.act == ACT_RELU) return launch_tail<ACT_RELU>(first, o0, o1, n2, st);
+  if (first.act == ACT_SOFTPLUS) return launch_tail<ACT_SOFTPLUS>(first, o0, o1, n2, st);
+  return launch_tail<ACT_NONE>(first, o0, o1, n2, st);
 }
 
 int launch_linear_shortk(const LinArgs& a, int epi, hipStream_t st) {

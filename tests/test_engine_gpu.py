@@ -846,3 +846,23 @@ def test_latent_perturb_nstd_kernel(B, nz, nstd, z):
                                               L.ptr(xbar), L.ptr(sigma), L.ptr(std_b), L.stream_ptr()), "ardae_latent_perturb_nstd")
     torch.cuda.synchronize()
     assert rel_l2(std_b, std.reshape(-1)) < 1e-5 and rel_l2(sigma, sigma_ref) < 1e-5 and rel_l2(xbar, xbar_ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,nz", [(128, 256), (64, 1250)])
+def test_auxconv_nrow_sampler_fused_two_head_tail_vs_oracle(B, nz):
+    """MNISTConvAuxIPVAE.forward_hidden on >= 32768 rows: z0 -> 800 -> (mean | logvar) runs as one launch with the hidden rows on chip
+    (sampler_tail_kernel with two heads; 25 column blocks - an odd count - and row-bias groups that straddle the 32-row blocks)."""
+    mc = O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus")
+    pm = O.init_params(O.model_param_spec(mc), 11, O.model_init_special(mc))
+    model, _ = build(mc, O.CdaeCfg("grad", 32, 1600, 64, 2))
+    model.load_state_dict(pm)
+    model = model.to("cuda")
+    g = torch.Generator().manual_seed(B + nz)
+    x = (torch.rand(B, 784, generator=g) < 0.2).float()
+    e0, e = torch.randn(B * nz, mc.noise_dim, generator=g), torch.randn(B * nz, mc.z_dim, generator=g)
+    z = model.forward_hidden(x.cuda(), nz=nz, noise=(e0.cuda(), e.cuda()))
+    pm64 = {k: v.double() for k, v in pm.items()}
+    ref = O.encode(mc, pm64, x.double(), (e0.double(), e.double()), nz).reshape(B * nz, -1).float()
+    assert z.shape == (B, nz, mc.z_dim)
+    assert rel_l2(z.reshape(B * nz, -1), ref) < 2e-5
+    assert float((z.reshape(B * nz, -1).cpu() - ref).abs().max()) < 1e-3
