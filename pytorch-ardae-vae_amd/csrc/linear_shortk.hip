@@ -249,13 +249,14 @@ int launch_shortk(const LinArgs& a, hipStream_t st) {
 }  // namespace
 
 // One source, K <= 128 and a multiple of 4 but NOT one of the panelled kernels' shapes, whole 128-row tiles and 32-column
-// blocks, enough rows to fill the chip; forward epilogue (bias, per-image row bias, activation) only.  ARDAE_SHORTK=0: off.
+// blocks, >= 8192 rows (64 workgroups: from there on it beats the generic kernel - at the 64-image shard of the 8-GPU run, 16384
+// rows, the fused sampler is 1.7 % of the step); forward epilogue (bias, per-image row bias, activation) only.  ARDAE_SHORTK=0: off.
 bool linear_shortk_eligible(const LinArgs& a, int epi) {
   static const bool on = !(getenv("ARDAE_SHORTK") && atoi(getenv("ARDAE_SHORTK")) == 0);
   if (!on || epi != EPI_ACT || a.nsrc != 1) return false;
   const int K = a.src[0].K;
   if (K <= 0 || K > SK_MAXK || (K & 3) || K % 32 == 0) return false;
-  if (a.M < 128 * 256 || (a.M % 128) || a.Nout <= 0 || (a.Nout % 32)) return false;
+  if (a.M < 128 * 64 || (a.M % 128) || a.Nout <= 0 || (a.Nout % 32)) return false;
   if ((a.src[0].ld & 3) || (reinterpret_cast<uintptr_t>(a.src[0].x) & 15)) return false;
   if (a.rowscale || a.Y2 || a.colsum || !a.Y) return false;
   if (a.rowbias && a.rows_per_group <= 0) return false;
