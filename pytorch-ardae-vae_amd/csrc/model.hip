@@ -245,6 +245,8 @@ int encode_stack(const ModelLayout& P, const ModelPacked& K, const float* params
 int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, const float* packed, const float* x,
                const float* noise, int B, int nz, ModelWs& W, float* z_out, bool keep_hidden, hipStream_t st) {
   ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
+  if (z_out && !keep_hidden)     // forward-only: the last layer writes the caller's buffer itself (one launch less per encode)
+    return encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, false, st);
   ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, W.z, keep_hidden, st));
   if (z_out) {
     ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -511,6 +511,16 @@ class ArdaeEngine:
         self._step_body(xs, x_vae, noise, beta)
         self._count_step(len(xs))
 
+    def input_buffers(self, n_cdae=None):
+        """The engine's static batch buffers ([B, input_dim] each: one per cDAE update, and the VAE batch's): a producer that
+        already works on the device (dynamic binarisation, a gather from a resident table) writes the next batches THERE and
+        passes the same tensors to step(), which then has nothing to copy."""
+        n = self.cfg.num_cdae_updates if n_cdae is None else int(n_cdae)
+        if self._xc is None or len(self._xc) != n:
+            flat = lambda: torch.empty(self.B, self.model.input_dim, device=self.dev, dtype=torch.float32)
+            self._xc, self._xv, self._graph = [flat() for _ in range(n)], flat(), None
+        return list(self._xc), self._xv
+
     def _count_step(self, n_cdae_updates):
         self.step_count += 1
         self.opt_m.steps = self.step_count

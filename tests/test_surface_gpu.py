@@ -232,3 +232,38 @@ def test_static_binarized_source():
         np.savetxt(os.path.join(d, "binarized_mnist_train.amat"), rows, fmt="%d")
         s2 = net.data.StaticBinarizedSource.from_amat(os.path.join(d, "binarized_mnist_train.amat"), device="cuda")
         assert torch.equal(s2.table.cpu(), torch.tensor(rows))
+
+
+def test_engine_input_buffers_zero_copy():
+    """`input_buffers()` hands out the engine's static batch buffers; a step fed through them equals a step fed with separate tensors
+    (eager steps and replayed ones)."""
+    mc, cc = O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 8, 64, 3)
+    B = 8
+
+    def run(use_buffers):
+        torch.manual_seed(0)
+        model = net.MNISTIPVAE(input_dim=24, noise_dim=10, h_dim=64, num_hidden_layers=2, nonlinearity="softplus", enc_type="concat", z_dim=8)
+        cdae = net.MLPGradCARDAE(input_dim=8, context_dim=8, std=1., h_dim=64, num_hidden_layers=3, nonlinearity="softplus",
+                                 noise_type="gaussian", enc_ctx=True, enc_input=True)
+        model.load_state_dict(O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc)))
+        cdae.load_state_dict(O.init_params(O.cdae_param_spec(cc), 1))
+        model, cdae = model.cuda(), cdae.cuda()
+        net.manual_seed(5)
+        eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=16), batch_size=B)
+        g = torch.Generator().manual_seed(2)
+        if use_buffers:
+            (xc,), xv = eng.input_buffers()
+            assert xc.shape == (B, 24) and xv.shape == (B, 24)
+        for _ in range(5):
+            a, b = torch.bernoulli(torch.full((B, 24), 0.3), generator=g).cuda(), torch.bernoulli(torch.full((B, 24), 0.3), generator=g).cuda()
+            if use_buffers:
+                xc.copy_(a); xv.copy_(b)
+                eng.step(xc, xv)
+            else:
+                eng.step(a, b)
+        torch.cuda.synchronize()
+        return model.flat_params().clone(), cdae.flat_params().clone()
+
+    m0, c0 = run(False)
+    m1, c1 = run(True)
+    assert torch.equal(m0, m1) and torch.equal(c0, c1)
