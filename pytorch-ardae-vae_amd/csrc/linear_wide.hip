@@ -74,7 +74,12 @@ bool linear_wide_eligible(const LinArgs& a, int epi) {
   if (a.act != ACT_NONE && a.act != ACT_RELU && a.act != ACT_SOFTPLUS) return false;
   if (epi == EPI_CHAIN && a.act != ACT_SOFTPLUS) return false;
   if (256 % (a.Nout / wgcols)) return false;   // a workgroup keeps its column panel
-  if (epi == EPI_ACT && a.rowbias && (a.rows_per_group <= 0 || a.rows_per_group % WBM)) return false;   // group must be tile-uniform
+  if (epi == EPI_ACT && a.rowbias) {
+    // a tile must not meet two images: groups that are multiples of the tile height, or whole groups of >= one tile laid out as
+    // "group tiles" (the kernel's tpg mode; per-tile column sums would count the doubly computed rows twice, so not with colsum)
+    if (a.rows_per_group <= 0) return false;
+    if (a.rows_per_group % WBM && (a.rows_per_group < WBM || a.M % a.rows_per_group || a.colsum)) return false;
+  }
   if (epi == EPI_ACT && a.rowscale && !a.rowscale_w) return false;
   // 32-bit per-lane byte offsets in the epilogue
   const int64_t ldmax = std::max<int64_t>({a.ldY, a.ldY2, a.ldS, a.ldR, a.ldQ});

@@ -524,7 +524,10 @@ __device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (
 // NP = K panels per tile (compile time: the tile body is one basic block).  grid % ncp == 0, so a workgroup keeps its
 // column panel: the weight slab and the column-only epilogue operands are loaded once.
 template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
-__global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, int nrt, int ncp) {
+// tpg > 0 ("group tiles"): the per-image row-bias groups are no multiple of the 64-row tile (nz_cdae 625 of the shipped recipes).  Tiles are
+// then laid out per group - tpg = ceil(rows_per_group / 64) of them, the last one shifted back so that it ENDS with its group - so that no
+// tile meets two images; the rows two tiles of a group share are computed (identically) and written twice, +2.4 % work at 625 rows.
+__global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, int nrt, int ncp, int tpg) {
   using PG = PanelGeo<NCH>;
   using EPI_T = WideEpi<EPI, ACT, F1, F2, NJ>;
   using SC = Sched<NCH, NP, NJ, EPI_T::NLT, EPI_T::NST, true>;
@@ -561,7 +564,13 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   const i32x4 rX = make_rsrc(a.src[0].x, (unsigned)a.M * ldx4);
   const unsigned xvoff = (unsigned)(tid / PG::C4) * ldx4 + (unsigned)(tid % PG::C4) * 16u;
   const unsigned xstep = (unsigned)PG::RPP * ldx4;
-  auto panel_x = [&](int rt, int p) -> unsigned { return (unsigned)(rt * WBM) * ldx4 + (unsigned)(p * 8 * NCH) * 4u; };
+  auto tile_row0 = [&](int rt) -> int {
+    if (tpg == 0) return rt * WBM;
+    const int g = rt / tpg, j = rt - g * tpg;
+    const int r = j * WBM, last = a.rows_per_group - WBM;
+    return __builtin_amdgcn_readfirstlane(g * a.rows_per_group + (r < last ? r : last));
+  };
+  auto panel_x = [&](int rt, int p) -> unsigned { return (unsigned)tile_row0(rt) * ldx4 + (unsigned)(p * 8 * NCH) * 4u; };
 
   f32x4 A[2][2], Bw[G][NJ], xv[NX];
   f32x2 l0[16 * NJ], l1[16 * NJ];
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
     const unsigned long long T0 = __builtin_amdgcn_s_memtime();
 #endif
     const int tr = tile;
-    const int row0 = tr * WBM;
+    const int row0 = tile_row0(tr);
     const int tnext = tile + rts < nrt ? tile + rts : tile;   // none: re-touch this tile (never used)
     f32x16 acc[2][NJ];
     tile_panels<0, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
@@ -647,7 +656,10 @@ int wide_grid(int ntiles, int ncp);
 template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
 int launch_wide(const LinArgs& a, hipStream_t st) {
   const int ncp = a.Nout / (128 * NJ);
-  const int ntiles = (a.M / WBM) * ncp;
+  // row-bias groups that are no multiple of the tile height: tiles per group (see the kernel); linear_wide_eligible admitted the shape
+  const int tpg = (EPI == EPI_ACT && a.rowbias && a.rows_per_group % WBM) ? (a.rows_per_group + WBM - 1) / WBM : 0;
+  const int nrt = tpg ? (a.M / a.rows_per_group) * tpg : a.M / WBM;
+  const int ntiles = nrt * ncp;
   const int grid = wide_grid(ntiles, ncp);
   if (g_prof_enabled) {
     char name[96];
@@ -659,7 +671,7 @@ int launch_wide(const LinArgs& a, hipStream_t st) {
                      ((EPI == EPI_DACT && a.Q) ? 1 : 0);
     prof_begin(st, name, 2.0 * a.M * (double)a.Nout * ksum, 4.0 * ((double)a.M * ksum + tensors * a.M * (double)a.Nout + ksum * a.Nout));
   }
-  hipLaunchKernelGGL((linear_wide_kernel<NCH, NP, NJ, EPI, ACT, F1, F2>), dim3(grid), dim3(256), 0, st, a, a.M / WBM, ncp);
+  hipLaunchKernelGGL((linear_wide_kernel<NCH, NP, NJ, EPI, ACT, F1, F2>), dim3(grid), dim3(256), 0, st, a, nrt, ncp, tpg);
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;

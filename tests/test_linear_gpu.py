@@ -348,6 +348,7 @@ def test_linear_dact_chain_more_activations(M, act):
 
 
 @pytest.mark.parametrize("M,K,Nout,rpg", [(80000, 100, 256, 625),      # short-K kernel, groups of 625 rows (the shipped recipes' nz_cdae)
+                                          (80000, 256, 256, 625), (40000, 512, 512, 625), (16000, 256, 256, 125),   # N-row kernel, "group tiles"
                                           (4000, 64, 96, 40), (4096, 256, 256, 100), (8192, 512, 512, 625), (640, 256, 64, 33), (300, 37, 40, 7)])
 def test_linear_rowbias_groups_not_tile_aligned(M, K, Nout, rpg):
     """Per-image row bias with groups that are no multiple of the 32-row blocks / 64-row tiles: a block meets two images (one division
