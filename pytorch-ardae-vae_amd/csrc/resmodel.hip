@@ -34,15 +34,18 @@ size_t al64(size_t n) { return (n + 63) & ~size_t(63); }
 // all operators of a model in ONE launch (a re-pack follows every optimiser step: ~50 launches of a few us each otherwise):
 // grid (max O, items); item = one weight-normalised operator, or (dir == nullptr) a bias sum  out[i] = a[i] + b[i]
 constexpr int WNC_MAX = 64;
-struct WnComposeItem { const float* dir; const float* scale; float* weff; float* inv; int O, I, norm; };
+struct WnComposeItem {
+  const float* dir; const float* scale; float* weff; float* inv; int O, I, norm;   // operator: weff [O, I], inv [O]
+  const float* add_a; const float* add_b;                                         // bias sum (dir == nullptr): weff[i] = add_a[i] + add_b[i], O entries
+};
 struct WnComposeBatch { int n; WnComposeItem it[WNC_MAX]; };
 __global__ __launch_bounds__(256) void wn_compose_batch_kernel(const WnComposeBatch b) {
   __shared__ float red[256];
   const WnComposeItem& w = b.it[blockIdx.y];
   const int o = blockIdx.x, t = threadIdx.x;
-  if (w.dir == nullptr) {       // bias sum: scale = a, inv = b (inputs), weff = out, O entries
+  if (w.dir == nullptr) {       // bias sum
     const int i = o * 256 + t;
-    if (i < w.O) w.weff[i] = w.scale[i] + w.inv[i];
+    if (i < w.O) w.weff[i] = w.add_a[i] + w.add_b[i];
     return;
   }
   if (o >= w.O) return;
@@ -675,15 +678,15 @@ int res_model_pack(const ardae_model_desc& d, const float* params, float* packed
   std::vector<PackItem> items;
   std::vector<WnComposeItem> comp;
   auto wn = [&](const WN& w, const WNPk& k) -> int {
-    comp.push_back(WnComposeItem{params + w.dir, params + w.scale, packed + k.weff, packed + k.inv, w.O, w.I, w.norm ? 1 : 0});
+    comp.push_back(WnComposeItem{params + w.dir, params + w.scale, packed + k.weff, packed + k.inv, w.O, w.I, w.norm ? 1 : 0, nullptr, nullptr});
     items.push_back(PackItem{packed + k.weff, w.I, w.O, w.I, 0, packed + k.f});
     items.push_back(PackItem{packed + k.weff, w.I, w.I, w.O, 1, packed + k.b});
     return 0;
   };
   auto blk = [&](const Blk& b, const BlkPk& k, int split) -> int {
     ARDAE_TRY(wn(b.a, k.a)); ARDAE_TRY(wn(b.h, k.h)); ARDAE_TRY(wn(b.s, k.s));
-    // bsum = b_h + b_s rides in the same launch (dir == nullptr: scale / inv are the two inputs; the inputs are never written)
-    comp.push_back(WnComposeItem{nullptr, params + b.h.bias, packed + k.bsum, const_cast<float*>(params + b.s.bias), b.Cout, 0, 0});
+    // bsum = b_h + b_s rides in the same launch
+    comp.push_back(WnComposeItem{nullptr, nullptr, packed + k.bsum, nullptr, b.Cout, 0, 0, params + b.h.bias, params + b.s.bias});
     if (split) {
       const int nn = b.a.I - split;
       items.push_back(PackItem{packed + k.a.weff, b.a.I, b.a.O, split, 0, packed + k.a_fi});
