@@ -43,7 +43,7 @@ def _inputs():
     return x1, x2, noise
 
 
-def _grads(x1, x2, noise, per_rank_batch):
+def _grads(x1, x2, noise, per_rank_batch, **cfg):
     """cDAE-phase and VAE-phase gradients (all-reduced inside the engine when a process group is up), no parameter update.
     noise=None: the engine's own Philox stream - every rank generates ITS ROWS of the global draws, so the result must not
     depend on the number of ranks either."""
@@ -51,7 +51,7 @@ def _grads(x1, x2, noise, per_rank_batch):
     dev = torch.device("cuda", 0)
     model, cdae = _build(dev)
     net.manual_seed(99)
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=per_rank_batch)
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ, **cfg), batch_size=per_rank_batch)
     nz = None if noise is None else {k: v.to(dev).contiguous() for k, v in noise.items()}
     eng.cdae_phase(x1.to(dev), nz, apply_update=False)
     eng.vae_phase(x2.to(dev), nz, apply_update=False)
@@ -130,6 +130,34 @@ def test_two_rank_segmented_graph_replay_equals_eager(tmp_path):
         err = (upd - want).abs() / (want.abs() + 1e-12)
         assert float(err.median()) < 1e-2, name
         assert float((upd - want).norm() / want.norm()) < 0.1, name
+
+
+def _worker_nstd(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from ardae_amd import dist
+    x1, x2, _ = _inputs()
+    lo, hi = dist.shard_rows(B)
+    gc, gm, loss = _grads(x1[lo:hi], x2[lo:hi], None, hi - lo, nstd_cdae=3)
+    lt = loss.clone()
+    torch.distributed.all_reduce(lt)
+    if rank == 0:
+        torch.save({"gc": gc, "gm": gm, "loss": lt / world}, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_with_nstd(tmp_path):
+    """--train-nstd-cdae 3 under data parallelism: every rank draws ITS rows of the (B nz nstd)-row global sigma / eps draws, so two
+    ranks on half batches reproduce the single-process gradients."""
+    out = str(tmp_path / "dp_nstd.pt")
+    mp.spawn(_worker_nstd, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    x1, x2, _ = _inputs()
+    gc, gm, loss = _grads(x1, x2, None, B, nstd_cdae=3)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert abs(float(got["loss"]) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert rel(got["gc"], gc) < 5e-4 and rel(got["gm"], gm) < 5e-4
 
 
 TWO_UPDATES = dict(num_cdae_updates=2, m_optimizer="amsgrad", d_optimizer="adam", d_beta1=0.6)
