@@ -5,6 +5,7 @@
 set -e
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+rm -rf $OUT      # rocprofv3 names its files by pid: leftovers of an earlier run under the same tag would be summarised instead
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export ARDAE_GRAPH=0   # individual launches: the kernel trace and the counters are per kernel either way

@@ -24,8 +24,8 @@ def short(name):
 
 
 def find(d, pat):
-    fs = glob.glob(os.path.join(d, "**", pat), recursive=True)
-    return fs[0] if fs else None
+    fs = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)
+    return fs[-1] if fs else None      # the newest one: gpurun merges into an existing directory, older runs' files stay there
 
 
 def main(src, dst_prefix):
