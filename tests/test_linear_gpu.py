@@ -361,3 +361,21 @@ def test_linear_rowbias_groups_not_tile_aligned(M, K, Nout, rpg):
     Y = torch.full((M, Nout), float("nan"), device="cuda")
     run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT["softplus"], bias=b.cuda(), rowbias=rb.cuda(), rows_per_group=rpg, Y=Y)
     assert relerr(Y, torch.nn.functional.softplus(pre)) < 2e-5
+
+
+@pytest.mark.parametrize("M,K,Nout,rpg", [(80000, 256, 256, 625), (80000, 100, 256, 625), (65536, 256, 256, 256)])
+def test_nrow_kernels_are_deterministic(M, K, Nout, rpg):
+    """Same inputs, five launches, bit-identical outputs: the group-tile mode writes the rows two tiles of an image share twice (from two
+    workgroups, identical values), the short-K kernel selects between two row-bias values per row - neither may depend on timing."""
+    g = torch.Generator().manual_seed(K + rpg)
+    X = torch.randn(M, K, generator=g).cuda(); W = (torch.randn(Nout, K, generator=g) / K ** 0.5).cuda(); b = torch.randn(Nout, generator=g).cuda()
+    rb = (torch.randn((M + rpg - 1) // rpg, Nout, generator=g) * 2).cuda()
+    wp = pack(W)
+    outs = []
+    for _ in range(5):
+        Y = torch.full((M, Nout), float("nan"), device="cuda")
+        run_linear(L.EPI_ACT, M, Nout, [(X, wp)], act=L.ACT["softplus"], bias=b, rowbias=rb, rows_per_group=rpg, Y=Y)
+        outs.append(Y)
+    assert not torch.isnan(outs[0]).any()
+    for Y in outs[1:]:
+        assert torch.equal(Y, outs[0])
