@@ -298,6 +298,9 @@ typedef struct ardae_profile_entry {
   double bytes;    /* algorithmic HBM bytes of those launches (operands read once + results written once)     */
 } ardae_profile_entry;
 int ardae_profile_enable(int on);
+/* Diagnostics: a one-thread kernel that writes the device's constant 100 MHz clock (s_memrealtime) to slots[slot] when the stream
+ * reaches it - an unprofiled timeline of a step (also inside captured graphs; tools / scratch use it, the product does not). */
+int ardae_debug_stamp(unsigned long long* slots, int slot, void* stream);
 /* synchronises, aggregates by kernel, clears the log; returns the number of distinct kernels */
 int ardae_profile_report(ardae_profile_entry* entries, int max_entries);
 

@@ -12,6 +12,14 @@ LIB_PATH = os.environ.get("ARDAE_LIB") or os.path.join(_HERE, "libardae_hip.so")
 c_float_p = ctypes.POINTER(ctypes.c_float)
 
 
+def debug_knob(name, default=None):
+    """Test / experiment switches (ARDAE_GRAPH, ARDAE_OVERLAP, ... and the kernel-selection switches of the library) are honoured
+    only together with ARDAE_DEBUG_KNOBS=1: a stray ARDAE_* variable cannot change what a production process runs."""
+    if os.environ.get("ARDAE_DEBUG_KNOBS") != "1":
+        return default
+    return os.environ.get(name, default)
+
+
 class LinSrc(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("ld", ctypes.c_int), ("K", ctypes.c_int), ("wp", ctypes.c_void_p)]
 
@@ -144,6 +152,7 @@ EXPORTS = {
                                           ctypes.c_int, ctypes.c_void_p]),
     "ardae_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "ardae_debug_stamp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "ardae_profile_report": (ctypes.c_int, [ctypes.POINTER(ProfileEntry), ctypes.c_int]),
     "ardae_cdae_score": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 2),

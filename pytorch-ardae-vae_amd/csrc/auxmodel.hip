@@ -227,7 +227,7 @@ int sampler_fwd(const AuxLayout& P, const AuxPacked& K, const float* params, con
 const float* noise_or_zero(const AuxLayout& P, const float* noise, int R, AuxWs& W, hipStream_t st, int& rc) {
   rc = 0;
   if (noise) return noise;
-  if (hipMemsetAsync(W.zero, 0, (size_t)R * (P.nd + P.zd) * sizeof(float), st) != hipSuccess) rc = (int)hipErrorUnknown;
+  if (rc == 0) rc = launch_fill(W.zero, (size_t)R * (P.nd + P.zd), 0.f, st);
   return W.zero;
 }
 
@@ -274,13 +274,11 @@ int aux_model_encode(const ardae_model_desc& d, const float* params, const float
   const float* nz_ptr = noise_or_zero(P, noise, B * nz, W, st, rc);
   ARDAE_TRY(rc);
   ARDAE_TRY(sampler_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, st));
-  if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (z_out) ARDAE_TRY(launch_copy(W.z, (size_t)B * nz * P.zd, z_out, st));
   if (hidden_out) {   // forward_hidden of the ENCODER (ivae/auxmnist.py:125-132, nz == 1): cat(h0, h)
     ARDAE_CHECK_ARG(nz == 1, "aux_model_encode: the hidden context is defined for nz == 1");
-    ARDAE_HIP(hipMemcpy2DAsync(hidden_out, 2 * (size_t)P.h * sizeof(float), W.e[P.nl], (size_t)P.h * sizeof(float), (size_t)P.h * sizeof(float), B,
-                               hipMemcpyDeviceToDevice, st));
-    ARDAE_HIP(hipMemcpy2DAsync(hidden_out + P.h, 2 * (size_t)P.h * sizeof(float), W.t[P.nl], (size_t)P.h * sizeof(float), (size_t)P.h * sizeof(float),
-                               B, hipMemcpyDeviceToDevice, st));
+    ARDAE_TRY(launch_copy2d(W.e[P.nl], (size_t)P.h, hidden_out, 2 * (size_t)P.h, B, (size_t)P.h, st));
+    ARDAE_TRY(launch_copy2d(W.t[P.nl], (size_t)P.h, hidden_out + P.h, 2 * (size_t)P.h, B, (size_t)P.h, st));
   }
   return 0;
 }
@@ -312,7 +310,7 @@ int aux_model_vae_forward(const ardae_model_desc& d, const float* params, const 
   ARDAE_CHECK_ARG(ws.ok, "aux_model_vae_forward: workspace too small");
   const int R = B * nz, h = P.h;
   ARDAE_TRY(sampler_fwd(P, K, params, packed, x, noise, B, nz, W, st));
-  ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  ARDAE_TRY(launch_copy(W.z, (size_t)R * P.zd, z_out, st));
   for (int l = 1; l <= P.nl; ++l) {
     LinArgs A{}; A.bias = params + P.dec[l - 1].b; A.Y = W.dcd[l]; A.ldY = h;
     ARDAE_TRY(lin1(EPI_ACT, P.act, R, h, l == 1 ? W.z : W.dcd[l - 1], l == 1 ? P.zd : h, P.dec[l - 1].in, packed + K.dec_f[l - 1], A, st));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace ardae {
@@ -40,6 +41,13 @@ void set_last_error(const char* fmt, ...);
     int rc__ = (call);         \
     if (rc__ != 0) return rc__; \
   } while (0)
+
+// Test / experiment switches (kernel selection, launch geometry): read from the environment ONLY when ARDAE_DEBUG_KNOBS=1 is
+// set as well, so that a stray ARDAE_* variable cannot change what a production process runs.
+inline const char* debug_knob(const char* name) {
+  static const bool armed = [] { const char* e = getenv("ARDAE_DEBUG_KNOBS"); return e && e[0] == '1' && e[1] == 0; }();
+  return armed ? getenv(name) : nullptr;
+}
 
 // ----------------------------------------------------------------------------------------------
 // activations (reference: utils/models.py:14-32; F.softplus beta=1 threshold=20, F.relu)

@@ -277,7 +277,7 @@ int conv_encode_fwd(const ConvLayout& P, const ConvPacked& K, const float* param
     LinArgs A{}; A.bias = params + P.fc5.b; A.Y = W.z; A.ldY = P.zd;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.t1, 800, 800, packed + K.fc5_f, A, st));
   }
-  if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (z_out) ARDAE_TRY(launch_copy(W.z, (size_t)R * P.zd, z_out, st));
   return 0;
 }
 
@@ -374,7 +374,7 @@ int conv_model_pack(const ardae_model_desc& d, const float* params, float* packe
 
 static const float* zero_noise(Bump& ws, const ConvLayout& P, int B, int nz, hipStream_t st) {
   float* zero = ws.take((size_t)B * nz * P.nd);
-  (void)hipMemsetAsync(zero, 0, (size_t)B * nz * P.nd * sizeof(float), st);
+  if (launch_fill(zero, (size_t)B * nz * P.nd, 0.f, st) != 0) return nullptr;
   return zero;
 }
 
@@ -399,7 +399,7 @@ int conv_model_decode(const ardae_model_desc& d, const float* params, const floa
   carve(P, ws, R, 1, 2, W);
   ARDAE_CHECK_ARG(ws.ok, "conv_model_decode: workspace too small");
   ARDAE_TRY(conv_decode_fwd(P, K, params, packed, z, R, W, st));
-  ARDAE_HIP(hipMemcpyAsync(out0, W.logit, (size_t)R * 784 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  ARDAE_TRY(launch_copy(W.logit, (size_t)R * 784, out0, st));
   return 0;
 }
 
@@ -654,15 +654,15 @@ int auxconv_model_encode(const ardae_model_desc& d, const float* params, const f
   ARDAE_CHECK_ARG(ws.ok, "auxconv_model_encode: workspace too small");
   const float* nptr = noise;
   if (!noise) {
-    ARDAE_HIP(hipMemsetAsync(W.zero, 0, (size_t)B * nz * (P.nd + P.zd) * sizeof(float), st));
+    ARDAE_TRY(launch_fill(W.zero, (size_t)B * nz * (P.nd + P.zd), 0.f, st));
     nptr = W.zero;
   }
   ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, nptr, B, nz, W, hidden_out != nullptr, st));
-  if (z_out) ARDAE_HIP(hipMemcpyAsync(z_out, W.D.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (z_out) ARDAE_TRY(launch_copy(W.D.z, (size_t)B * nz * P.zd, z_out, st));
   if (hidden_out) {
     ARDAE_CHECK_ARG(nz == 1, "auxconv_model_encode: the hidden context is defined for nz == 1");
-    ARDAE_HIP(hipMemcpy2DAsync(hidden_out, 1600 * sizeof(float), W.h4a, 800 * sizeof(float), 800 * sizeof(float), B, hipMemcpyDeviceToDevice, st));
-    ARDAE_HIP(hipMemcpy2DAsync(hidden_out + 800, 1600 * sizeof(float), W.D.t1, 800 * sizeof(float), 800 * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+    ARDAE_TRY(launch_copy2d(W.h4a, 800, hidden_out, 1600, B, 800, st));
+    ARDAE_TRY(launch_copy2d(W.D.t1, 800, hidden_out + 800, 1600, B, 800, st));
   }
   return 0;
 }
@@ -676,7 +676,7 @@ int auxconv_model_decode(const ardae_model_desc& d, const float* params, const f
   aux_carve(P, ws, R, 1, 2, W);
   ARDAE_CHECK_ARG(ws.ok, "auxconv_model_decode: workspace too small");
   ARDAE_TRY(conv_decode_fwd(P.dec, K.dec, params, packed, z, R, W.D, st));
-  ARDAE_HIP(hipMemcpyAsync(out0, W.D.logit, (size_t)R * 784 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  ARDAE_TRY(launch_copy(W.D.logit, (size_t)R * 784, out0, st));
   return 0;
 }
 
@@ -690,7 +690,7 @@ int auxconv_model_vae_forward(const ardae_model_desc& d, const float* params, co
   ARDAE_CHECK_ARG(ws.ok, "auxconv_model_vae_forward: workspace too small");
   const int R = B * nz;
   ARDAE_TRY(aux_sampler_fwd(P, K, params, packed, x, noise, B, nz, W, true, st));
-  ARDAE_HIP(hipMemcpyAsync(z_out, W.D.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  ARDAE_TRY(launch_copy(W.D.z, (size_t)R * P.zd, z_out, st));
   ARDAE_TRY(conv_decode_fwd(P.dec, K.dec, params, packed, W.D.z, R, W.D, st));
   ARDAE_TRY(launch_vae_loss(0, W.D.logit, nullptr, x, W.D.z, R, nz, 784, P.zd, beta, 0, 0.f, nullptr, W.D.rec_row, W.D.pri_row, nullptr, nullptr, nullptr, st));
   return launch_vae_loss_finalize(W.D.rec_row, W.D.pri_row, R, beta, losses, st);

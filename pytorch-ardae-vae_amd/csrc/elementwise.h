@@ -41,6 +41,11 @@ int launch_rmsprop(float* p, const float* g, float* sq, float* buf, int64_t n, d
 
 // y += alpha*x (the entropy-gradient seed of ivae_ardae.py:834 added to dL/dz)
 int launch_axpy(const float* x, int64_t n, float alpha, float* y, hipStream_t st);
+// y[i] = v;  y = x;  y[r][c] = x[r][c] (row strides ldx / ldy) - kernels instead of hipMemsetAsync / hipMemcpyAsync / hipMemcpy2DAsync: as
+// graph nodes those are not ordered against their neighbour kernels when a linear graph goes out as one AQL batch (elementwise.hip)
+int launch_fill(float* y, int64_t n, float v, hipStream_t st);
+int launch_copy(const float* x, int64_t n, float* y, hipStream_t st);
+int launch_copy2d(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, hipStream_t st);
 // y = alpha*x + beta (the encoder's 2x-1 rescale, ivae/mnist.py:81)
 int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t st);
 // Row losses of ImplicitPosteriorVAE.loss (ivae/mnist.py:240-249, toy.py:777-786) and, when write_grads, their gradients:

@@ -331,6 +331,20 @@ __global__ void axpy_kernel(const float* __restrict__ x, int64_t n, float alpha,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
 
+// The library issues no hipMemsetAsync / hipMemcpyAsync: as nodes of a captured graph they are not ordered against the
+// neighbouring kernel nodes when ROCm 7.2 submits a linear graph as one batch of AQL packets (seen on MI355X: the zero-noise
+// block of encode(x, std=0) was read before it had been cleared in ~2 of 3 replays).  Fills and copies are kernels like the rest.
+__global__ void fill_kernel(float* __restrict__ y, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = v;
+}
+__global__ void copy2d_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int64_t rows, int64_t cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i - r * cols;
+    y[r * ldy + c] = x[r * ldx + c];
+  }
+}
+
 __global__ void affine_kernel(const float* __restrict__ x, int64_t n, float alpha, float beta, float* __restrict__ y) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = alpha * x[i] + beta;
 }
@@ -556,6 +570,22 @@ int launch_axpy(const float* x, int64_t n, float alpha, float* y, hipStream_t st
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
+
+int launch_fill(float* y, int64_t n, float v, hipStream_t st) {
+  ARDAE_CHECK_ARG(y && n > 0, "fill: bad arguments");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, y, n, v);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_copy2d(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t cols, hipStream_t st) {
+  ARDAE_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= cols, "copy2d: bad arguments");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, ldx, y, ldy, rows, cols);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_copy(const float* x, int64_t n, float* y, hipStream_t st) { return launch_copy2d(x, n, y, n, 1, n, st); }
 
 int launch_affine(const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t st) {
   ARDAE_CHECK_ARG(x && y && n > 0, "affine: bad arguments");

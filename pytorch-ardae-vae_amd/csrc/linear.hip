@@ -512,7 +512,7 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
     ARDAE_TRY(validate_linear(a, epi));
     return launch_linear_shortk(a, epi, st);
   }
-  static const bool wide_on = !(getenv("ARDAE_WIDE") && atoi(getenv("ARDAE_WIDE")) == 0);
+  static const bool wide_on = !(debug_knob("ARDAE_WIDE") && atoi(debug_knob("ARDAE_WIDE")) == 0);
   if (wide_on && linear_wide_eligible(a, epi)) {
     if (epi == EPI_ACT) ARDAE_CHECK_ARG(!a.rowbias || a.rows_per_group > 0, "linear: rows_per_group must be positive");
     if (epi == EPI_DACT || epi == EPI_CHAIN) ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT/EPI_CHAIN need S");

@@ -113,7 +113,7 @@ int launch_narrow(const LinArgs& a, hipStream_t st) {
 // One source of K = 256, Nout <= 32, whole 128-row tiles (the row-tile size the per-tile loss partials are sized for:
 // linear_row_tile() of the narrow geometry), vector-aligned rows; plain bias epilogue or the DAE loss.  ARDAE_NARROW=0: off.
 bool linear_narrow_eligible(const LinArgs& a, int epi) {
-  static const bool on = !(getenv("ARDAE_NARROW") && atoi(getenv("ARDAE_NARROW")) == 0);
+  static const bool on = !(debug_knob("ARDAE_NARROW") && atoi(debug_knob("ARDAE_NARROW")) == 0);
   if (!on || a.nsrc != 1 || a.src[0].K != 256 || a.Nout <= 0 || a.Nout > 32 || a.M <= 0 || (a.M % 128)) return false;
   if ((a.src[0].ld & 3) || (reinterpret_cast<uintptr_t>(a.src[0].x) & 15) || a.colsum != nullptr) return false;
   if (epi == EPI_ACT) return a.act == ACT_NONE && !a.rowbias && !a.rowscale && !a.Y2 && a.Y != nullptr;

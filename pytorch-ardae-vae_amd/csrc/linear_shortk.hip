@@ -252,7 +252,7 @@ int launch_shortk(const LinArgs& a, hipStream_t st) {
 // blocks, >= 8192 rows (64 workgroups: from there on it beats the generic kernel - at the 64-image shard of the 8-GPU run, 16384
 // rows, the fused sampler is 1.7 % of the step); forward epilogue (bias, per-image row bias, activation) only.  ARDAE_SHORTK=0: off.
 bool linear_shortk_eligible(const LinArgs& a, int epi) {
-  static const bool on = !(getenv("ARDAE_SHORTK") && atoi(getenv("ARDAE_SHORTK")) == 0);
+  static const bool on = !(debug_knob("ARDAE_SHORTK") && atoi(debug_knob("ARDAE_SHORTK")) == 0);
   if (!on || epi != EPI_ACT || a.nsrc != 1) return false;
   const int K = a.src[0].K;
   if (K <= 0 || K > SK_MAXK || (K & 3) || K % 32 == 0) return false;
@@ -266,7 +266,7 @@ bool linear_shortk_eligible(const LinArgs& a, int epi) {
 // `first` is the short-K layer as launch_linear would get it (its Y is ignored), followed by Z = hidden . W2^T + b2 with N2 <= 32
 // columns.  ARDAE_SAMPLER_TAIL=0: off.
 bool sampler_tail_eligible(const LinArgs& first, int n2) {
-  static const bool on = !(getenv("ARDAE_SAMPLER_TAIL") && atoi(getenv("ARDAE_SAMPLER_TAIL")) == 0);
+  static const bool on = !(debug_knob("ARDAE_SAMPLER_TAIL") && atoi(debug_knob("ARDAE_SAMPLER_TAIL")) == 0);
   if (!on || n2 < 1 || n2 > 32) return false;
   LinArgs a = first;
   if (!a.Y) a.Y = const_cast<float*>(a.src[0].x);   // the single-layer rule wants an output pointer; unused here

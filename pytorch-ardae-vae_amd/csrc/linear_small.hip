@@ -201,8 +201,8 @@ int launch_small(const LinArgs& a, hipStream_t st) {
 // Per-image problems only: up to SMALL_MAX_TILES workgroups (beyond that the throughput tilings win), no per-tile side
 // outputs (column sums, DAE-loss partials: those belong to N-row launches).  ARDAE_SMALL=0 switches the kernel off.
 bool linear_small_eligible(const LinArgs& a, int epi) {
-  static const bool on = !(getenv("ARDAE_SMALL") && atoi(getenv("ARDAE_SMALL")) == 0);
-  static const int max_tiles = getenv("ARDAE_SMALL_MAX_TILES") ? atoi(getenv("ARDAE_SMALL_MAX_TILES")) : 512;
+  static const bool on = !(debug_knob("ARDAE_SMALL") && atoi(debug_knob("ARDAE_SMALL")) == 0);
+  static const int max_tiles = debug_knob("ARDAE_SMALL_MAX_TILES") ? atoi(debug_knob("ARDAE_SMALL_MAX_TILES")) : 512;
   if (!on || epi == EPI_DAE_LOSS || a.colsum != nullptr || a.tile_loss != nullptr) return false;
   if (a.M <= 0 || a.Nout <= 0) return false;
   if (epi == EPI_CHAIN && a.act == ACT_NONE) return false;

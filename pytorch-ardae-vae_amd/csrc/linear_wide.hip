@@ -6,7 +6,7 @@ namespace ardae {
 namespace wide {
 
 int wide_grid(int ntiles, int ncp) {
-  static const char* genv = getenv("ARDAE_WIDE_GRID");   // experiments: resident workgroups
+  static const char* genv = debug_knob("ARDAE_WIDE_GRID");   // experiments: resident workgroups
   int g = genv ? atoi(genv) : 256;
   g -= g % ncp;
   return ntiles < g ? ntiles : g;

@@ -249,7 +249,7 @@ int encode_fwd(const ModelLayout& P, const ModelPacked& K, const float* params, 
     return encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, z_out, false, st);
   ARDAE_TRY(encode_stack(P, K, params, packed, noise, B, nz, W.rb, W.t, W.z, keep_hidden, st));
   if (z_out) {
-    ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)B * nz * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ARDAE_TRY(launch_copy(W.z, (size_t)B * nz * P.zd, z_out, st));
   }
   return 0;
 }
@@ -355,7 +355,7 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   const float* nz_ptr = noise;
   if (!noise) {   // encode(x, std=0): the reference multiplies its draw by 0
     float* zero = ws.take((size_t)B * nz * P.nd);
-    ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * nz * P.nd * sizeof(float), st));
+    ARDAE_TRY(launch_fill(zero, (size_t)B * nz * P.nd, 0.f, st));
     nz_ptr = zero;
   }
   ARDAE_CHECK_ARG(ws.ok, "model_encode: internal workspace accounting error");
@@ -387,7 +387,7 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
   float* zero = ws.take((size_t)B * P.nd);
   ARDAE_CHECK_ARG(ws.ok, "model_encode_pair: internal workspace accounting error");
   if (phase != 2) {
-    ARDAE_HIP(hipMemsetAsync(zero, 0, (size_t)B * P.nd * sizeof(float), st));
+    ARDAE_TRY(launch_fill(zero, (size_t)B * P.nd, 0.f, st));
     ARDAE_TRY(encode_trunk(P, K, params, packed, x, B, W, st));
     ARDAE_TRY(encode_stack(P, K, params, packed, zero, B, 1, W.rb, t0, z0_out, false, st));    // encode(x, std=0): the draw is multiplied by 0
   }

@@ -79,3 +79,16 @@ int ardae_profile_report(ardae_profile_entry* entries, int max_entries) {
 }
 
 }  // extern "C"
+
+namespace {
+__global__ void debug_stamp_kernel(unsigned long long* slots, int slot) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) slots[slot] = __builtin_amdgcn_s_memrealtime();
+}
+}  // namespace
+
+extern "C" int ardae_debug_stamp(unsigned long long* slots, int slot, void* stream) {
+  ARDAE_CHECK_ARG(slots && slot >= 0, "debug_stamp: bad arguments");
+  hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots, slot);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}

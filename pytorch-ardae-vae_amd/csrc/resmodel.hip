@@ -614,7 +614,7 @@ int sampler_fwd(const ResLayout& P, const ResPacked& K, const float* params, con
   { LinArgs A{}; A.rowbias = W.rbh; A.rowbias_ld = P.cdim; A.rows_per_group = nz; A.Y = W.hh; A.ldY = P.cdim;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.cdim, W.z0, P.nd, P.nd, packed + K.efc.fn, A, st)); }
   RES_LAUNCH(act_inplace_kernel, (int64_t)R * P.cdim, W.hh, (int)ACT_ELU, (int64_t)R * P.cdim);
-  if (hidden_out) ARDAE_HIP(hipMemcpyAsync(hidden_out, W.hh, (size_t)R * P.cdim * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (hidden_out) ARDAE_TRY(launch_copy(W.hh, (size_t)R * P.cdim, hidden_out, st));
   { LinArgs A{}; A.bias = params + P.mu.b; A.Y = W.mu; A.ldY = P.zd; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.hh, P.cdim, P.cdim, packed + K.mu.f, A, st)); }
   { LinArgs A{}; A.bias = params + P.lv.b; A.Y = W.lvr; A.ldY = P.zd; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.hh, P.cdim, P.cdim, packed + K.lv.f, A, st)); }
   RES_LAUNCH(spm4_kernel, (int64_t)R * P.zd, W.lvr, (const float*)nullptr, W.lv, (int64_t)R * P.zd);
@@ -635,14 +635,14 @@ int decoder_fwd(const ResLayout& P, const ResPacked& K, const float* params, con
   ARDAE_TRY(blk_fwd(P.dec[5], K.dec[5], params, packed, W.db[4].out, R, ACT_ELU, W.db[5], st));
   RES_LAUNCH(upsample2_fwd_kernel, (int64_t)R * 784 * 16, W.db[5].out, 14, 16, W.u28, (int64_t)R * 784 * 16);
   ARDAE_TRY(blk_fwd(P.dec[6], K.dec[6], params, packed, W.u28, R, ACT_NONE, W.db[6], st));
-  if (logits && logits != W.db[6].out) ARDAE_HIP(hipMemcpyAsync(logits, W.db[6].out, (size_t)R * 784 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (logits && logits != W.db[6].out) ARDAE_TRY(launch_copy(W.db[6].out, (size_t)R * 784, logits, st));
   return 0;
 }
 
 const float* noise_or_zero(const ResLayout& P, const float* noise, int R, ResWs& W, hipStream_t st, int& rc) {
   rc = 0;
   if (noise) return noise;
-  if (hipMemsetAsync(W.zero, 0, (size_t)R * (P.nd + P.zd) * sizeof(float), st) != hipSuccess) rc = (int)hipErrorUnknown;
+  if (rc == 0) rc = launch_fill(W.zero, (size_t)R * (P.nd + P.zd), 0.f, st);
   return W.zero;
 }
 
@@ -764,7 +764,7 @@ int res_model_vae_forward(const ardae_model_desc& d, const float* params, const 
   const int R = B * nz;
   ARDAE_TRY(trunk_fwd(P, K, params, packed, x, B, W, st));
   ARDAE_TRY(sampler_fwd(P, K, params, packed, noise, B, nz, W, W.z, nullptr, st));
-  ARDAE_HIP(hipMemcpyAsync(z_out, W.z, (size_t)R * P.zd * sizeof(float), hipMemcpyDeviceToDevice, st));
+  ARDAE_TRY(launch_copy(W.z, (size_t)R * P.zd, z_out, st));
   ARDAE_TRY(decoder_fwd(P, K, params, packed, W.z, R, W, nullptr, st));
   ARDAE_TRY(launch_vae_loss(0, W.db[6].out, nullptr, x, W.z, R, nz, 784, P.zd, beta, 0, 0.f, nullptr, W.rec_row, W.pri_row, nullptr, nullptr, nullptr, st));
   return launch_vae_loss_finalize(W.rec_row, W.pri_row, R, beta, losses, st);

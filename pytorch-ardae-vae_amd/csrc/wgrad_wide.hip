@@ -352,7 +352,7 @@ bool al16g(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // 0: not eligible, 1: square geometry (256 x 256 tiles), 2: narrow geometry (256 x 32 tiles)
 int wgrad_wide_geometry(const WgradProblem& p) {
-  static const bool off = getenv("ARDAE_WGRAD_WIDE") && atoi(getenv("ARDAE_WGRAD_WIDE")) == 0;
+  static const bool off = debug_knob("ARDAE_WGRAD_WIDE") && atoi(debug_knob("ARDAE_WGRAD_WIDE")) == 0;
   if (off) return 0;
   if (p.O % WT || p.I % 32 || p.M % WRC || p.M < 64 * WRC) return 0;
   for (int k = 0; k < p.npairs; ++k) {

@@ -103,17 +103,20 @@ class _FlatOpt:
 
 
 class ArdaeEngine:
-    """`graph=True` (default): `step()` captures the whole iteration in a HIP graph at its second call and replays it
-    afterwards - the ~100 kernel launches of a step then cost one submission, and the 15-30 us the command processor
-    spends between dependent kernels of a stream shrink to a few (measured: 174 -> 151 us per big linear launch).  What
-    changes from step to step lives in device memory: a 32-byte step state (Philox base offset, Adam's t and bias
-    corrections, `ardae_step_state_advance`) and the two static image buffers the caller's batches are copied into.
-    Noise injection (parity tests) and lists of cDAE batches fall back to eager launches of the same calls.
+    """`graph=True` (default): `step()` captures the iteration at its third call and replays it afterwards.  What changes from
+    step to step lives in device memory: a 32-byte step state (Philox base offset, Adam's t and bias corrections,
+    `ardae_step_state_advance`) and the static image buffers the caller's batches are copied into.  Noise injection (parity
+    tests) runs the same launches eagerly.
 
-    Multi-rank runs (world > 1) replay too: the step is captured as a SEQUENCE of graphs cut at the gradient all-reduces
-    (capture ends where `_allreduce_mean` is reached, the collective runs eagerly between two replays, a new capture starts
-    behind it), so a rank submits three graphs and two collectives per step instead of ~110 launches - whatever the
-    backend (RCCL over xGMI in `bench.py --gpus N`, gloo in the rehearsal tests)."""
+    A step is a PLAN of units (`_plan` / `_units`): stretches of launches on ONE stream each, ordered by events between
+    them, with the gradient all-reduces (world > 1) as eager items in between.  Every unit is captured as its own LINEAR HIP
+    graph: ROCm submits a single-stream graph as one batch of AQL packets (measured on MI355X / ROCm 7.2: 3.3 us of host time
+    per node), while a graph with a forked stream is enqueued node by node at the cost of eager launches (9.3 us per node:
+    the 8-rank shard of config #2, 113 launches in 1.2 ms, was HOST-bound in round 2, and the side branch only reached its
+    queue 0.7 ms into the step).  Concurrency between the VAE forward half and the cDAE phase therefore comes from two
+    linear graphs on two streams, not from a fork inside one graph; the same units run eagerly when graphs are off, so
+    replayed == eager bit for bit, for any world size and any backend (RCCL over xGMI in `bench.py --gpus N`, gloo in the
+    rehearsal tests).  `graph=True` makes a refused capture an error; `graph="auto"` falls back to eager launches with a warning."""
 
     RNG_STRIDE = 16   # Philox offsets reserved per step (draws use base + 0, 1, 2, ...)
 
@@ -169,17 +172,21 @@ class ArdaeEngine:
         # --m-optimizer / --d-optimizer (ivae_ardae.py:545-556,612-622); the model's RMSprop is built with d_momentum there (:553)
         self.opt_m = _FlatOpt(cfg.m_optimizer, model._flat, model._flat.numel(), cfg.m_lr, cfg.m_beta1, cfg.d_momentum, state=self.state)
         self.opt_c = _FlatOpt(cfg.d_optimizer, cdae._flat, self.n_c, cfg.d_lr, cfg.d_beta1, cfg.d_momentum)
-        self.use_graph = bool(graph) and os.environ.get("ARDAE_GRAPH", "1") != "0"
-        self._graph, self._graph_key, self._xc, self._xv = None, None, None, None      # _xc: list of static batch buffers
-        self._capture = None          # segmented capture in progress (world > 1): see _allreduce_mean
+        if graph not in (True, False, "auto"):
+            raise ValueError(f"graph must be True, False or 'auto', got {graph!r}")
+        self.use_graph = bool(graph) and L.debug_knob("ARDAE_GRAPH", "1") != "0"
+        self.graph_strict = graph is True       # a refused capture is an error (bench.py must not silently time eager launches)
+        self._graph, self._graph_key, self._xc, self._xv = None, None, None, None      # _graph: the captured plan; _xc: static batch buffers
         self._in_step, self._draws, self._warmed = False, 0, False
         self._last_beta, self._beta_stable = None, 0
         # The first half of the VAE update (sampler + decoder + ELBO pieces on the VAE batch, ~25 per-image launches) needs
         # nothing from the cDAE update: step() runs it on a side stream next to the cDAE phase's N-row kernels.
-        self.overlap = os.environ.get("ARDAE_OVERLAP", "1") != "0"
+        self.overlap = L.debug_knob("ARDAE_OVERLAP", "1") != "0"
         # MLP models: the decoder half of the VAE backward (down to dL/dz) joins the forward half on the side stream
-        self.split_backward = int(md.kind) < 2 and os.environ.get("ARDAE_SPLIT_BACKWARD", "1") != "0"
+        self.split_backward = int(md.kind) < 2 and L.debug_knob("ARDAE_SPLIT_BACKWARD", "1") != "0"
         self._side = torch.cuda.Stream(device=self.dev) if self.overlap else None
+        self._cap_stream = torch.cuda.Stream(device=self.dev)
+        self._stamps = None                             # diagnostics: see enable_stamps()
         self._log = None                                # scalar log channel (scalar_log.ScalarLog), one more launch at the end of the step
         self.repack()
 
@@ -225,53 +232,114 @@ class ArdaeEngine:
         L.check(self.lib.ardae_model_encode_hidden(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), self.B,
                                                    L.ptr(ws), ws.numel(), L.ptr(z0_out), L.ptr(out), L.stream_ptr()), "ardae_model_encode_hidden")
 
-    def _allreduce_mean(self, t):
-        """Average a flat gradient buffer over the ranks.  While a multi-rank step is being captured this is a SEGMENT CUT: the
-        running capture ends here (after the side stream has joined - a graph must not end with a forked stream), the collective
-        is recorded as an eager item of the replay list, and a new capture begins behind it."""
-        if self.world == 1:
-            return
-        cap = self._capture
-        if cap is None:
-            dist.allreduce_mean_(t, self.pg)
-            return
-        if cap["side_open"]:
-            torch.cuda.current_stream().wait_stream(self._side)
-            cap["side_open"] = False
-        cap["ctx"].__exit__(None, None, None)
-        cap["items"] += [cap["graph"], t]
-        cap["graph"] = torch.cuda.CUDAGraph()
-        cap["ctx"] = torch.cuda.graph(cap["graph"], pool=cap["pool"])
-        cap["ctx"].__enter__()
+    # ------------------------------------------------------------------------------------------------------------
+    # The step as a plan.  A segment is ("run", name, stream, deps, fn) or ("allreduce", tensor); `_units` merges neighbouring
+    # segments of a stream into units (= what one linear graph holds).  A unit ends where another stream waits for it.
+    def _plan(self, xs, x_vae, noise, beta):
+        cfg = self.cfg
+        vae_draw = self.RNG_STRIDE - 1            # the VAE sampler's noise keeps its own offset whatever the launch order
+        # injected noise: one dict for everything, or a list with one dict per cDAE update (the last one also holds "vae")
+        nlist = list(noise) if isinstance(noise, (list, tuple)) else [noise] * len(xs)
+        nv = nlist[-1]["vae"] if nlist[-1] else self.noise_v
+        side = "side" if self.overlap else "main"
+        segs = [("run", "advance", "main", (), lambda: self.opt_m.advance(self.lib, self.RNG_STRIDE))]   # Philox base += stride, model optimiser's t += 1
+        vae_fwd = ("run", "vae_fwd", side, ("advance",), lambda: self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw))
+        if self.overlap:
+            # first in launch order: its ~30 per-image launches run beside the head of the cDAE phase (per-image launches too),
+            # before the N-row kernels take every CU
+            segs.append(vae_fwd)
+        for i, xc in enumerate(xs):
+            segs.append(("run", f"cdae_grads{i}", "main", (), lambda xc=xc, i=i: self._cdae_grads(xc, nlist[i], 3 * i)))
+            if self.world > 1:
+                segs.append(("allreduce", self.grads_c[:self.n_c]))
+            segs.append(("run", f"cdae_update{i}", "main", (), self._cdae_update))
+        if not self.overlap:
+            segs.append(vae_fwd)
+        segs.append(("run", "vae_bwd", "main", ("vae_fwd",) if self.overlap else (), lambda: self._vae_backward_grads(x_vae, nv, beta)))
+        if self.world > 1:
+            segs.append(("allreduce", self.grads_m))
 
-    def _capture_segments(self, xs, x_vae, beta):
-        """Capture one step as graphs cut at the all-reduces; returns the replay list [graph, tensor, graph, tensor, graph]."""
-        cap = {"items": [], "graph": torch.cuda.CUDAGraph(), "pool": torch.cuda.graph_pool_handle(), "side_open": False}
-        cap["ctx"] = torch.cuda.graph(cap["graph"], pool=cap["pool"])
-        cap["ctx"].__enter__()
-        self._capture = cap
-        try:
-            self._step_body(xs, x_vae, None, beta)
-        except BaseException:
-            self._capture = None
-            try:
-                cap["ctx"].__exit__(None, None, None)
-            except Exception:
-                pass
-            raise
-        self._capture = None
-        cap["ctx"].__exit__(None, None, None)
-        return cap["items"] + [cap["graph"]]
+        def model_update():
+            self._model_update()
+            if self._log is not None:
+                self._log.record(cfg.beta if beta is None else beta)
+        segs.append(("run", "model_update", "main", (), model_update))
+        if self._stamps is not None:
+            def wrap(name, fn):
+                def run():
+                    self._stamp(name + " >")
+                    fn()
+                    self._stamp(name + " <")
+                return run
+            segs = [s if s[0] != "run" else (s[0], s[1], s[2], s[3], wrap(s[1], s[4])) for s in segs]
+        return segs
 
-    def _replay(self):
-        if isinstance(self._graph, list):
-            for item in self._graph:
-                if torch.is_tensor(item):
-                    dist.allreduce_mean_(item, self.pg)
+    @staticmethod
+    def _units(segs):
+        """[("run", stream, wait_for (unit indices on other streams), [fns], record (bool)) | ("allreduce", tensor)] in launch order."""
+        needed = {d for s in segs if s[0] == "run" for d in s[3]}          # segments another stream waits for
+        units, where, open_unit = [], {}, {}                                # where: segment name -> unit index; open_unit: stream -> index
+        for s in segs:
+            if s[0] == "allreduce":
+                units.append(["allreduce", s[1]])
+                open_unit.clear()
+                continue
+            _, name, stream, deps, fn = s
+            waits = sorted({where[d] for d in deps if units[where[d]][1] != stream})
+            k = open_unit.get(stream)
+            if k is None or waits:
+                units.append(["run", stream, waits, [], False])
+                k = len(units) - 1
+            units[k][3].append(fn)
+            where[name] = k
+            open_unit[stream] = None if name in needed else k               # a unit somebody waits for ends here
+            if name in needed:
+                units[k][4] = True
+        return units
+
+    def _run_units(self, units, graphs=None, capture=False):
+        """Launch a plan: eagerly (graphs None), capturing every unit into its own linear graph (capture=True: returns them),
+        or replaying captured graphs."""
+        main = torch.cuda.current_stream()
+        streams = {"main": main, "side": self._side}
+        events, out = {}, []
+        for k, u in enumerate(units):
+            if u[0] == "allreduce":
+                dist.allreduce_mean_(u[1], self.pg)
+                out.append(None)
+                continue
+            _, sname, waits, fns, record = u
+            st = streams[sname]
+            for w in waits:
+                st.wait_event(events[w])
+            if sname != "main" and not waits:        # a side unit without explicit dependencies still follows what main has queued
+                st.wait_stream(main)
+            if capture:
+                g = torch.cuda.CUDAGraph()
+                # (captured on a stream of its own - the default stream cannot capture -, replayed on the unit's stream)
+                with torch.cuda.graph(g, stream=self._cap_stream):
+                    for fn in fns:
+                        fn()
+                out.append(g)
+                with torch.cuda.stream(st):
+                    g.replay()
+            elif graphs is not None:
+                if st is main:
+                    graphs[k].replay()
                 else:
-                    item.replay()
-        else:
-            self._graph.replay()
+                    with torch.cuda.stream(st):
+                        graphs[k].replay()
+            elif st is main:
+                for fn in fns:
+                    fn()
+            else:
+                with torch.cuda.stream(st):
+                    for fn in fns:
+                        fn()
+            if record:
+                events[k] = torch.cuda.Event()
+                events[k].record(st)
+        return out
 
     def _normal(self, out, draw=None):
         """One standard-normal draw.  Inside `step()` the offset comes from the device step state (graph-replayable);
@@ -292,54 +360,53 @@ class ArdaeEngine:
         return out
 
     # ------------------------------------------------------------------------------------------------------------
-    def cdae_phase(self, x, noise=None, apply_update=True, drawn=None):
-        """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z]).
-        drawn: event after which the engine's own three draws (sampler, sigma, eps) are in their buffers - step() issues them
-        on the side stream, next to the per-image trunk this method starts with."""
+    def cdae_phase(self, x, noise=None, apply_update=True):
+        """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z])."""
+        self._cdae_grads(x, noise)
+        if self.world > 1:
+            dist.allreduce_mean_(self.grads_c[:self.n_c], self.pg)
+        if apply_update:
+            self._cdae_update()
+
+    def _cdae_grads(self, x, noise=None, draw0=None):
+        """ivae_ardae.py:713-776: sampler on N rows, latent statistics, perturbation, cDAE loss and its gradients (local shard).
+        draw0: index of the first of this update's three Philox draws inside the step."""
         self._check_batch(x, "cdae_phase")
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         B, nz, z = self.B, cfg.nz_cdae, self.model.z_dim
         if noise:
             ns, xi, eps = noise["sampler"], noise["sigma"].reshape(-1), noise["eps"]
-        elif drawn is not None:
-            ns, xi, eps = self.noise_s, self.xi, self.eps
         else:
-            ns, xi, eps = self._normal(self.noise_s), self._normal(self.xi), self._normal(self.eps)
-        # context == latent_mean == encode(x, std=0) (lt0) and forward_hidden(x, nz) share the per-image trunk: one pass,
-        # cut in two where the noise is first needed when it is being drawn on the side stream
-        def pair(phase):
-            L.check(lib.ardae_model_encode_pair(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(ns), B, nz,
-                                                L.ptr(self.ws), self.ws.numel(), L.ptr(self.z0), L.ptr(self.latent), phase, st),
-                    "ardae_model_encode_pair")
-        # (waiting for the draws in the MIDDLE of the pair - per-image trunk first - was measured: under HIP-graph replay the extra
-        # cross-stream edge cost 0.22 ms per step on MI355X / ROCm 7.2; the wait sits in front of the pair)
+            d = (None, None, None) if draw0 is None else (draw0, draw0 + 1, draw0 + 2)
+            ns, xi, eps = self._normal(self.noise_s, d[0]), self._normal(self.xi, d[1]), self._normal(self.eps, d[2])
         if self.hidden_ctx:
             # aux models: hidden = model.encode.forward_hidden(x, std=0) and latent_mean = model.encode(x, std=0) are ONE std = 0 pass
             # (ivae_ardae.py:737-739,748), then the N-row pass
-            if drawn is not None and not noise:
-                torch.cuda.current_stream().wait_event(drawn)
             self._hidden(x, self.z0, self.ctx_c, self.ws_small)
             self._encode(x, ns, nz, self.latent, self.ws)
         else:
-            if drawn is not None and not noise:
-                torch.cuda.current_stream().wait_event(drawn)
-            pair(0)
+            # context == latent_mean == encode(x, std=0) (lt0) and forward_hidden(x, nz) share the per-image trunk: one pass
+            L.check(lib.ardae_model_encode_pair(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(ns), B, nz,
+                                                L.ptr(self.ws), self.ws.numel(), L.ptr(self.z0), L.ptr(self.latent), 0, st),
+                    "ardae_model_encode_pair")
         if self.data_ctx:
             self._data_context(x, self.ctx_c)
+        self._stamp("  sampler done")
         nstd = int(cfg.nstd_cdae)
         L.check(lib.ardae_latent_perturb_nstd(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, nstd, z, cfg.std_scale, cfg.delta,
                                               L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb_nstd")
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
                                           L.ptr(self.sigma), L.ptr(eps), L.ptr(self.ctx_c), B, nz * nstd, L.ptr(self.ws), self.ws.numel(),
                                           L.ptr(self.loss_c), L.ptr(self.grads_c), None, st), "ardae_cdae_loss_grads")
-        self._allreduce_mean(self.grads_c[:self.n_c])
-        if apply_update:
-            if self._in_step and self.opt_c.adam:
-                self.opt_c.advance(lib)           # the cDAE's own Adam block: t advances once per cDAE update
-            self.opt_c.apply(lib, self.grads_c, self._in_step)
-            if not self._in_step:
-                self.opt_c.steps += 1
-            self._pack_cdae()
+
+    def _cdae_update(self):
+        """ivae_ardae.py:777-779: the cDAE optimiser's step on the (rank-averaged) gradients, then the weight re-pack."""
+        if self._in_step and self.opt_c.adam:
+            self.opt_c.advance(self.lib)           # the cDAE's own Adam block: t advances once per cDAE update
+        self.opt_c.apply(self.lib, self.grads_c, self._in_step)
+        if not self._in_step:
+            self.opt_c.steps += 1
+        self._pack_cdae()
 
     def _data_context(self, x, out):
         """--cdae-ctx-type data: the flattened image, centred to 2x - 1 for the MNIST family (ivae_ardae.py:730-734,809-813)."""
@@ -373,6 +440,13 @@ class ArdaeEngine:
 
     def vae_backward_part(self, x, nv, beta=None, apply_update=True):
         """ivae_ardae.py:829-846: entropy gradient through the (updated) cDAE, backward, Adam."""
+        self._vae_backward_grads(x, nv, beta)
+        if self.world > 1:
+            dist.allreduce_mean_(self.grads_m, self.pg)
+        if apply_update:
+            self._model_update()
+
+    def _vae_backward_grads(self, x, nv, beta=None):
         self._check_batch(x, "vae_backward_part")
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         beta = cfg.beta if beta is None else beta
@@ -392,68 +466,62 @@ class ArdaeEngine:
             L.check(lib.ardae_model_vae_backward(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(nv), B, nz,
                                                  float(beta), 1.0, L.ptr(self.g), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.grads_m),
                                                  0.0, st), "ardae_model_vae_backward")
-        self._allreduce_mean(self.grads_m)
-        if apply_update:
-            self.opt_m.apply(lib, self.grads_m, self._in_step)   # in a step: t and the bias corrections come from the device step state
-            if not self._in_step:
-                self.step_count += 1
-                self.opt_m.steps = self.step_count
-            self._pack_model()
+
+    def _model_update(self):
+        self.opt_m.apply(self.lib, self.grads_m, self._in_step)   # in a step: t and the bias corrections come from the device step state
+        if not self._in_step:
+            self.step_count += 1
+            self.opt_m.steps = self.step_count
+            self.state[1:2].fill_(self.step_count)      # phase calls made directly keep the device t (scalar log, later step() calls) in step
+        self._pack_model()
 
     def vae_phase(self, x, noise=None, beta=None, apply_update=True):
         """ivae_ardae.py:781-846.  noise: optional dict(vae [B*nz_model, nd])."""
         nv = self.vae_forward_part(x, noise, beta)
         self.vae_backward_part(x, nv, beta, apply_update)
 
-    def _step_body(self, xs, x_vae, noise, beta):
-        """The launches of one iteration, in stream order (this is what the graph captures)."""
-        cfg = self.cfg
+    def _step_body(self, xs, x_vae, noise, beta, capture=False):
+        """One iteration: eager launches of the plan's units, or (capture=True) one linear graph per unit - returns the replay list."""
         self._in_step, self._draws = True, 0
         try:
-            self.opt_m.advance(self.lib, self.RNG_STRIDE)       # Philox base offset += stride, model optimiser's t += 1
-            vae_draw = self.RNG_STRIDE - 1            # the VAE sampler's noise keeps its own offset whatever the launch order
-            # injected noise: one dict for everything, or a list with one dict per cDAE update (the last one also holds "vae")
-            nlist = list(noise) if isinstance(noise, (list, tuple)) else [noise] * len(xs)
-            noise = None if noise is None else nlist[0]
-            if self.overlap:
-                main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                drawn = None
-                with torch.cuda.stream(self._side):
-                    if noise is None and len(xs) == 1:
-                        # the cDAE update's three draws need nothing but the step state: they run beside the sampler trunk
-                        self._normal(self.noise_s, 0); self._normal(self.xi, 1); self._normal(self.eps, 2)
-                        self._draws = 3
-                        drawn = torch.cuda.Event()
-                        drawn.record(self._side)
-                if self._capture is not None:
-                    # segmented capture: the side stream's work must sit in the FIRST graph (it is joined at the first cut), and
-                    # replay order does not depend on the order of capture
-                    self._capture["side_open"] = True
-                    with torch.cuda.stream(self._side):
-                        nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
-                    for i, xc in enumerate(xs):
-                        self.cdae_phase(xc, nlist[i], drawn=drawn)
-                    if self._capture["side_open"]:
-                        main.wait_stream(self._side)
-                        self._capture["side_open"] = False
-                else:
-                    # eager launches reach the GPU in host order: the cDAE phase (the critical path) is enqueued before the
-                    # side stream's ~30 small launches, which have the whole phase to finish in
-                    for i, xc in enumerate(xs):
-                        self.cdae_phase(xc, nlist[i], drawn=drawn)
-                    with torch.cuda.stream(self._side):
-                        nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
-                    main.wait_stream(self._side)
-            else:
-                for i, xc in enumerate(xs):
-                    self.cdae_phase(xc, nlist[i])
-                nv = self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw)
-            self.vae_backward_part(x_vae, nv, beta)
-            if self._log is not None:
-                self._log.record(cfg.beta if beta is None else beta)
+            units = self._units(self._plan(xs, x_vae, noise, beta))
+            graphs = self._run_units(units, capture=capture)
+            return (units, graphs) if capture else None
         finally:
             self._in_step = False
+
+    def _replay(self):
+        units, graphs = self._graph
+        self._run_units(units, graphs=graphs)
+
+    # ---- diagnostics: an unprofiled timeline of the step (device clock stamps between the pieces of the plan) ----------------
+    def enable_stamps(self, on=True):
+        """Insert one-thread timestamp kernels (`ardae_debug_stamp`, the device's constant 100 MHz clock) at the boundaries of the
+        plan's segments and between the calls of the cDAE phase; `read_stamps()` returns the last step's (name, microseconds)
+        pairs.  Each stamp is a launch of its own (~5 us on its stream): a diagnostic, never on in timed runs."""
+        self._stamps = {"buf": torch.zeros(256, dtype=torch.int64, device=self.dev), "names": []} if on else None
+        self._graph = None
+
+    def _stamp(self, name):
+        st = self._stamps
+        if st is None:
+            return
+        if name not in st["names"]:
+            st["names"].append(name)
+        L.check(self.lib.ardae_debug_stamp(ctypes.c_void_p(st["buf"].data_ptr()), st["names"].index(name), L.stream_ptr()), "ardae_debug_stamp")
+
+    def read_stamps(self):
+        st = self._stamps
+        torch.cuda.synchronize()
+        v = st["buf"].cpu().tolist()
+        t0 = min(v[i] for i in range(len(st["names"])))
+        return sorted(((n, (v[i] - t0) / 100.0) for i, n in enumerate(st["names"])), key=lambda kv: kv[1])
+
+    def plan_summary(self):
+        """What a replayed step submits, in launch order: "graph:<stream>" per linear graph, "allreduce" per collective."""
+        if self._graph is None:
+            return None
+        return ["allreduce" if u[0] == "allreduce" else f"graph:{u[1]}" for u in self._graph[0]]
 
     def step(self, x_cdae, x_vae, noise=None, beta=None):
         """One iteration of the reference loop: num_cdae_updates cDAE updates (each on its own batch in the reference; the
@@ -491,21 +559,18 @@ class ArdaeEngine:
                 self._warmed = True
             else:
                 try:
-                    if self.world > 1:
-                        g = self._capture_segments(self._xc, self._xv, b)
-                    else:
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
-                            self._step_body(self._xc, self._xv, None, b)
-                except Exception as exc:   # capture refused: eager from now on
-                    self.use_graph = False
+                    g = self._step_body(self._xc, self._xv, None, b, capture=True)      # runs the step too (each unit is replayed once captured)
+                except Exception as exc:
+                    if self.graph_strict:
+                        raise RuntimeError(f"ArdaeEngine(graph=True): HIP graph capture failed ({exc}); pass graph='auto' to fall back to "
+                                           "eager launches, or graph=False") from exc
+                    self.use_graph = False      # graph="auto": eager from now on
                     self._graph = None
                     import warnings
                     warnings.warn(f"ArdaeEngine: HIP graph capture failed ({exc}); continuing with eager launches")
                     self._step_body(self._xc, self._xv, None, b)
                 else:
                     self._graph, self._graph_key = g, key
-                    self._replay()
             self._count_step(len(xs))
             return
         self._step_body(xs, x_vae, noise, beta)
@@ -609,12 +674,15 @@ class ArdaeEngine:
         if eng is not None:     # written by this engine: continue the same noise stream
             rng.manual_seed(eng["rng_seed"], eng.get("rng_host_offset", rng.get_state()["offset"]))
             self.state.copy_(eng["step_state"].to(self.dev))
-        else:                   # written by the reference / the module path: only the optimisers' t matters
-            self.state.zero_()
+        else:                   # written by the reference / the module path: the optimisers' t, and Philox offsets this run has not used yet
+            self.state.zero_()      # (a resumed run with an unchanged seed would otherwise replay the draws of steps 1..step_count)
+            self.state[0] = self.RNG_STRIDE * self.step_count
         self.state[1] = self.step_count
         self.opt_c.state.zero_()
         self.opt_c.state[1] = self.opt_c.steps
         self._graph = None      # parameters were rewritten outside of the captured step
+        if self._log is not None:
+            self._log.resync()   # the log's iteration numbers come from the device t: first unreported iteration = step_count + 1
         self.repack()
 
     def stats(self):

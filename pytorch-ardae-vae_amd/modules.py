@@ -54,8 +54,30 @@ class FlatParamModule(nn.Module):
                 if p not in mod._modules:
                     mod.add_module(p, boxes.get(p, _Box)() if mod is self else _Box())
                 mod = mod._modules[p]
-            mod.register_parameter(parts[-1], nn.Parameter(self._flat[off:off + n].view(shape)))
+            par = nn.Parameter(self._flat[off:off + n].view(shape))
+            par._ardae_owner = weakref.ref(self)          # net.Adam / net.RMSprop find the owning module through it (optim.py)
+            mod.register_parameter(parts[-1], par)
         self._packed = None
+        self._tracked = False        # see _pack_is_current
+        self._packed_ver = None
+
+    # Weight image policy of the module path.  Default: re-pack at EVERY use (one launch over ~2-12 MB), because tensor version
+    # counters cannot be trusted to see an update - `p.data.add_(...)`, which is how the reference's vendored Adam writes
+    # (utils/optim.py:106), bumps none - so any optimiser, the reference's included, may be used with these modules.  Once one of
+    # THIS package's optimisers (optim.py: they bump the counters) is built over the parameters the module switches to tracking:
+    # the image is rebuilt only when a parameter's version has moved (optimiser step, load_state_dict, any in-place op on p).
+    # Writing through `p.data` by hand in that mode needs `mark_dirty()`.
+    def _pack_is_current(self):
+        if self._packed is None or not self._tracked:
+            return False
+        return self._packed_ver == tuple(p._version for p in self.parameters())
+
+    def _note_packed(self):
+        self._packed_ver = tuple(p._version for p in self.parameters())
+
+    def mark_dirty(self):
+        """Parameters were written behind autograd's back (`p.data...`) while one of net's optimisers tracks them."""
+        self._packed_ver = None
 
     # keep the parameters views of the flat buffer across .to()/.cuda()/.float()
     def _apply(self, fn, recurse=True):
@@ -158,14 +180,15 @@ class ConditionalARDAE(FlatParamModule):
         self._default_init()
 
     def _packed_weights(self):
-        """MFMA-lane-linear image of the current weights.  Re-packed at EVERY call (one launch over ~2-12 MB): tensor version
-        counters cannot be trusted to see an update - `p.data.add_(...)`, which is how the reference's vendored Adam writes
-        (utils/optim.py:106), bumps none - so any optimiser, the reference's included, may be used with these modules.
-        (The fused engine keeps its own image and re-packs right after its own optimiser kernels.)"""
+        """MFMA-lane-linear image of the current weights (policy: FlatParamModule._pack_is_current; the fused engine keeps its own
+        image and re-packs right after its own optimiser kernels)."""
+        if self._pack_is_current():
+            return self._packed
         lib = L.lib()
         if self._packed is None:
             self._packed = self._ws(lib.ardae_cdae_packed_floats(ctypes.byref(self._desc)))
         L.check(lib.ardae_cdae_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_cdae_pack")
+        self._note_packed()
         return self._packed
 
     def _prep(self, input, context, std):
@@ -320,11 +343,14 @@ class ImplicitPosteriorVAE(FlatParamModule):
                 p["encode.fc.fc.weight"].normal_()
 
     def _packed_weights(self):
-        """See ConditionalARDAE._packed_weights: re-packed at every call, whatever wrote the parameters."""
+        """See ConditionalARDAE._packed_weights."""
+        if self._pack_is_current():
+            return self._packed
         lib = L.lib()
         if self._packed is None:
             self._packed = self._ws(lib.ardae_model_packed_floats(ctypes.byref(self._desc)))
         L.check(lib.ardae_model_pack(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed), L.stream_ptr()), "ardae_model_pack")
+        self._note_packed()
         return self._packed
 
     def _x(self, input):
@@ -451,8 +477,14 @@ class ImplicitPosteriorVAE(FlatParamModule):
             if self._kind in AUX_KINDS:
                 cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321, ivae/auxconv.py, ivae/auxresconv.py:299
             cov = cov.contiguous()
-            Lc = torch.empty_like(cov)                        # all B factorisations in one launch (MultivariateNormal's, ivae/mnist.py:397)
-            L.check(L.lib().ardae_cholesky_batched(L.ptr(cov), B, zd, L.ptr(Lc), L.stream_ptr()), "ardae_cholesky_batched")
+            if zd <= 64:
+                Lc = torch.empty_like(cov)                    # all B factorisations in one launch (MultivariateNormal's, ivae/mnist.py:397)
+                L.check(L.lib().ardae_cholesky_batched(L.ptr(cov), B, zd, L.ptr(Lc), L.stream_ptr()), "ardae_cholesky_batched")
+            else:
+                # the LDS-resident kernel holds one z x z matrix per workgroup (z <= 64, every shipped recipe has z 32); larger latent
+                # spaces factorise on the device through the library solver MultivariateNormal itself would use - evaluation only
+                Lc, info = torch.linalg.cholesky_ex(cov)
+                Lc = torch.where((info == 0).view(B, 1, 1), Lc, torch.full_like(Lc, float("nan")))
             if not bool(torch.isfinite(Lc).all()):
                 raise ValueError("logprob: a sample covariance is not positive definite (torch.distributions would raise here too)")
             if prop_noise is None:

@@ -37,6 +37,17 @@ def _bump(p):
 class _FlatStateOptimizer(Optimizer):
     _state_names = ()
 
+    def __init__(self, params, defaults):
+        super().__init__(params, defaults)
+        # these optimisers bump the parameters' version counters after every step, so the owning modules may keep their packed
+        # weight image until a version moves instead of rebuilding it at every forward (modules.py::FlatParamModule._pack_is_current)
+        for group in self.param_groups:
+            for p in group["params"]:
+                owner = getattr(p, "_ardae_owner", None)
+                owner = owner() if owner is not None else None
+                if owner is not None:
+                    owner._tracked = True
+
     def _state_for(self, p):
         st = self.state[p]
         if len(st) == 0:

@@ -35,6 +35,10 @@ class ScalarLog:
         self._t_last = time.time()
         engine.attach_log(self)
 
+    def resync(self):
+        """The engine's step count was set from outside (load_checkpoints): records older than it are stale, the next one is new."""
+        self._next = self.eng.step_count + 1
+
     def record(self, beta):
         """Called by the engine as the last launch of a step (on the step's stream)."""
         e = self.eng

@@ -236,7 +236,7 @@ def test_cdae_nrow_kernels_opt_in_variants(knob):
     oracle comparison is re-run in a child process with the knob set."""
     import subprocess
     import sys
-    env = dict(os.environ)
+    env = dict(os.environ, ARDAE_DEBUG_KNOBS="1")      # the switches are inert without it
     k, _, v = knob.partition("=")
     env[k] = v or "1"
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",

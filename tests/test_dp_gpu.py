@@ -93,7 +93,7 @@ def _steps(per_rank_batch, lo, hi, graph, nsteps=5, **cfg):
         x2 = torch.bernoulli(torch.full((B, MC.input_dim), 0.3), generator=g)
         eng.step(x1[lo:hi].contiguous().to(dev), x2[lo:hi].contiguous().to(dev))
     torch.cuda.synchronize()
-    return model.flat_params().cpu().clone(), cdae.flat_params().cpu().clone(), eng._graph
+    return model.flat_params().cpu().clone(), cdae.flat_params().cpu().clone(), eng.plan_summary()
 
 
 def _worker_steps(rank, world, port, out):
@@ -106,22 +106,23 @@ def _worker_steps(rank, world, port, out):
     pm_g, pc_g, g_g = _steps(hi - lo, lo, hi, graph=True)
     if rank == 0:
         torch.save({"pm_eager": pm_e, "pc_eager": pc_e, "pm_graph": pm_g, "pc_graph": pc_g, "eager_has_graph": g_e is not None,
-                    "segments": [("allreduce" if torch.is_tensor(i) else "graph") for i in g_g] if isinstance(g_g, list) else None}, out)
+                    "segments": g_g}, out)
     torch.distributed.destroy_process_group()
 
 
 def test_two_rank_segmented_graph_replay_equals_eager(tmp_path):
-    """world > 1 replays the step as graphs cut at the two gradient all-reduces (engine._capture_segments): five steps of two
-    ranks with replay must give exactly the parameters of five steps of two ranks with eager launches (same kernels, same
-    collectives, same noise), and both must track the single-process run on the whole batch."""
+    """world > 1 replays the step as linear graphs cut at the two gradient all-reduces and at the cross-stream waits
+    (engine._plan / _units): five steps of two ranks with replay must give exactly the parameters of five steps of two ranks with
+    eager launches (same kernels, same collectives, same noise), and both must track the single-process run on the whole batch."""
     out = str(tmp_path / "dp_steps.pt")
     mp.spawn(_worker_steps, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
     assert got["eager_has_graph"] is False
-    assert got["segments"] == ["graph", "allreduce", "graph", "allreduce", "graph"]
+    # advance | VAE forward half beside | cDAE gradients | all-reduce | cDAE update | VAE backward (joins the side stream) | all-reduce | model update
+    assert got["segments"] == ["graph:main", "graph:side", "graph:main", "allreduce", "graph:main", "graph:main", "allreduce", "graph:main"]
     assert torch.equal(got["pm_graph"], got["pm_eager"]) and torch.equal(got["pc_graph"], got["pc_eager"])
     pm1, pc1, g1 = _steps(B, 0, B, graph=True)
-    assert g1 is not None and not isinstance(g1, list)
+    assert g1 == ["graph:main", "graph:side", "graph:main", "graph:main"]
     # five sign-like RMSprop / Adam steps amplify the fp32 sum-order difference between "two halves averaged" and "one batch"
     # (single-step agreement is pinned at 5e-4 in test_two_ranks_on_one_gpu_equal_single_process): the trajectories must track
     model0, cdae0 = _build(torch.device("cuda", 0))
@@ -173,18 +174,20 @@ def _worker_steps2(rank, world, port, out):
     pm_g, pc_g, g_g = _steps(hi - lo, lo, hi, graph=True, **TWO_UPDATES)
     if rank == 0:
         torch.save({"pm_eager": pm_e, "pc_eager": pc_e, "pm_graph": pm_g, "pc_graph": pc_g,
-                    "segments": [("allreduce" if torch.is_tensor(i) else "graph") for i in g_g] if isinstance(g_g, list) else None}, out)
+                    "segments": g_g}, out)
     torch.distributed.destroy_process_group()
 
 
 def test_two_rank_replay_with_two_cdae_updates_and_adam_pair(tmp_path):
     """--num-cdae-updates 2 (the shipped residual-conv recipes) on two ranks: three gradient all-reduces per step, so the step
-    replays as FOUR graphs; with Adam on both networks each keeps its own device-resident step count (the cDAE's advances twice
+    replays as linear graphs cut at each of them (and at the join with the side stream); with Adam on both networks each keeps its own device-resident step count (the cDAE's advances twice
     per step).  Replayed == eager bit for bit."""
     out = str(tmp_path / "dp_steps2.pt")
     mp.spawn(_worker_steps2, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
-    assert got["segments"] == ["graph", "allreduce", "graph", "allreduce", "graph", "allreduce", "graph"]
+    # the cDAE update of batch 0 and the gradients of batch 1 share a graph (no collective, no wait between them)
+    assert got["segments"] == ["graph:main", "graph:side", "graph:main", "allreduce", "graph:main", "allreduce", "graph:main", "graph:main", "allreduce",
+                               "graph:main"]
     assert torch.equal(got["pm_graph"], got["pm_eager"]) and torch.equal(got["pc_graph"], got["pc_eager"])
     assert torch.isfinite(got["pm_graph"]).all() and torch.isfinite(got["pc_graph"]).all()
 

@@ -285,7 +285,7 @@ def test_linear_generic_kernel_fallback_paths():
     import os
     import subprocess
     import sys
-    env = dict(os.environ, ARDAE_SMALL="0", ARDAE_NARROW="0", ARDAE_SHORTK="0")
+    env = dict(os.environ, ARDAE_DEBUG_KNOBS="1", ARDAE_SMALL="0", ARDAE_NARROW="0", ARDAE_SHORTK="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k", "not fallback_paths"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
