@@ -81,6 +81,13 @@ int ardae_linear_col_panels(int M, int nout);
 /* M[n][k] = transpose ? W[k*ldw + n] : W[n*ldw + k]  ->  MFMA-lane-linear image (out: ardae_packed_floats) */
 int ardae_pack_weight(const float* W, int ldw, int nout, int k, int transpose, float* out, void* stream);
 int ardae_linear(const ardae_linear_args* args, int epilogue, void* stream);
+/* A row-local CHAIN of nl layers (layer l's input = layer l - 1's Y) in ONE launch: the workgroup keeps its 64-row tile in LDS
+ * between layers and reloads the next layer's weight slab behind the current layer's MFMAs - what the N-row passes of the cDAE
+ * update (models/graddae/mlp.py:400-444: forward, score, forward-mode and backward runs of h x h layers) use when a rank's shard
+ * is only a few tiles per CU (data-parallel runs).  Results are bit-identical to nl calls of ardae_linear.
+ * ardae_linear_chain_eligible: 1 if the shapes qualify (K = Nout = 256, M % 64 == 0, few row tiles, one epilogue kind). */
+int ardae_linear_chain_eligible(const ardae_linear_args* layers, int nl, int epilogue);
+int ardae_linear_chain(const ardae_linear_args* layers, int nl, int epilogue, void* stream);
 
 
 /* ---- K6w: batched weight gradients  dW[o][i] = sum_pairs sum_m G[m][o] X[m][i]  -------------------------------

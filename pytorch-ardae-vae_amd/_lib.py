@@ -96,6 +96,8 @@ EXPORTS = {
     "ardae_pack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_linear": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_void_p]),
+    "ardae_linear_chain_eligible": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_int]),
+    "ardae_linear_chain": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "ardae_wgrad_splits": (ctypes.c_int, [ctypes.c_int] * 4),
     "ardae_wgrad_batch": (ctypes.c_int, [ctypes.POINTER(WgradProblem), ctypes.c_int, ctypes.c_void_p]),
     "ardae_latent_perturb": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 4),

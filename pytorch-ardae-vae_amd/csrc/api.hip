@@ -37,6 +37,14 @@ int ardae_linear(const ardae_linear_args* args, int epilogue, void* stream) {
   return launch_linear(*args, epilogue, (hipStream_t)stream);
 }
 
+int ardae_linear_chain_eligible(const ardae_linear_args* layers, int nl, int epilogue) {
+  return (layers != nullptr && linear_chain_eligible(layers, nl, epilogue)) ? 1 : 0;
+}
+int ardae_linear_chain(const ardae_linear_args* layers, int nl, int epilogue, void* stream) {
+  ARDAE_CHECK_ARG(layers != nullptr, "ardae_linear_chain: layers is NULL");
+  return launch_linear_chain(layers, nl, epilogue, (hipStream_t)stream);
+}
+
 int ardae_wgrad_splits(int M, int O, int I, int nproblems_hint) { return wgrad_splits(M, O, I, nproblems_hint); }
 int ardae_wgrad_batch(const ardae_wgrad_problem* problems, int nproblems, void* stream) {
   return launch_wgrad_batch(problems, nproblems, (hipStream_t)stream);

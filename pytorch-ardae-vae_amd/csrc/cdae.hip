@@ -176,11 +176,40 @@ int cdae_pack_impl(const CdaeLayout& P, const PackedLayout& K, const float* para
 }
 
 // one fused Linear launch with a single source
-int lin(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
+LinArgs lin_args(int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a) {
   a.M = M; a.Nout = Nout; a.nsrc = 1; a.act = act;
   a.src[0].x = x; a.src[0].ld = ldx; a.src[0].K = K; a.src[0].wp = wp;
-  return launch_linear(a, epi, st);
+  return a;
 }
+int lin(int epi, int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a, hipStream_t st) {
+  return launch_linear(lin_args(act, M, Nout, x, ldx, K, wp, a), epi, st);
+}
+
+// A run of consecutive N-row layers of one epilogue kind, each reading its predecessor's output: the longest prefixes that
+// qualify go out as ONE launch each (linear_chain.hip: the small-shard regime), the rest layer by layer.
+struct LayerRun {
+  int epi;
+  hipStream_t st;
+  std::vector<LinArgs> v;
+  LayerRun(int epi_, hipStream_t st_) : epi(epi_), st(st_) {}
+  void add(int act, int M, int Nout, const float* x, int ldx, int K, const float* wp, LinArgs a) { v.push_back(lin_args(act, M, Nout, x, ldx, K, wp, a)); }
+  int flush() {
+    size_t i = 0;
+    while (i < v.size()) {
+      size_t n = v.size() - i;
+      while (n >= 2 && !linear_chain_eligible(v.data() + i, (int)n, epi)) --n;
+      if (n >= 2) {
+        ARDAE_TRY(launch_linear_chain(v.data() + i, (int)n, epi, st));
+        i += n;
+      } else {
+        ARDAE_TRY(launch_linear(v[i], epi, st));
+        i += 1;
+      }
+    }
+    v.clear();
+    return 0;
+  }
+};
 
 int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed, const float* xbar, const float* sigma,
               const float* eps, const float* ctx, int B, int S, float* workspace, size_t ws_floats, float* loss, float* grads,
@@ -220,35 +249,47 @@ int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed
     ARDAE_TRY(lin(EPI_ACT, ACT_NONE, B, h, cL[L], h, h, packed + K.w1c_f, A, st));
   }
   // ------------------------------------------------------------------ forward: inp + energy MLP (N rows)
-  for (int l = 1; l <= L; ++l) {
-    LinArgs A{}; A.bias = params + P.inp[l - 1].b; A.Y = a[l]; A.ldY = h;
-    ARDAE_TRY(lin(EPI_ACT, act, N, h, l == 1 ? xbar : a[l - 1], l == 1 ? z : h, P.inp[l - 1].in, packed + K.inp_f[l - 1], A, st));
+  {
+    LayerRun run(EPI_ACT, st);
+    for (int l = 1; l <= L; ++l) {
+      LinArgs A{}; A.bias = params + P.inp[l - 1].b; A.Y = a[l]; A.ldY = h;
+      run.add(act, N, h, l == 1 ? xbar : a[l - 1], l == 1 ? z : h, P.inp[l - 1].in, packed + K.inp_f[l - 1], A);
+    }
+    ARDAE_TRY(run.flush());
   }
   const float* wfc = params + P.neg[L].w;   // grad kind: w [1,h]
-  for (int l = 1; l <= L; ++l) {
-    LinArgs A{}; A.Y = hh[l]; A.ldY = h;
-    if (l == 1) {
-      A.rowbias = cb; A.rowbias_ld = h; A.rows_per_group = S; A.rowscale = sigma; A.rowscale_w = W1s;
-    } else {
-      A.bias = params + P.neg[l - 1].b;
+  {
+    LayerRun run(EPI_ACT, st);
+    for (int l = 1; l <= L; ++l) {
+      LinArgs A{}; A.Y = hh[l]; A.ldY = h;
+      if (l == 1) {
+        A.rowbias = cb; A.rowbias_ld = h; A.rows_per_group = S; A.rowscale = sigma; A.rowscale_w = W1s;
+      } else {
+        A.bias = params + P.neg[l - 1].b;
+      }
+      if (P.kind == 0 && l == L) { A.Y2 = e[L]; A.ldY2 = h; A.R = wfc; }   // e_L = -w (.) s(h_L)
+      run.add(act, N, h, l == 1 ? a[L] : hh[l - 1], h, h, l == 1 ? packed + K.w1a_f : packed + K.neg_f[l - 1], A);
     }
-    if (P.kind == 0 && l == L) { A.Y2 = e[L]; A.ldY2 = h; A.R = wfc; }   // e_L = -w (.) s(h_L)
-    ARDAE_TRY(lin(EPI_ACT, act, N, h, l == 1 ? a[L] : hh[l - 1], h, h, l == 1 ? packed + K.w1a_f : packed + K.neg_f[l - 1], A, st));
+    ARDAE_TRY(run.flush());
   }
   const float inv_nz = 1.0f / ((float)N * (float)z);
   if (P.kind == 0) {
     // ---------------------------------------------------------------- score pass (input-gradient of the energy)
-    for (int l = L; l >= 2; --l) {
-      LinArgs A{}; A.S = hh[l - 1]; A.ldS = h; A.Y = e[l - 1]; A.ldY = h;
-      ARDAE_TRY(lin(EPI_DACT, act, N, h, e[l], h, h, packed + K.neg_b[l - 1], A, st));
-    }
     {
-      LinArgs A{}; A.S = a[L]; A.ldS = h; A.Y = r[L]; A.ldY = h;
-      ARDAE_TRY(lin(EPI_DACT, act, N, h, e[1], h, h, packed + K.w1a_b, A, st));
-    }
-    for (int l = L; l >= 2; --l) {
-      LinArgs A{}; A.S = a[l - 1]; A.ldS = h; A.Y = r[l - 1]; A.ldY = h;
-      ARDAE_TRY(lin(EPI_DACT, act, N, h, r[l], h, h, packed + K.inp_b[l - 1], A, st));
+      LayerRun run(EPI_DACT, st);
+      for (int l = L; l >= 2; --l) {
+        LinArgs A{}; A.S = hh[l - 1]; A.ldS = h; A.Y = e[l - 1]; A.ldY = h;
+        run.add(act, N, h, e[l], h, h, packed + K.neg_b[l - 1], A);
+      }
+      {
+        LinArgs A{}; A.S = a[L]; A.ldS = h; A.Y = r[L]; A.ldY = h;
+        run.add(act, N, h, e[1], h, h, packed + K.w1a_b, A);
+      }
+      for (int l = L; l >= 2; --l) {
+        LinArgs A{}; A.S = a[l - 1]; A.ldS = h; A.Y = r[l - 1]; A.ldY = h;
+        run.add(act, N, h, r[l], h, h, packed + K.inp_b[l - 1], A);
+      }
+      ARDAE_TRY(run.flush());
     }
     if (!need_grads) {   // glogprob: g = r_1 A_1
       LinArgs A{}; A.Y = g; A.ldY = z;
@@ -276,30 +317,38 @@ int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed
   std::vector<float*>&qhat = qbar, &phat = pbar;   // in-place: qhat_l overwrites qbar_l, phat_l overwrites pbar_l
   if (P.kind == 0) {
     // forward-mode chain through the score pass
-    for (int l = 1; l <= L; ++l) {
-      LinArgs A{}; A.S = a[l]; A.ldS = h; A.R = r[l]; A.ldR = h; A.Y = tau[l]; A.ldY = h; A.Y2 = pbar[l]; A.ldY2 = h;
-      if (l == 1) ARDAE_TRY(lin(EPI_CHAIN, act, N, h, gbar, z, z, packed + K.inp_f[0], A, st));
-      else ARDAE_TRY(lin(EPI_CHAIN, act, N, h, tau[l - 1], h, h, packed + K.inp_f[l - 1], A, st));
-    }
-    for (int l = 1; l <= L; ++l) {
-      LinArgs A{}; A.S = hh[l]; A.ldS = h; A.R = e[l]; A.ldR = h; A.Y = taup[l]; A.ldY = h; A.Y2 = qbar[l]; A.ldY2 = h;
-      if (l == L) A.colsum = cs_taup;
-      ARDAE_TRY(lin(EPI_CHAIN, act, N, h, l == 1 ? tau[L] : taup[l - 1], h, h, l == 1 ? packed + K.w1a_f : packed + K.neg_f[l - 1], A, st));
+    {
+      LayerRun run(EPI_CHAIN, st);
+      for (int l = 1; l <= L; ++l) {
+        LinArgs A{}; A.S = a[l]; A.ldS = h; A.R = r[l]; A.ldR = h; A.Y = tau[l]; A.ldY = h; A.Y2 = pbar[l]; A.ldY2 = h;
+        if (l == 1) run.add(act, N, h, gbar, z, z, packed + K.inp_f[0], A);
+        else run.add(act, N, h, tau[l - 1], h, h, packed + K.inp_f[l - 1], A);
+      }
+      for (int l = 1; l <= L; ++l) {
+        LinArgs A{}; A.S = hh[l]; A.ldS = h; A.R = e[l]; A.ldR = h; A.Y = taup[l]; A.ldY = h; A.Y2 = qbar[l]; A.ldY2 = h;
+        if (l == L) A.colsum = cs_taup;
+        run.add(act, N, h, l == 1 ? tau[L] : taup[l - 1], h, h, l == 1 ? packed + K.w1a_f : packed + K.neg_f[l - 1], A);
+      }
+      ARDAE_TRY(run.flush());
     }
     // wbar = -colsum(tau'_L)  -> grads of neglogprob.fc.weight [1,h]
     ARDAE_TRY(launch_segment_sum(cs_taup, h, 1, ctiles, h, -1.0f, grads + P.neg[L].w, h, st));
     // ordinary backward of the energy chain, seeded ONLY by the qbar_l
-    for (int l = L; l >= 2; --l) {
-      LinArgs A{}; A.S = hh[l - 1]; A.ldS = h; A.Q = qbar[l - 1]; A.ldQ = h; A.Y = qhat[l - 1]; A.ldY = h;
-      ARDAE_TRY(lin(EPI_DACT, act, N, h, qhat[l], h, h, packed + K.neg_b[l - 1], A, st));
-    }
     {
-      LinArgs A{}; A.S = a[L]; A.ldS = h; A.Q = pbar[L]; A.ldQ = h; A.Y = phat[L]; A.ldY = h;
-      ARDAE_TRY(lin(EPI_DACT, act, N, h, qhat[1], h, h, packed + K.w1a_b, A, st));
-    }
-    for (int l = L; l >= 2; --l) {
-      LinArgs A{}; A.S = a[l - 1]; A.ldS = h; A.Q = pbar[l - 1]; A.ldQ = h; A.Y = phat[l - 1]; A.ldY = h;
-      ARDAE_TRY(lin(EPI_DACT, act, N, h, phat[l], h, h, packed + K.inp_b[l - 1], A, st));
+      LayerRun run(EPI_DACT, st);
+      for (int l = L; l >= 2; --l) {
+        LinArgs A{}; A.S = hh[l - 1]; A.ldS = h; A.Q = qbar[l - 1]; A.ldQ = h; A.Y = qhat[l - 1]; A.ldY = h;
+        run.add(act, N, h, qhat[l], h, h, packed + K.neg_b[l - 1], A);
+      }
+      {
+        LinArgs A{}; A.S = a[L]; A.ldS = h; A.Q = pbar[L]; A.ldQ = h; A.Y = phat[L]; A.ldY = h;
+        run.add(act, N, h, qhat[1], h, h, packed + K.w1a_b, A);
+      }
+      for (int l = L; l >= 2; --l) {
+        LinArgs A{}; A.S = a[l - 1]; A.ldS = h; A.Q = pbar[l - 1]; A.ldQ = h; A.Y = phat[l - 1]; A.ldY = h;
+        run.add(act, N, h, phat[l], h, h, packed + K.inp_b[l - 1], A);
+      }
+      ARDAE_TRY(run.flush());
     }
   } else {
     // direct-score variant: a single ordinary backward from gbar

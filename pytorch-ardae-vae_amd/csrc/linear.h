@@ -50,4 +50,8 @@ int launch_sampler_tail(const LinArgs& first, const float* wp2, const float* bia
 bool linear_wide_eligible(const LinArgs& a, int epi);
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st);
 
+// row-local CHAINS of K = Nout = 256 layers in one launch (linear_chain.hip): the small-shard regime (few tiles per workgroup)
+bool linear_chain_eligible(const LinArgs* layers, int nl, int epi);
+int launch_linear_chain(const LinArgs* layers, int nl, int epi, hipStream_t st);
+
 }  // namespace ardae

@@ -1,0 +1,11 @@
+// Kernel instantiations of linear_chain_kernel.h (dact); see linear_chain.hip for the dispatcher.
+#define ARDAE_WIDE_INST_TU
+#define ARDAE_CHAIN_INST_TU
+#include "linear_chain_kernel.h"
+
+namespace ardae {
+namespace wide {
+ARDAE_CHAIN_FOR_DACT(ARDAE_CHAIN_INSTANTIATE, ACT_SOFTPLUS)
+ARDAE_CHAIN_FOR_DACT(ARDAE_CHAIN_INSTANTIATE, ACT_RELU)
+}  // namespace wide
+}  // namespace ardae

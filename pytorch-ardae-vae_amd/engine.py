@@ -188,6 +188,7 @@ class ArdaeEngine:
         self._cap_stream = torch.cuda.Stream(device=self.dev)
         self._stamps = None                             # diagnostics: see enable_stamps()
         self._log = None                                # scalar log channel (scalar_log.ScalarLog), one more launch at the end of the step
+        self.opt_m.advance(self.lib, self.RNG_STRIDE)   # the step state always describes the COMING step (t = 1, first Philox block)
         self.repack()
 
     def attach_log(self, log):
@@ -242,8 +243,10 @@ class ArdaeEngine:
         nlist = list(noise) if isinstance(noise, (list, tuple)) else [noise] * len(xs)
         nv = nlist[-1]["vae"] if nlist[-1] else self.noise_v
         side = "side" if self.overlap else "main"
-        segs = [("run", "advance", "main", (), lambda: self.opt_m.advance(self.lib, self.RNG_STRIDE))]   # Philox base += stride, model optimiser's t += 1
-        vae_fwd = ("run", "vae_fwd", side, ("advance",), lambda: self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw))
+        # (the device step state is advanced at the END of a step, for the next one: nothing stands between the start of a step and
+        # the two streams' first launches)
+        segs = []
+        vae_fwd = ("run", "vae_fwd", side, (), lambda: self.vae_forward_part(x_vae, nlist[-1], beta, draw=vae_draw))
         if self.overlap:
             # first in launch order: its ~30 per-image launches run beside the head of the cDAE phase (per-image launches too),
             # before the N-row kernels take every CU
@@ -263,6 +266,7 @@ class ArdaeEngine:
             self._model_update()
             if self._log is not None:
                 self._log.record(cfg.beta if beta is None else beta)
+            self.opt_m.advance(self.lib, self.RNG_STRIDE)       # for the NEXT step: Philox base += stride, model optimiser's t += 1
         segs.append(("run", "model_update", "main", (), model_update))
         if self._stamps is not None:
             def wrap(name, fn):
@@ -342,7 +346,8 @@ class ArdaeEngine:
         return out
 
     def _normal(self, out, draw=None):
-        """One standard-normal draw.  Inside `step()` the offset comes from the device step state (graph-replayable);
+        """One standard-normal draw.  Inside `step()` the offset comes from the device step state (graph-replayable: the block is
+        advanced by the last launch of every step, for the next one);
         phase calls made directly use the host-side stream of `rng`.  `draw`: fixed index of the draw inside the step
         (so that the numbers do not depend on the order in which concurrent parts of the step are launched)."""
         first = self.rank * out.numel()        # equal shards: this rank's rows of the global draw (independent of the rank count)
@@ -472,7 +477,7 @@ class ArdaeEngine:
         if not self._in_step:
             self.step_count += 1
             self.opt_m.steps = self.step_count
-            self.state[1:2].fill_(self.step_count)      # phase calls made directly keep the device t (scalar log, later step() calls) in step
+            self.opt_m.advance(self.lib, self.RNG_STRIDE)   # phase calls made directly keep the device block (t of the coming step) in step
         self._pack_model()
 
     def vae_phase(self, x, noise=None, beta=None, apply_update=True):
@@ -671,13 +676,14 @@ class ArdaeEngine:
         self.step_count = m_steps if (m_steps or eng is None) else int(eng["step_count"])
         self.opt_m.steps = self.step_count
         self.opt_c.steps = c_steps if (c_steps or eng is None) else int(eng.get("cdae_steps", 0))
-        if eng is not None:     # written by this engine: continue the same noise stream
+        if eng is not None:     # written by this engine: continue the same noise stream (the saved block already describes the coming step)
             rng.manual_seed(eng["rng_seed"], eng.get("rng_host_offset", rng.get_state()["offset"]))
             self.state.copy_(eng["step_state"].to(self.dev))
         else:                   # written by the reference / the module path: the optimisers' t, and Philox offsets this run has not used yet
             self.state.zero_()      # (a resumed run with an unchanged seed would otherwise replay the draws of steps 1..step_count)
             self.state[0] = self.RNG_STRIDE * self.step_count
-        self.state[1] = self.step_count
+            self.state[1] = self.step_count
+            self.opt_m.advance(self.lib, self.RNG_STRIDE)
         self.opt_c.state.zero_()
         self.opt_c.state[1] = self.opt_c.steps
         self._graph = None      # parameters were rewritten outside of the captured step

@@ -379,3 +379,110 @@ def test_nrow_kernels_are_deterministic(M, K, Nout, rpg):
     assert not torch.isnan(outs[0]).any()
     for Y in outs[1:]:
         assert torch.equal(Y, outs[0])
+
+
+def _make_args(M, Nout, x, wp, **kw):
+    a = L.LinearArgs()
+    a.M, a.Nout, a.nsrc = M, Nout, 1
+    a.src[0].x = x.data_ptr(); a.src[0].ld = x.stride(0); a.src[0].K = x.shape[1]; a.src[0].wp = wp.data_ptr()
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            setattr(a, k, v.data_ptr())
+            ldname = {"S": "ldS", "R": "ldR", "Q": "ldQ", "Y": "ldY", "Y2": "ldY2", "rowbias": "rowbias_ld"}.get(k)
+            if ldname:
+                setattr(a, ldname, v.stride(0))
+        else:
+            setattr(a, k, v)
+    return a
+
+
+@pytest.mark.parametrize("M", [8192, 16384, 24576])
+@pytest.mark.parametrize("kind", ["act", "act_energy", "act_energy_noseed", "dact", "dact_q", "chain"])
+@pytest.mark.parametrize("nl", [2, 3, 5])
+def test_linear_chain_kernel_equals_per_layer_launches(M, kind, nl):
+    """linear_chain_kernel (a row-local run of h x h layers in ONE launch, the tile handed from layer to layer through LDS, the
+    next layer's weight slab reloaded behind the MFMAs) against nl launches of ardae_linear on the same data: same MFMA order,
+    same epilogue code - bit-identical, every tensor of every layer.  One tile per workgroup (16384 rows = the 8-rank shard of
+    config #2), half a chip (8192) and one-or-two tiles (24576); 2 layers (first + last body), 3 (one pass of the rolled middle
+    body) and 5 (the score / forward-mode / backward runs of L = 3); first layer with row bias + sigma term, last with the score
+    seed; the last CHAIN layer with per-tile column sums."""
+    h, act = 256, 2
+    g = torch.Generator(device="cuda").manual_seed(M + nl)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    X = rn(M, h)
+    Ws = [rn(h, h) / h ** 0.5 for _ in range(nl)]
+    wps = [pack(W) for W in Ws]
+    S = [torch.nn.functional.softplus(rn(M, h) * 3) for _ in range(nl)]
+    R = [rn(M, h) for _ in range(nl)]
+    Q0 = [rn(M, h) for _ in range(nl)]
+    bias = [rn(h) for _ in range(nl)]
+    rpg = 256
+    rowbias, sigma, wsig, wfc = rn(M // rpg, h), rn(M).abs(), rn(h), rn(h)
+    epi = {"act": L.EPI_ACT, "act_energy": L.EPI_ACT, "act_energy_noseed": L.EPI_ACT, "dact": L.EPI_DACT, "dact_q": L.EPI_DACT, "chain": L.EPI_CHAIN}[kind]
+    ntile = M // 64
+
+    def build(tag):
+        """LinearArgs of the nl layers writing into fresh output tensors; returns (array, outputs to compare)."""
+        Y = [torch.full((M, h), float("nan"), device="cuda") for _ in range(nl)]
+        Y2 = [torch.full((M, h), float("nan"), device="cuda") for _ in range(nl)]
+        Q = [q.clone() for q in Q0]
+        cs = torch.full((ntile, h), float("nan"), device="cuda")
+        arr = (L.LinearArgs * nl)()
+        for l in range(nl):
+            x = X if l == 0 else Y[l - 1]
+            if kind == "act":
+                a = _make_args(M, h, x, wps[l], act=act, bias=bias[l], Y=Y[l])
+            elif kind in ("act_energy", "act_energy_noseed"):
+                kw = dict(act=act, Y=Y[l])
+                if l == 0:
+                    kw.update(rowbias=rowbias, rows_per_group=rpg, rowscale=sigma, rowscale_w=wsig)
+                else:
+                    kw.update(bias=bias[l])
+                if l == nl - 1 and kind == "act_energy":
+                    kw.update(Y2=Y2[l], R=wfc)
+                a = _make_args(M, h, x, wps[l], **kw)
+            elif kind == "dact":
+                a = _make_args(M, h, x, wps[l], act=act, S=S[l], Y=Y[l])
+            elif kind == "dact_q":
+                Y[l] = Q[l]                                     # in place, as the backward pass runs it (qhat_l overwrites qbar_l)
+                a = _make_args(M, h, x, wps[l], act=act, S=S[l], Q=Q[l], Y=Q[l])
+            else:
+                kw = dict(act=act, S=S[l], R=R[l], Y=Y[l], Y2=Y2[l])
+                if l == nl - 1:
+                    kw.update(colsum=cs)
+                a = _make_args(M, h, x, wps[l], **kw)
+            arr[l] = a
+        return arr, Y, Y2, cs
+
+    lib = L.lib()
+    arr, Ya, Y2a, csa = build("per layer")
+    for l in range(nl):
+        L.check(lib.ardae_linear(ctypes.byref(arr[l]), epi, L.stream_ptr()), "ardae_linear")
+    arr, Yb, Y2b, csb = build("chain")
+    assert lib.ardae_linear_chain_eligible(arr, nl, epi) == 1
+    L.check(lib.ardae_linear_chain(arr, nl, epi, L.stream_ptr()), "ardae_linear_chain")
+    torch.cuda.synchronize()
+    for l in range(nl):
+        assert not torch.isnan(Yb[l]).any(), f"layer {l}: rows never written"
+        assert torch.equal(Ya[l], Yb[l]), f"Y of layer {l}: max |diff| {float((Ya[l] - Yb[l]).abs().max())}"
+        if kind == "chain" or (kind == "act_energy" and l == nl - 1):
+            assert torch.equal(Y2a[l], Y2b[l]), f"Y2 of layer {l}"
+    if kind == "chain":
+        assert torch.equal(csa, csb)
+
+
+def test_linear_chain_refuses_what_it_cannot_run():
+    h, M = 256, 16384
+    X = torch.randn(M, h, device="cuda"); W = pack(torch.randn(h, h, device="cuda"))
+    Y = [torch.empty(M, h, device="cuda") for _ in range(2)]
+    arr = (L.LinearArgs * 2)()
+    arr[0] = _make_args(M, h, X, W, act=2, Y=Y[0])
+    arr[1] = _make_args(M, h, X, W, act=2, Y=Y[1])               # second layer does not read the first one's output
+    assert L.lib().ardae_linear_chain_eligible(arr, 2, L.EPI_ACT) == 0
+    with pytest.raises(ValueError):
+        L.check(L.lib().ardae_linear_chain(arr, 2, L.EPI_ACT, L.stream_ptr()))
+    arr[1] = _make_args(M, h, Y[0], W, act=2, Y=Y[1])
+    assert L.lib().ardae_linear_chain_eligible(arr, 2, L.EPI_ACT) == 1
+    assert L.lib().ardae_linear_chain_eligible(arr, 1, L.EPI_ACT) == 0        # a chain has at least two layers
+    arr[0] = _make_args(4096, h, X, W, act=2, Y=Y[0]); arr[1] = _make_args(4096, h, Y[0], W, act=2, Y=Y[1])
+    assert L.lib().ardae_linear_chain_eligible(arr, 2, L.EPI_ACT) == 0        # 64 tiles: the small-M tiling fills the chip better

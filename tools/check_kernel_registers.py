@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time guard for the inline-asm kernels (linear_wide_kernel.h, wgrad_wide.hip).
+"""Build-time guard for the inline-asm kernels (linear_wide_kernel.h, linear_chain_kernel.h, wgrad_wide.hip).
 
 Their operand loads are issued by inline asm long before use, so the compiler does not know that those registers are "in
 flight": a register copy or spill it inserts between such a load and the s_waitcnt that lands it reads garbage (seen once:
@@ -26,7 +26,7 @@ import sys
 import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
-KERNELS = re.compile(r"linear_wide_kernel|wgrad_wide_kernel")
+KERNELS = re.compile(r"linear_wide_kernel|linear_chain_kernel|wgrad_wide_kernel")
 
 
 def regs(tok):
@@ -134,7 +134,7 @@ def check(hipcc, src, inc):
             continue
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\S+)", body).group(1))
         fm = re.search(re.escape(name) + r":.*?s_endpgm", t, re.S)
-        bad = scan(fm.group(0).split("\n"), no_agpr_moves="linear_wide_kernel" in name)
+        bad = scan(fm.group(0).split("\n"), no_agpr_moves=("linear_wide_kernel" in name or "linear_chain_kernel" in name))
         if scratch != 0 or bad:
             res.append((name, scratch, bad))
     return src, res
@@ -143,7 +143,7 @@ def check(hipcc, src, inc):
 def main():
     hipcc, csrc = sys.argv[1], sys.argv[2]
     files = sys.argv[3:] or [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))
-                             if re.match(r"(linear_wide_inst_|wgrad_wide).*\.hip$", f)]
+                             if re.match(r"(linear_wide_inst_|linear_chain_inst_|wgrad_wide).*\.hip$", f)]
     inc = os.path.join(csrc, "..", "..", "include")
     with ThreadPoolExecutor(max_workers=8) as ex:
         results = list(ex.map(lambda f: check(hipcc, f, inc), files))

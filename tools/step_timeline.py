@@ -3,8 +3,8 @@
 
     python tools/step_timeline.py <dir or kernel_trace.csv> [--step -2] [--out profiles/<tag>_timeline.txt]
 
-A step starts at its `step_state_advance_kernel` launch (the first launch of `ArdaeEngine._step_body`); the bench's two
-`bernoulli` launches in front of it belong to the step too.  For every kernel of the chosen step: start offset, duration,
+A step ends with its `step_state_advance_kernel` launch (the last launch of `ArdaeEngine`'s plan: the device step state is
+advanced for the NEXT step); the bench's two `bernoulli` launches behind it belong to the next step.  For every kernel of the chosen step: start offset, duration,
 queue, and the idle gap on the critical path (time since the latest end of any kernel that started before it).  The summary
 gives the union of busy time, the idle time inside the step and the per-family totals - the numbers DESIGN section 6 quotes.
 """
@@ -38,7 +38,7 @@ def main():
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
     rows.sort()
-    # the model optimiser's advance opens a step (the cDAE's own advance, when it has an Adam block, comes later inside it)
+    # the model optimiser's advance closes a step (the cDAE's own advance, when it has an Adam block, sits inside it)
     marks = [i for i, r in enumerate(rows) if r[2].startswith(a.marker)]
     # keep only marks that are followed by a long stretch (first advance of a step): steps = gaps between consecutive first marks
     starts = []
@@ -46,12 +46,7 @@ def main():
         if not starts or rows[i][0] - rows[starts[-1]][0] > 200_000:   # > 0.2 ms apart
             starts.append(i)
     k = a.step if a.step >= 0 else len(starts) + a.step
-    lo, hi = starts[k], starts[k + 1]
-    # pull the bernoulli launches in front of the marker into the step
-    while lo > 0 and rows[lo - 1][2].startswith("bernoulli"):
-        lo -= 1
-    while hi > 0 and rows[hi - 1][2].startswith("bernoulli"):
-        hi -= 1
+    lo, hi = starts[k] + 1, starts[k + 1] + 1
     step = rows[lo:hi]
     t0 = step[0][0]
     out = []
