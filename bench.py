@@ -71,6 +71,21 @@ def cpu_baseline(steps=5, warm=2):
             "s_per_step": dt, "s_per_step_all": [round(t, 3) for t in times[warm:]]}
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources the loaded library was built from (csrc/*.hip, *.h, include/*.h): profiles/pmc_summary.json carries
+    the same hash of the tree its counters were taken from (tools/summarize_profile.py), so stale counters are never quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for d, pats in ((os.path.join(ROOT, "pytorch-ardae-vae_amd", "csrc"), (".hip", ".h")), (os.path.join(ROOT, "include"), (".h",))):
+        files += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(pats)]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def kernel_family(name):
     """Template instantiations of one kernel are ONE family: `linear_wide_kernel<8, 4, 2, 2, 0, 0>` -> `linear_wide_kernel`."""
     return name.split("<", 1)[0].strip()
@@ -94,16 +109,26 @@ def roofline_of(rep, prof_steps):
     ach = tf(top)
     tot_ms = sum(e["total_ms"] for e in fams)
     tot_fl = sum(e["flops"] for e in fams)
-    traffic, traffic_src = None, None
+    traffic, traffic_src = None, "profiles/pmc_summary.json is missing"
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (a STORED profile value, not measured in this run)
         with open(pmc) as f:
             doc = json.load(f)
-        per = [(doc[n]["hbm_bytes_per_launch"], e["calls"]) for e in rep for n in [e["name"]]
-               if kernel_family(n) == top["name"] and n in doc and doc[n].get("hbm_bytes_per_launch")]
-        if per:
-            traffic = sum(b * c for b, c in per) / sum(c for _, c in per)
-            traffic_src = "profiles/pmc_summary.json (stored rocprofv3 --pmc passes; launch-weighted mean over the family's instantiations)"
+        meta = doc.get("_meta", {})
+        here = kernel_source_hash()
+        if meta.get("kernel_source_sha256") != here:
+            # the counters were taken from another build of the kernels: say so instead of quoting them
+            traffic_src = (f"null: profiles/pmc_summary.json was recorded from kernel sources {str(meta.get('kernel_source_sha256'))[:12]} "
+                           f"(git {meta.get('git', '?')}), the loaded library is built from {here[:12]}")
+        else:
+            per = [(doc[n]["hbm_bytes_per_launch"], e["calls"]) for e in rep for n in [e["name"]]
+                   if kernel_family(n) == top["name"] and n in doc and doc[n].get("hbm_bytes_per_launch")]
+            if per:
+                traffic = sum(b * c for b, c in per) / sum(c for _, c in per)
+                traffic_src = (f"profiles/pmc_summary.json (stored rocprofv3 --pmc passes of git {meta.get('git', '?')}, same kernel sources as the loaded "
+                               "library; launch-weighted mean over the family's instantiations)")
+            else:
+                traffic_src = "null: no counter rows for the dominant family in profiles/pmc_summary.json"
     single = max((e for e in rep if e["flops"] > 0 and e["total_ms"] > 0.02 * tot_ms), key=tf, default=None)
     return {"bound": "mfma", "kernel": top["name"], "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -111,8 +136,9 @@ def roofline_of(rep, prof_steps):
             "avg_launch_us": 1e3 * top["total_ms"] / top["calls"], "launches_per_step": top["calls"] / prof_steps,
             "algorithmic_gflop_per_launch": top["flops"] / top["calls"] / 1e9,
             "algorithmic_mbytes_per_launch": top["bytes"] / top["calls"] / 1e6,
-            "all_kernels_time_weighted": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                          "kernel_ms_per_step": tot_ms / prof_steps},
+            # FLOPs the kernels actually execute per step (per-launch algorithmic FLOPs of every launch of the instrumented steps): less than
+            # SURVEY 8(d)'s formula, which counts the W_1c c products on all N rows although the engine computes them once per image
+            "executed_tflop_per_step": tot_fl / prof_steps / 1e12,
             "best_single_kernel": None if single is None else {"name": single["name"], "achieved": tf(single), "frac": tf(single) / FP32_MFMA_PEAK_TFLOPS,
                                                                 "share_of_step_kernel_time": single["total_ms"] / tot_ms},
             "families": [{"name": e["name"], "calls_per_step": e["calls"] / prof_steps, "ms_per_step": e["total_ms"] / prof_steps,
@@ -183,10 +209,31 @@ def main():
         one_step()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    rank_report = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        # per-rank wall times of the timed region (the headline takes their MAX) and the latency of the step's two collectives,
+        # so that a multi-GPU line explains itself: compute per rank vs. time spent in the gradient all-reduces
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        t = mine.clone()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+        from ardae_amd import dist as D
+        lat = {}
+        for name, buf in (("cdae_grads", eng.grads_c[:eng.n_c]), ("model_grads", eng.grads_m)):
+            scratch = buf.clone()
+            for _ in range(3):
+                D.allreduce_mean_(scratch)
+            torch.cuda.synchronize(); torch.distributed.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                D.allreduce_mean_(scratch)
+            e1.record(); torch.cuda.synchronize()
+            lat[name] = {"bytes": scratch.numel() * 4, "us_per_allreduce_mean": 1e3 * e0.elapsed_time(e1) / 20}
+        rank_report = {"ms_per_step_by_rank": [1e3 * float(x) / args.steps for x in every], "collectives": lat,
+                       "plan": eng.plan_summary()}
     stats = eng.stats()
 
     # ---- live per-kernel timing (HIP events on the launch stream), separate from the throughput region
@@ -210,6 +257,7 @@ def main():
     if rank == 0:
         steps_per_s = args.steps / dt
         flop = algorithmic_flops_per_step(GLOBAL_B, NZ)
+        executed = roofline["executed_tflop_per_step"] * 1e12 * world if roofline else None      # rank 0's kernels x ranks (equal shards)
         out = {
             "metric": "AR-DAE-VAE train-steps/sec (batch 512, nz_cdae 256) on dbMNIST", "value": steps_per_s, "unit": "train-steps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -217,11 +265,18 @@ def main():
             "config": {"workload": "BASELINE config #2: MNISTIPVAE mlp z=32 h=256 + cDAE mlp-grad h=256 L=3, global batch 512, "
                                    "nz_cdae 256 (131072 rows), dynamic binarisation on device, 1 cDAE + 1 VAE update per step",
                        "global_batch": GLOBAL_B, "nz_cdae": NZ, "per_gpu_batch": B, "parallelism": f"dp{world}"},
+            # two whole-step figures: FLOPs the kernels EXECUTE (the honest utilisation), and SURVEY 8(d)'s formula, which also counts
+            # work the reference performs on all N rows but the engine hoists to once per image (W_1c c and its weight gradient)
+            "executed_tflop_per_step": None if executed is None else executed / 1e12,
+            "whole_step_tflops_executed": None if executed is None else executed * steps_per_s / 1e12,
+            "whole_step_frac_executed": None if executed is None else executed * steps_per_s / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
             "algorithmic_tflop_per_step": flop / 1e12,
+            "algorithmic_tflop_note": "SURVEY 8(d) formula, incl. per-image-hoisted work the reference performs on every row",
             "whole_step_tflops": flop * steps_per_s / 1e12,
             "whole_step_frac_of_fp32_mfma_peak": flop * steps_per_s / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
             "losses": stats,
             "hip_graph": bool(eng._graph is not None),
+            "ranks": rank_report,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (contract)

@@ -122,6 +122,16 @@ int ardae_latent_perturb(const float* latent, const float* z0, const float* xi, 
  * the statistics are those of the nz samples.  xi [B*nz*nstd], eps / xbar [B*nz*nstd, z], sigma [B*nz*nstd]; row (b, i, j) <- latent[b, i] */
 int ardae_latent_perturb_nstd(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int nstd, int z,
                               float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream);
+/* The same perturbation with its two draws made INSIDE the kernel (ivae_ardae.py:761 `torch.randn_like(std)` and
+ * models/graddae/mlp.py:21-23 `add_gaussian_noise`): no xi / eps inputs; the kernel generates the Philox counters of its image's rows,
+ * keyed exactly like ardae_philox_normal_at (element i of this rank's rows = element first_row [* z] + i of the global draw with
+ * (seed, offset_xi / offset_eps [+ the step state's base offset])), and writes the eps rows to eps_out for the DAE loss.  Same
+ * numbers as two ardae_philox_normal_at calls followed by ardae_latent_perturb, two launches and 2 x N (z + 1) floats of HBM traffic
+ * less.  ardae_latent_perturb_draw_ok: 1 if (nz, nstd, z) qualifies (nstd == 1, z a power of two, nz % 4 == 0, nz z <= 8192). */
+int ardae_latent_perturb_draw_ok(int nz, int nstd, int z);
+int ardae_latent_perturb_draw(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float delta, uint64_t seed,
+                              uint64_t offset_xi, uint64_t offset_eps, const void* state, uint64_t first_row, float* xbar, float* sigma,
+                              float* eps_out, float* std_b, void* stream);
 /* u = s (z - z0[b])  (ivae_ardae.py:827) */
 int ardae_center_scale(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float* u, void* stream);
 /* Philox4x32-10 counter RNG (replaces torch.randn at ivae/mnist.py:73, ivae_ardae.py:761, graddae/mlp.py:22) */

@@ -102,6 +102,9 @@ EXPORTS = {
     "ardae_wgrad_batch": (ctypes.c_int, [ctypes.POINTER(WgradProblem), ctypes.c_int, ctypes.c_void_p]),
     "ardae_latent_perturb": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 4),
     "ardae_latent_perturb_nstd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 4),
+    "ardae_latent_perturb_draw_ok": (ctypes.c_int, [ctypes.c_int] * 3),
+    "ardae_latent_perturb_draw": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [ctypes.c_uint64] * 3 +
+                                  [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_void_p] * 5),
     "ardae_center_scale": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2),
     "ardae_philox_normal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),
     "ardae_philox_uniform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),

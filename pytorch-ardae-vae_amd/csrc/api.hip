@@ -58,6 +58,13 @@ int ardae_latent_perturb_nstd(const float* latent, const float* z0, const float*
                               float std_scale, float delta, float* xbar, float* sigma, float* std_b, void* stream) {
   return launch_latent_perturb(latent, z0, xi, eps, B, nz, nstd, z, std_scale, delta, xbar, sigma, std_b, (hipStream_t)stream);
 }
+int ardae_latent_perturb_draw_ok(int nz, int nstd, int z) { return latent_perturb_draw_ok(nz, nstd, z) ? 1 : 0; }
+int ardae_latent_perturb_draw(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float delta, uint64_t seed,
+                              uint64_t offset_xi, uint64_t offset_eps, const void* state, uint64_t first_row, float* xbar, float* sigma,
+                              float* eps_out, float* std_b, void* stream) {
+  return launch_latent_perturb_draw(latent, z0, B, nz, z, std_scale, delta, seed, offset_xi, offset_eps, state, first_row, xbar, sigma, eps_out,
+                                    std_b, (hipStream_t)stream);
+}
 int ardae_center_scale(const float* latent, const float* z0, int B, int nz, int z, float std_scale, float* u, void* stream) {
   return launch_center_scale(latent, z0, B, nz, z, std_scale, u, (hipStream_t)stream);
 }

@@ -10,6 +10,12 @@ namespace ardae {
 //   sigma[b, i] = std_b * xi[b, i];  xbar = u + sigma * eps
 int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int nstd, int zd,
                           float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st);
+// the same with xi and eps DRAWN IN THE KERNEL (Philox keyed like launch_philox_normal_at: element i of this rank's rows = element
+// first_row (* zd) + i of the global draws (seed, off_xi / off_eps [+ state])); eps_out receives the eps rows (the DAE loss reads them)
+bool latent_perturb_draw_ok(int nz, int nstd, int zd);
+int launch_latent_perturb_draw(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float delta, uint64_t seed,
+                               uint64_t off_xi, uint64_t off_eps, const void* state, uint64_t first_row, float* xbar, float* sigma,
+                               float* eps_out, float* std_b, hipStream_t st);
 // u = s (z - z0[b]) only (VAE phase, sigma = 0: ivae_ardae.py:827)
 int launch_center_scale(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float* u,
                         hipStream_t st);

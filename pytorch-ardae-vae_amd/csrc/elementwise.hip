@@ -30,6 +30,20 @@ __device__ __forceinline__ void philox4(uint64_t seed, uint64_t offset, uint64_t
   for (int i = 0; i < 4; ++i) out[i] = s.c[i];
 }
 __device__ __forceinline__ float u01_open(uint32_t x) { return ((x >> 8) + 1u) * (1.0f / 16777216.0f); }  // (0,1]
+// the four standard normals of Philox counter `idx` (Box-Muller on the two word pairs): the ONE definition every draw uses -
+// the stand-alone kernel and the draws fused into their consumers give the same numbers for the same (seed, offset, element)
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t offset, uint64_t idx, float v[4]) {
+  uint32_t r[4];
+  philox4(seed, offset, idx, r);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float rad = sqrtf(-2.0f * logf(u01_open(r[2 * h])));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u01_open(r[2 * h + 1]), &sn, &cs);
+    v[2 * h] = rad * cs;
+    v[2 * h + 1] = rad * sn;
+  }
+}
 
 // Device-resident step state (ardae_step_state_advance): lets a captured HIP graph replay the step with fresh noise and
 // the right Adam bias correction - kernel arguments are frozen at capture, this block is not.
@@ -56,17 +70,8 @@ __global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one counter = 4 normals
   if (q * 4 >= n) return;
   if (state) offset += state->rng_offset;
-  uint32_t r[4];
-  philox4(seed, offset, q0 + (uint64_t)q, r);
   float v[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float rad = sqrtf(-2.0f * logf(u01_open(r[2 * h])));
-    float sn, cs;
-    sincosf(6.28318530717958647692f * u01_open(r[2 * h + 1]), &sn, &cs);
-    v[2 * h] = rad * cs;
-    v[2 * h + 1] = rad * sn;
-  }
+  philox_normal4(seed, offset, q0 + (uint64_t)q, v);
   if (q * 4 + 4 <= n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
     *reinterpret_cast<f32x4*>(out + q * 4) = f32x4{v[0], v[1], v[2], v[3]};
   } else {
@@ -161,13 +166,26 @@ __global__ __launch_bounds__(256) void latent_perturb_kernel(const float* __rest
 // Register-resident variant for nz * zd <= 256 * NV with zd a power of two: thread t owns elements t + 256 j (all of the same
 // latent dimension d = t % zd, samples r = t / zd + (256 / zd) j - the same assignment and summation order as the kernel
 // above, so the results are bit-identical), loaded ONCE with all NV loads in flight instead of three dependent passes.
-template <int NV>
+// DRAW (north star: "fused per-sample Gaussian-perturb + sigma-scaling" with the draws made in the kernel): xi and eps are not read
+// but GENERATED here - counter c of the global eps draw covers elements 4c .. 4c + 3, thread t computes counters t, t + 256, ... of
+// its image into LDS, from where every thread picks the elements it owns (the same ownership as the injected-noise form, so the
+// statistics are bit-identical for equal numbers); eps is also written out (the DAE-loss layer needs it: rho = sigma g + eps).
+// Keyed exactly like ardae_philox_normal_at: element i of a rank's shard = element first + i of the global draw (seed, offset).
+struct PerturbDraw {
+  uint64_t seed, off_xi, off_eps;     // Philox offsets of the two draws (the step state's base offset is added when state != null)
+  const StepState* state;
+  uint64_t first_row;                 // this rank's first row of the global [rows] / [rows, z] draws
+  float* eps_out;
+};
+
+template <int NV, bool DRAW>
 __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __restrict__ latent, const float* __restrict__ z0,
                                                                  const float* __restrict__ xi, const float* __restrict__ eps, int nz,
                                                                  int zd, float std_scale, float delta, float* __restrict__ xbar,
-                                                                 float* __restrict__ sigma, float* __restrict__ std_b) {
+                                                                 float* __restrict__ sigma, float* __restrict__ std_b, const PerturbDraw dr) {
   __shared__ float red[256];
   __shared__ float stat[256];
+  extern __shared__ float nbuf[];    // DRAW: nz * zd normals (eps of this image) + nz (xi)
   const int b = blockIdx.x, t = threadIdx.x;
   const int d = t & (zd - 1), RG = 256 / zd;
   const size_t base = (size_t)b * nz * zd;
@@ -177,8 +195,30 @@ __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __
   float u[NV], ev[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) u[j] = (t + 256 * j < per_image) ? lat[t + 256 * j] : z0d;
+  if (DRAW) {
+    const uint64_t base_off = dr.state ? dr.state->rng_offset : 0;
+    const uint64_t q_eps = (dr.first_row * (uint64_t)zd + base) >> 2;        // first counter of this image's eps block
+    for (int c = t; 4 * c < per_image; c += 256) {
+      float v[4];
+      philox_normal4(dr.seed, dr.off_eps + base_off, q_eps + (uint64_t)c, v);
+      *reinterpret_cast<f32x4*>(nbuf + 4 * c) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    const uint64_t q_xi = (dr.first_row + (uint64_t)b * nz) >> 2;
+    for (int c = t; 4 * c < nz; c += 256) {
+      float v[4];
+      philox_normal4(dr.seed, dr.off_xi + base_off, q_xi + (uint64_t)c, v);
+      *reinterpret_cast<f32x4*>(nbuf + per_image + 4 * c) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < NV; ++j) ev[j] = (t + 256 * j < per_image) ? eps[base + t + 256 * j] : 0.f;
+    for (int j = 0; j < NV; ++j) {
+      ev[j] = (t + 256 * j < per_image) ? nbuf[t + 256 * j] : 0.f;
+      if (t + 256 * j < per_image) dr.eps_out[base + t + 256 * j] = ev[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) ev[j] = (t + 256 * j < per_image) ? eps[base + t + 256 * j] : 0.f;
+  }
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -222,7 +262,7 @@ __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __
   for (int j = 0; j < NV; ++j) {
     if (t + 256 * j < per_image) {
       const size_t row = (size_t)b * nz + r0 + RG * j;
-      const float sg = sb * xi[row];
+      const float sg = sb * (DRAW ? nbuf[per_image + r0 + RG * j] : xi[row]);
       xbar[base + t + 256 * j] = u[j] + sg * ev[j];
       if (d == 0) sigma[row] = sg;
     }
@@ -431,6 +471,34 @@ inline int grid_for(int64_t n, int cap = 4096) {
 
 }  // namespace
 
+// can the draws of xi / eps be made inside the perturbation kernel?  (register-resident form, whole Philox counters per image)
+bool latent_perturb_draw_ok(int nz, int nstd, int zd) {
+  int zp = 1;
+  while (zp < zd) zp <<= 1;
+  const int64_t per_image = (int64_t)nz * zd;
+  return nstd == 1 && zp == zd && zd >= 4 && zd <= 256 && per_image >= 256 * 4 && per_image <= 256 * 32 && nz % 4 == 0;
+}
+
+int launch_latent_perturb_draw(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float delta, uint64_t seed,
+                               uint64_t off_xi, uint64_t off_eps, const void* state, uint64_t first_row, float* xbar, float* sigma,
+                               float* eps_out, float* std_b, hipStream_t st) {
+  ARDAE_CHECK_ARG(latent && z0 && xbar && sigma && eps_out && std_b && B > 0, "latent_perturb_draw: null pointer");
+  ARDAE_CHECK_ARG(latent_perturb_draw_ok(nz, 1, zd), "latent_perturb_draw: shape not eligible (nz=%d z=%d): draw separately", nz, zd);
+  ARDAE_CHECK_ARG((first_row & 3) == 0, "latent_perturb_draw: first_row must be a multiple of 4 (one Philox counter = 4 normals)");
+  const int64_t per_image = (int64_t)nz * zd;
+  const PerturbDraw dr{seed, off_xi, off_eps, (const StepState*)state, first_row, eps_out};
+  const size_t lds = (size_t)(per_image + nz) * sizeof(float);     // <= 33 KiB
+#define ARDAE_LP_DRAW(NV_)                                                                                                              \
+  hipLaunchKernelGGL((latent_perturb_reg_kernel<NV_, true>), dim3(B), dim3(256), lds, st, latent, z0, nullptr, nullptr, nz, zd, std_scale, \
+                     delta, xbar, sigma, std_b, dr)
+  if (per_image <= 256 * 8) ARDAE_LP_DRAW(8);
+  else if (per_image <= 256 * 16) ARDAE_LP_DRAW(16);
+  else ARDAE_LP_DRAW(32);
+#undef ARDAE_LP_DRAW
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_latent_perturb(const float* latent, const float* z0, const float* xi, const float* eps, int B, int nz, int nstd, int zd,
                           float std_scale, float delta, float* xbar, float* sigma, float* std_b, hipStream_t st) {
   ARDAE_CHECK_ARG(latent && z0 && xi && eps && xbar && sigma && std_b, "latent_perturb: null pointer");
@@ -440,9 +508,10 @@ int launch_latent_perturb(const float* latent, const float* z0, const float* xi,
   while (zp < zd) zp <<= 1;
   const int64_t per_image = (int64_t)nz * zd;
   const bool reg_ok = nstd == 1 && zp == zd && zd <= 256 && per_image >= 256 * 4;
-#define ARDAE_LP_REG(NV_)                                                                                                          \
-  hipLaunchKernelGGL(latent_perturb_reg_kernel<NV_>, dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, std_scale, delta, xbar, \
-                     sigma, std_b)
+  const PerturbDraw nodraw{};
+#define ARDAE_LP_REG(NV_)                                                                                                                      \
+  hipLaunchKernelGGL((latent_perturb_reg_kernel<NV_, false>), dim3(B), dim3(256), 0, st, latent, z0, xi, eps, nz, zd, std_scale, delta, xbar, \
+                     sigma, std_b, nodraw)
   if (reg_ok && per_image <= 256 * 8) ARDAE_LP_REG(8);
   else if (reg_ok && per_image <= 256 * 16) ARDAE_LP_REG(16);
   else if (reg_ok && per_image <= 256 * 32) ARDAE_LP_REG(32);

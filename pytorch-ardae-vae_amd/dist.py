@@ -30,12 +30,14 @@ def shard_rows(global_batch, group=None):
     return r * per, (r + 1) * per
 
 
-def allreduce_mean_(flat, group=None):
-    """In-place average of a flat gradient buffer over the ranks (no-op for a single process)."""
+def allreduce_mean_(flat, group=None, force=False):
+    """In-place average of a flat gradient buffer over the ranks (no-op for a single process, unless `force`: a one-rank group
+    then still issues the collective - how the RCCL path is exercised on a single GPU)."""
     w = world_size(group)
-    if w > 1:
+    if w > 1 or (force and torch.distributed.is_available() and torch.distributed.is_initialized()):
         torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
-        flat.mul_(1.0 / w)
+        if w > 1:
+            flat.mul_(1.0 / w)
     return flat
 
 

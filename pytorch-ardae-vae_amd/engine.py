@@ -120,7 +120,7 @@ class ArdaeEngine:
 
     RNG_STRIDE = 16   # Philox offsets reserved per step (draws use base + 0, 1, 2, ...)
 
-    def __init__(self, model, cdae, cfg: TrainConfig, batch_size, process_group=None, graph=True):
+    def __init__(self, model, cdae, cfg: TrainConfig, batch_size, process_group=None, graph=True, force_dp=False):
         model._require_gpu()
         cdae._require_gpu()
         self.model, self.cdae, self.cfg = model, cdae, cfg
@@ -130,6 +130,9 @@ class ArdaeEngine:
         self.pg = process_group
         self.world = dist.world_size(process_group)
         self.rank = dist.rank(process_group)
+        # force_dp: run the data-parallel plan (graphs cut at the gradient all-reduces, the collectives issued between them) even
+        # with ONE rank - exercises the RCCL path on a single GPU (tests/test_dp_gpu.py)
+        self.dp = self.world > 1 or bool(force_dp)
         md, cd = model._desc, cdae._desc
         B, nzc, nzm = self.B, cfg.nz_cdae, cfg.nz_model
         N = B * nzc
@@ -185,6 +188,7 @@ class ArdaeEngine:
         # MLP models: the decoder half of the VAE backward (down to dL/dz) joins the forward half on the side stream
         self.split_backward = int(md.kind) < 2 and L.debug_knob("ARDAE_SPLIT_BACKWARD", "1") != "0"
         self._side = torch.cuda.Stream(device=self.dev) if self.overlap else None
+        self.fused_draws = L.debug_knob("ARDAE_FUSED_DRAW", "1") != "0"     # sigma / eps draws inside the perturbation kernel
         self._cap_stream = torch.cuda.Stream(device=self.dev)
         self._stamps = None                             # diagnostics: see enable_stamps()
         self._log = None                                # scalar log channel (scalar_log.ScalarLog), one more launch at the end of the step
@@ -253,13 +257,13 @@ class ArdaeEngine:
             segs.append(vae_fwd)
         for i, xc in enumerate(xs):
             segs.append(("run", f"cdae_grads{i}", "main", (), lambda xc=xc, i=i: self._cdae_grads(xc, nlist[i], 3 * i)))
-            if self.world > 1:
+            if self.dp:
                 segs.append(("allreduce", self.grads_c[:self.n_c]))
             segs.append(("run", f"cdae_update{i}", "main", (), self._cdae_update))
         if not self.overlap:
             segs.append(vae_fwd)
         segs.append(("run", "vae_bwd", "main", ("vae_fwd",) if self.overlap else (), lambda: self._vae_backward_grads(x_vae, nv, beta)))
-        if self.world > 1:
+        if self.dp:
             segs.append(("allreduce", self.grads_m))
 
         def model_update():
@@ -309,7 +313,7 @@ class ArdaeEngine:
         events, out = {}, []
         for k, u in enumerate(units):
             if u[0] == "allreduce":
-                dist.allreduce_mean_(u[1], self.pg)
+                dist.allreduce_mean_(u[1], self.pg, force=self.dp)
                 out.append(None)
                 continue
             _, sname, waits, fns, record = u
@@ -368,8 +372,8 @@ class ArdaeEngine:
     def cdae_phase(self, x, noise=None, apply_update=True):
         """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z])."""
         self._cdae_grads(x, noise)
-        if self.world > 1:
-            dist.allreduce_mean_(self.grads_c[:self.n_c], self.pg)
+        if self.dp:
+            dist.allreduce_mean_(self.grads_c[:self.n_c], self.pg, force=True)
         if apply_update:
             self._cdae_update()
 
@@ -379,11 +383,16 @@ class ArdaeEngine:
         self._check_batch(x, "cdae_phase")
         cfg, lib, st = self.cfg, self.lib, L.stream_ptr()
         B, nz, z = self.B, cfg.nz_cdae, self.model.z_dim
+        nstd = int(cfg.nstd_cdae)
+        # inside a step the sigma- and eps-draws are made by the perturbation kernel itself where the shape allows (same Philox
+        # keying as the separate draws: same numbers, two launches less)
+        fused = (not noise) and self._in_step and draw0 is not None and self.fused_draws and bool(lib.ardae_latent_perturb_draw_ok(nz, nstd, z))
         if noise:
             ns, xi, eps = noise["sampler"], noise["sigma"].reshape(-1), noise["eps"]
         else:
             d = (None, None, None) if draw0 is None else (draw0, draw0 + 1, draw0 + 2)
-            ns, xi, eps = self._normal(self.noise_s, d[0]), self._normal(self.xi, d[1]), self._normal(self.eps, d[2])
+            ns = self._normal(self.noise_s, d[0])
+            xi, eps = (self.xi, self.eps) if fused else (self._normal(self.xi, d[1]), self._normal(self.eps, d[2]))
         if self.hidden_ctx:
             # aux models: hidden = model.encode.forward_hidden(x, std=0) and latent_mean = model.encode(x, std=0) are ONE std = 0 pass
             # (ivae_ardae.py:737-739,748), then the N-row pass
@@ -397,9 +406,15 @@ class ArdaeEngine:
         if self.data_ctx:
             self._data_context(x, self.ctx_c)
         self._stamp("  sampler done")
-        nstd = int(cfg.nstd_cdae)
-        L.check(lib.ardae_latent_perturb_nstd(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, nstd, z, cfg.std_scale, cfg.delta,
-                                              L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb_nstd")
+        if fused:
+            L.check(lib.ardae_latent_perturb_draw(L.ptr(self.latent), L.ptr(self.z0), B, nz, z, cfg.std_scale, cfg.delta,
+                                                  ctypes.c_uint64(rng.get_state()["seed"]), ctypes.c_uint64(d[1]), ctypes.c_uint64(d[2]),
+                                                  ctypes.c_void_p(self.state.data_ptr()), ctypes.c_uint64(self.rank * B * nz),
+                                                  L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(eps), L.ptr(self.std_b), st),
+                    "ardae_latent_perturb_draw")
+        else:
+            L.check(lib.ardae_latent_perturb_nstd(L.ptr(self.latent), L.ptr(self.z0), L.ptr(xi), L.ptr(eps), B, nz, nstd, z, cfg.std_scale, cfg.delta,
+                                                  L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(self.std_b), st), "ardae_latent_perturb_nstd")
         L.check(lib.ardae_cdae_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.xbar),
                                           L.ptr(self.sigma), L.ptr(eps), L.ptr(self.ctx_c), B, nz * nstd, L.ptr(self.ws), self.ws.numel(),
                                           L.ptr(self.loss_c), L.ptr(self.grads_c), None, st), "ardae_cdae_loss_grads")
@@ -446,8 +461,8 @@ class ArdaeEngine:
     def vae_backward_part(self, x, nv, beta=None, apply_update=True):
         """ivae_ardae.py:829-846: entropy gradient through the (updated) cDAE, backward, Adam."""
         self._vae_backward_grads(x, nv, beta)
-        if self.world > 1:
-            dist.allreduce_mean_(self.grads_m, self.pg)
+        if self.dp:
+            dist.allreduce_mean_(self.grads_m, self.pg, force=True)
         if apply_update:
             self._model_update()
 

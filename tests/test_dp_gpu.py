@@ -79,14 +79,14 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def _steps(per_rank_batch, lo, hi, graph, nsteps=5, **cfg):
+def _steps(per_rank_batch, lo, hi, graph, nsteps=5, force_dp=False, **cfg):
     """nsteps full train steps (own Philox noise, fresh images per step) on images [lo, hi) of each global batch; returns the
     flat parameters and whether the engine ended up replaying captured graphs."""
     import ardae_amd as net
     dev = torch.device("cuda", 0)
     model, cdae = _build(dev)
     net.manual_seed(99)
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ, **cfg), batch_size=per_rank_batch, graph=graph)
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ, **cfg), batch_size=per_rank_batch, graph=graph, force_dp=force_dp)
     g = torch.Generator().manual_seed(21)
     for _ in range(nsteps):
         x1 = torch.bernoulli(torch.full((B, MC.input_dim), 0.3), generator=g)
@@ -231,3 +231,31 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["value"] > 0 and d["roofline"]["kernel"]
     for k in ("cdae_loss", "model_loss"):
         assert d["losses"][k] == d["losses"][k]          # not NaN
+
+
+def _worker_rccl_one_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    pm_e, pc_e, _ = _steps(B, 0, B, graph=False, force_dp=True)
+    pm_g, pc_g, plan = _steps(B, 0, B, graph=True, force_dp=True)
+    pm_1, pc_1, plan1 = _steps(B, 0, B, graph=True)                 # the ordinary single-rank plan (no collectives)
+    torch.save({"pm_eager": pm_e, "pc_eager": pc_e, "pm_graph": pm_g, "pc_graph": pc_g, "pm_plain": pm_1, "pc_plain": pc_1, "plan": plan,
+                "plain_plan": plan1, "backend": torch.distributed.get_backend()}, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_collectives_between_the_graphs_on_one_rank(tmp_path):
+    """RCCL as far as one GPU allows: a ONE-rank `nccl` (= RCCL) process group with `force_dp=True`, so that the step runs the
+    data-parallel plan - linear graphs cut at the two gradient all-reduces, the collectives issued by torch.distributed between
+    the replays, ordered on the current stream, none of them captured.  A one-rank all-reduce is the identity, so the result must
+    equal the eager run of the same plan AND the ordinary single-rank plan, bit for bit."""
+    out = str(tmp_path / "rccl1.pt")
+    mp.spawn(_worker_rccl_one_rank, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = torch.load(out, weights_only=True)
+    assert got["backend"] == "nccl"
+    assert got["plan"] == ["graph:side", "graph:main", "allreduce", "graph:main", "graph:main", "allreduce", "graph:main"]
+    assert got["plain_plan"] == ["graph:side", "graph:main", "graph:main"]
+    for a, b in (("pm_graph", "pm_eager"), ("pc_graph", "pc_eager"), ("pm_graph", "pm_plain"), ("pc_graph", "pc_plain")):
+        assert torch.equal(got[a], got[b]), (a, b)
+    assert torch.isfinite(got["pm_graph"]).all()

@@ -492,6 +492,43 @@ def test_latent_perturb_kernels(B, nz, z):
     assert rel_l2(xbar, xbar_ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,nz,z,rank", [(5, 256, 32, 0), (8, 256, 32, 3), (4, 64, 32, 1), (6, 512, 16, 2), (3, 128, 8, 0), (64, 256, 32, 7)])
+def test_latent_perturb_with_in_kernel_draws_equals_separate_draws(B, nz, z, rank):
+    """North star: 'fused per-sample Gaussian-perturb + sigma-scaling' with the draws made in the kernel (ivae_ardae.py:761,
+    graddae/mlp.py:21-23).  ardae_latent_perturb_draw generates the Philox counters of xi and eps itself; for the same (seed,
+    offset, element) keying - including a rank's row offset into the global draws and the step state's base offset - it must
+    give BIT-IDENTICAL xbar / sigma / std_b / eps to two ardae_philox_normal_at launches followed by ardae_latent_perturb."""
+    import ctypes
+    from ardae_amd import _lib as L
+    lib = L.lib()
+    assert lib.ardae_latent_perturb_draw_ok(nz, 1, z) == 1
+    g = torch.Generator().manual_seed(B + nz + z)
+    z0 = torch.randn(B, z, generator=g).cuda()
+    latent = (z0[:, None, :].cpu() + 0.05 * torch.randn(B, nz, z, generator=g)).cuda().contiguous()
+    seed, k_xi, k_eps = 0xC0FFEE, 4, 5
+    state = torch.zeros(4, dtype=torch.int64, device="cuda")
+    L.check(lib.ardae_step_state_advance(ctypes.c_void_p(state.data_ptr()), ctypes.c_uint64(48), 1e-4, 0.5, 0.999, L.stream_ptr()))
+    first = rank * B * nz
+    xi, eps = torch.empty(B * nz, device="cuda"), torch.empty(B * nz, z, device="cuda")
+    for t, k, f in ((xi, k_xi, first), (eps, k_eps, first * z)):
+        L.check(lib.ardae_philox_normal_at(L.ptr(t), t.numel(), ctypes.c_uint64(seed), ctypes.c_uint64(k), ctypes.c_void_p(state.data_ptr()),
+                                           ctypes.c_uint64(f), L.stream_ptr()))
+    new = lambda *s: torch.full(s, float("nan"), device="cuda")
+    xbar, sigma, std_b = new(B * nz, z), new(B * nz), new(B)
+    L.check(lib.ardae_latent_perturb(L.ptr(latent), L.ptr(z0), L.ptr(xi), L.ptr(eps), B, nz, z, 1e4, 0.1, L.ptr(xbar), L.ptr(sigma), L.ptr(std_b),
+                                     L.stream_ptr()))
+    xbar2, sigma2, std_b2, eps2 = new(B * nz, z), new(B * nz), new(B), new(B * nz, z)
+    L.check(lib.ardae_latent_perturb_draw(L.ptr(latent), L.ptr(z0), B, nz, z, 1e4, 0.1, ctypes.c_uint64(seed), ctypes.c_uint64(k_xi), ctypes.c_uint64(k_eps),
+                                          ctypes.c_void_p(state.data_ptr()), ctypes.c_uint64(first), L.ptr(xbar2), L.ptr(sigma2), L.ptr(eps2), L.ptr(std_b2),
+                                          L.stream_ptr()), "ardae_latent_perturb_draw")
+    torch.cuda.synchronize()
+    assert torch.equal(eps2, eps) and torch.equal(std_b2, std_b) and torch.equal(sigma2, sigma) and torch.equal(xbar2, xbar)
+    # moments of the in-kernel draw (B nz z normals)
+    if eps2.numel() >= 100_000:
+        assert abs(float(eps2.mean())) < 4.0 / eps2.numel() ** 0.5 and abs(float(eps2.var()) - 1.0) < 0.02
+    assert lib.ardae_latent_perturb_draw_ok(625, 1, 32) == 0 and lib.ardae_latent_perturb_draw_ok(256, 3, 32) == 0     # ragged counters / nstd: separate draws
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_engine_two_cdae_updates_per_step(graph):
     """--num-cdae-updates 2 (the shipped mnist-conv / auxresconvct recipes, run_vae_dbmnist.sh): two cDAE updates on their own

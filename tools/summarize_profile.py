@@ -70,6 +70,17 @@ def main(src, dst_prefix):
             out["linear_wide_kernel<%s, %s, %s, %s, %d, %d>" % (a[0], a[1], a[2], a[3], a[4] == "true", a[5] == "true")] = out[k]
         if k.startswith("wgrad_wide_kernel<"):
             out["wgrad_wide_kernel<256x256>" if "4, 4, 2" in k else "wgrad_wide_kernel<256x32>"] = out[k]
+    # which build the counters belong to: bench.py quotes them only for a library built from the same kernel sources
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import subprocess
+    from bench import kernel_source_hash
+    try:
+        git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
+        dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "pytorch-ardae-vae_amd/csrc", "include"], capture_output=True, text=True).stdout.strip())
+    except OSError:
+        git, dirty = "?", False
+    out["_meta"] = {"git": git + ("+uncommitted kernel changes" if dirty else ""), "kernel_source_sha256": kernel_source_hash(), "source": src}
     with open(os.path.join(os.path.dirname(dst_prefix) or ".", "pmc_summary.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", dst_prefix + "_kernel_stats.csv", "and pmc_summary.json with", len(out), "kernels")
