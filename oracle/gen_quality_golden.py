@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Oracle side of the IWAE-64 quality gate at BASELINE config #2 widths (test infrastructure).
+
+    python oracle/gen_quality_golden.py [--lr 1e-3] [--steps 1000] [--every 200] [--seeds 2024 1 2] [--out tests/golden/quality_cfg2.npz]
+
+Trains the CPU oracle (the pinned restatement of ivae_ardae.py:707-846) on the synthetic four-prototype problem of
+tests/test_training_quality_gpu.py at config #2's widths (784 pixels, noise 100, h 256, z 32; cDAE mlp-grad h 256 L 3) with 32 images x 256
+Monte-Carlo rows per batch - 8192 rows, the size from which the HIP engine runs its production N-row kernels - once per noise seed, and
+records the IWAE-64 bound on 256 held-out images every `--every` steps.  The GPU test trains the engine on the SAME batches (regenerated from
+the same generator seeds) with its own Philox noise and compares the seed-averaged bounds: a CPU training of this size takes minutes per seed,
+which is why its numbers travel as a fixture and are not recomputed on the GPU box.  Stored: the settings, the per-seed / per-checkpoint
+bounds, the initial bound.  Nothing of the reference is stored.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ardae_oracle as O  # noqa: E402
+
+MC = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus")
+CC = O.CdaeCfg("grad", 32, 32, 256, 3)
+B, NZ, K, NEVAL = 32, 256, 64, 256
+
+
+def data(gen, n):
+    proto = (torch.rand(4, MC.input_dim, generator=torch.Generator().manual_seed(5)) < 0.35).float() * 0.8 + 0.1
+    idx = torch.randint(0, 4, (n,), generator=gen)
+    return torch.bernoulli(proto[idx], generator=gen)
+
+
+def eval_set():
+    x_eval = data(torch.Generator().manual_seed(999), NEVAL)
+    ge = torch.Generator().manual_seed(7)
+    return x_eval, torch.randn(NEVAL, K, MC.noise_dim, generator=ge), torch.randn(NEVAL, K, MC.z_dim, generator=ge)
+
+
+def batches(steps):
+    gen = torch.Generator().manual_seed(123)
+    return [(data(gen, B), data(gen, B)) for _ in range(steps)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--every", type=int, default=200)
+    ap.add_argument("--seeds", type=int, nargs="+", default=[2024, 1, 2])
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "quality_cfg2.npz"))
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    pm0 = O.init_params(O.model_param_spec(MC), 0, O.model_init_special(MC))
+    pc0 = O.init_params(O.cdae_param_spec(CC), 1)
+    x_eval, enc_noise, prop_noise = eval_set()
+    bs = batches(a.steps)
+    tc = O.TrainCfg(nz_cdae=NZ, m_lr=a.lr, d_lr=a.lr)
+    ll0 = float(O.iwae_logprob(MC, pm0, x_eval, K, enc_noise, prop_noise))
+    marks = list(range(a.every, a.steps + 1, a.every))
+    table = np.zeros((len(a.seeds), len(marks)))
+    for si, seed in enumerate(a.seeds):
+        pm = {k: v.clone() for k, v in pm0.items()}
+        pc = {k: v.clone() for k, v in pc0.items()}
+        st_m, st_c = {}, {}
+        gn = torch.Generator().manual_seed(seed)
+        t0 = time.time()
+        for t, (x1, x2) in enumerate(bs, 1):
+            O.train_step(MC, CC, tc, pm, pc, st_m, st_c, x1, x2, O.draw_step_noise(MC, tc, B, gn))
+            if t in marks:
+                table[si, marks.index(t)] = float(O.iwae_logprob(MC, pm, x_eval, K, enc_noise, prop_noise))
+                print(f"seed {seed} step {t}: IWAE-{K} {table[si, marks.index(t)]:.3f}  ({time.time() - t0:.0f} s)", flush=True)
+    print("init", ll0, "\n", table)
+    np.savez(a.out, lr=a.lr, steps=a.steps, marks=np.array(marks), seeds=np.array(a.seeds), iwae=table, iwae_init=ll0, B=B, NZ=NZ, K=K)
+
+
+if __name__ == "__main__":
+    main()

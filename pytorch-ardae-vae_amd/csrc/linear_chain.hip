@@ -16,7 +16,12 @@ bool al16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // most row tiles per workgroup for which one launch per chain beats one launch per layer (per-layer launches amortise their
 // fixed cost over the tiles and keep the NEXT tile's panel loads in flight; the chain kernel pays an exposed input load per tile)
 int chain_max_tiles() {
-  static const int v = debug_knob("ARDAE_CHAIN_MAX_TILES") ? atoi(debug_knob("ARDAE_CHAIN_MAX_TILES")) : 512;
+  static const int v = debug_knob("ARDAE_CHAIN_MAX_TILES") ? atoi(debug_knob("ARDAE_CHAIN_MAX_TILES")) : 1024;
+  return v;
+}
+// ... and for the chains whose last layer stages the next tile (EPI_ACT, EPI_DACT without Q: linear_chain_kernel's PF)
+int chain_pf_max_tiles() {
+  static const int v = debug_knob("ARDAE_CHAIN_PF_MAX_TILES") ? atoi(debug_knob("ARDAE_CHAIN_PF_MAX_TILES")) : 1024;
   return v;
 }
 }  // namespace
@@ -27,7 +32,8 @@ int chain_max_tiles() {
 bool linear_chain_eligible(const LinArgs* L, int nl, int epi) {
   if (nl < 2 || nl > CH_MAXL || !(epi == EPI_ACT || epi == EPI_DACT || epi == EPI_CHAIN)) return false;
   const int M = L[0].M;
-  if (M <= 0 || (M % WBM) || M / WBM < 128 || M / WBM > chain_max_tiles()) return false;
+  const bool pf = epi == EPI_ACT || (epi == EPI_DACT && L[0].Q == nullptr);
+  if (M <= 0 || (M % WBM) || M / WBM < 128 || M / WBM > (pf ? std::max(chain_pf_max_tiles(), chain_max_tiles()) : chain_max_tiles())) return false;
   for (int l = 0; l < nl; ++l) {
     const LinArgs& a = L[l];
     if (!linear_wide_eligible(a, epi)) return false;

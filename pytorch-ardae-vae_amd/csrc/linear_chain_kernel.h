@@ -62,24 +62,39 @@ struct ChainCtx {
   const PrevOut& prev;
   unsigned raddr;           // fragment base of the tile set this layer reads
   unsigned bvoff;           // lane * 16
-  const float* wnext;       // next layer's slab of this wave (HN)
+  const float* wnext;       // next layer's slab of this wave (HN) / the first layer's again (NT)
   int kch;
   int row0, colw;
+  // NT (last layer of a tile, another tile follows): the next tile's input panels travel HBM -> registers -> the free tile set
+  const i32x4& rX;
+  unsigned xvoff, xstep, xsoff_next, wfree;
 };
 
 // One chunk of a chain layer's K loop: 16 MFMAs with, spread behind them,
 //   2 fragment reads A(g + 1) | 2 slab reloads of chunk g - 1 (next layer) | deferred stores of the PREVIOUS layer
 //   | 2 row-bias loads | epilogue-operand loads of THIS layer
 // PNST: tensors the previous layer stores per element (0: first layer of a chain); HN: there is a next layer.
-template <int GC, bool HN, int PNST, class EPI_T>
+template <int GC, bool HN, bool NT, int PNST, class EPI_T>
 struct ChainChunk {
-  static constexpr int NLT = EPI_T::NLT, NJ = CH_NJ, NMF = 8 * CH_NJ;
+  static constexpr int NLT = EPI_T::NLT, NJ = CH_NJ, NMF = 8 * CH_NJ, NX = PanelGeo<CH_NCH>::NX;
   using SC = Sched<CH_NCH, CH_NP, CH_NJ, NLT, (PNST > 0 ? PNST : 1), (PNST > 0)>;
   static constexpr int C = GC % CH_NCH, P = GC / CH_NCH;
-  static constexpr int n_a = GC + 1 < CH_G ? 2 : 0, n_sl = (HN && GC >= 1) ? 2 : 0, n_st = SC::st_hi(GC) - SC::st_lo(GC), n_rb = SC::n_rb(GC),
-                       n_op = SC::ld_hi(GC) - SC::ld_lo(GC);
-  static constexpr int o_a = 0, o_sl = o_a + n_a, o_st = o_sl + n_sl, o_rb = o_st + n_st, o_op = o_rb + n_rb, total = o_op + n_op;
+  static constexpr bool RS = HN || NT;                         // the slab is reloaded behind the MFMAs (next layer's / the first layer's)
+  static constexpr int XW = CH_NCH - 3;                        // chunk of a panel that moves the prefetched panel to LDS
+  static constexpr int n_a = GC + 1 < CH_G ? 2 : 0, n_sl = (RS && GC >= 1) ? 2 : 0, n_x = (NT && C == 0) ? NX : 0, n_w = (NT && C == XW) ? NX : 0,
+                       n_st = SC::st_hi(GC) - SC::st_lo(GC), n_rb = SC::n_rb(GC), n_op = SC::ld_hi(GC) - SC::ld_lo(GC);
+  static constexpr int o_a = 0, o_sl = o_a + n_a, o_x = o_sl + n_sl, o_w = o_x + n_x, o_st = o_w + n_w, o_rb = o_st + n_st, o_op = o_rb + n_rb,
+                       total = o_op + n_op;
   static constexpr int PER = (total + NMF - 1) / NMF;
+  // vector-memory operations of chunk g besides the panel loads; those younger than the panel loads of chunk (P, 0) when chunk (P, XW)
+  // moves them to LDS (vmcnt retires in order, so capping at 63 only waits longer)
+  static constexpr int vmem_rest(int g) { return (SC::st_hi(g) - SC::st_lo(g)) + SC::n_rb(g) + (SC::ld_hi(g) - SC::ld_lo(g)); }
+  static constexpr int vm_panel() {
+    int n = vmem_rest(P * CH_NCH);
+    for (int k = 1; k < XW; ++k) n += vmem_rest(P * CH_NCH + k) + 2;
+    n += 2;
+    return n > 63 ? 63 : n;
+  }
 
   using Ctx = ChainCtx<EPI_T>;
   struct Ptrs {
@@ -87,14 +102,22 @@ struct ChainChunk {
   };
 
   template <int K>
-  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x2* l0, f32x2* l1, float (&rb)[CH_NJ], const Ctx& x, Ptrs& q) {
+  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[CH_NJ], const Ctx& x,
+                                            Ptrs& q) {
     const EPI_T& ep = x.epi;
     if constexpr (K < o_sl) {   // fragments of the next chunk (panels are contiguous: one base, compile-time offsets)
       constexpr int i = K - o_a, G1 = GC + 1;
       lds_read4<(G1 / CH_NCH) * WBUF_BYTES + (G1 % CH_NCH) * 32 + i * 32 * WLDW * 4>(A[G1 & 1][i], x.raddr);
-    } else if constexpr (K < o_st) {
+    } else if constexpr (K < o_x) {
       constexpr int j = K - o_sl;
       gload4_agpr_again(Bw[GC - 1][j], x.bvoff, x.wnext + ((size_t)j * x.kch + (GC - 1)) * 256);
+    } else if constexpr (K < o_w) {   // panel P of the NEXT tile's input
+      constexpr int u = K - o_x;
+      bload4<0>(xv[u], x.xvoff, x.rX, x.xsoff_next + (unsigned)(P * 256) + (unsigned)u * x.xstep);
+    } else if constexpr (K < o_st) {
+      constexpr int u = K - o_w;
+      if constexpr (u == 0) wait_panel<vm_panel(), NX>(xv);
+      lds_write4<P * WBUF_BYTES + u * PanelGeo<CH_NCH>::RPP * WLDW * 4>(x.wfree, xv[u]);
     } else if constexpr (K < o_rb) {
       constexpr int idx = SC::st_lo(GC) + (K - o_st), PN = PNST > 0 ? PNST : 1;
       constexpr int HB = idx / (8 * PN), tns = (idx / 8) % PN, e = idx % 8;
@@ -136,38 +159,39 @@ struct ChainChunk {
   }
 
   template <int S, int R = 0>
-  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x2* l0, f32x2* l1, float (&rb)[CH_NJ], const Ctx& x, Ptrs& q) {
+  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[CH_NJ], const Ctx& x,
+                                              Ptrs& q) {
     if constexpr (R < PER && S * PER + R < total) {
-      op<S * PER + R>(A, Bw, l0, l1, rb, x, q);
-      slot<S, R + 1>(A, Bw, l0, l1, rb, x, q);
+      op<S * PER + R>(A, Bw, xv, l0, l1, rb, x, q);
+      slot<S, R + 1>(A, Bw, xv, l0, l1, rb, x, q);
     }
   }
 
   template <int S>
-  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][CH_NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x2* l0, f32x2* l1, float (&rb)[CH_NJ],
-                                               const Ctx& x, Ptrs& q) {
+  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][CH_NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
+                                               float (&rb)[CH_NJ], const Ctx& x, Ptrs& q) {
     if constexpr (S < NMF) {
       constexpr int kq = S / (2 * NJ), i = (S / NJ) & 1, j = S % NJ;
       mfma_vab<GC == 0 && kq == 0, GC == CH_G - 1 && S == NMF - 1>(acc[i][j], A[GC & 1][i][kq], Bw[GC][j][kq]);
-      slot<S>(A, Bw, l0, l1, rb, x, q);
-      steps<S + 1>(acc, A, Bw, l0, l1, rb, x, q);
+      slot<S>(A, Bw, xv, l0, l1, rb, x, q);
+      steps<S + 1>(acc, A, Bw, xv, l0, l1, rb, x, q);
     }
   }
 
-  static __device__ __forceinline__ void run(f32x16 (&acc)[2][CH_NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x2* l0, f32x2* l1, float (&rb)[CH_NJ],
-                                             const Ctx& x) {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2][CH_NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
+                                             float (&rb)[CH_NJ], const Ctx& x) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[GC & 1][0]), "+v"(A[GC & 1][1]) : : "memory");   // this chunk's fragments have landed
     Ptrs q{0u, 0u, 0u, 0u};
-    steps<0>(acc, A, Bw, l0, l1, rb, x, q);
+    steps<0>(acc, A, Bw, xv, l0, l1, rb, x, q);
   }
 };
 
-template <int GC, bool HN, int PNST, class EPI_T>
-__device__ __forceinline__ void chain_chunks(f32x16 (&acc)[2][CH_NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x2* l0, f32x2* l1, float (&rb)[CH_NJ],
-                                             const ChainCtx<EPI_T>& x) {
+template <int GC, bool HN, bool NT, int PNST, class EPI_T>
+__device__ __forceinline__ void chain_chunks(f32x16 (&acc)[2][CH_NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[CH_G][CH_NJ], f32x4 (&xv)[PanelGeo<CH_NCH>::NX], f32x2* l0,
+                                             f32x2* l1, float (&rb)[CH_NJ], const ChainCtx<EPI_T>& x) {
   if constexpr (GC < CH_G) {
-    ChainChunk<GC, HN, PNST, EPI_T>::run(acc, A, Bw, l0, l1, rb, x);
-    chain_chunks<GC + 1, HN, PNST, EPI_T>(acc, A, Bw, l0, l1, rb, x);
+    ChainChunk<GC, HN, NT, PNST, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
+    chain_chunks<GC + 1, HN, NT, PNST, EPI_T>(acc, A, Bw, xv, l0, l1, rb, x);
   }
 }
 
@@ -214,52 +238,64 @@ __global__ __launch_bounds__(256, 1) void linear_chain_kernel(const ChainArgs ca
 #pragma unroll
   for (int i = 0; i < 16 * CH_NJ; ++i) l0[i] = l1[i] = f32x2{0.f, 0.f};
 
+  const LinArgs& a0 = ca.L[0];
+  const unsigned ldx4 = (unsigned)a0.src[0].ld * 4u;
+  const i32x4 rX = make_rsrc(a0.src[0].x, (unsigned)a0.M * ldx4);
+  const unsigned xvoff = (unsigned)(tid / PG::C4) * ldx4 + (unsigned)(tid % PG::C4) * 16u;
+  const unsigned xstep = (unsigned)PG::RPP * ldx4;
+  // PF: the last layer of a tile prefetches the NEXT tile's input and the first layer's slab behind its MFMAs (16 more VGPRs: only the
+  // epilogues whose register budget has them - the others pay an exposed input load per tile)
+  constexpr bool PF = EPI == EPI_ACT || (EPI == EPI_DACT && !FQ);
+  int tpar = 0;                 // layer l of this tile reads tile set (l + tpar) & 1
+  // the chain's input tile (four panels) into tile set tpar and the first layer's slab into the AGPRs, latency exposed: once per
+  // launch with PF (every later tile is staged by its predecessor's last layer), once per tile without.  No branches around it:
+  // values defined by the asm loads must not meet other definitions at a control-flow join (see linear_wide_kernel)
+  auto stage = [&](int row0) {
+    f32x4 xv[CH_NP][NX];
+#pragma unroll
+    for (int p = 0; p < CH_NP; ++p)
+#pragma unroll
+      for (int u = 0; u < NX; ++u) bload4<0>(xv[p][u], xvoff, rX, (unsigned)row0 * ldx4 + (unsigned)p * 256u + (unsigned)u * xstep);
+    const float* wp = a0.src[0].wp + (size_t)(wave * CH_NJ) * kch * 256;
+#pragma unroll
+    for (int g = 0; g < CH_G; ++g) {
+      gload4_agpr_again(Bw[g][0], bvoff, wp + (size_t)g * 256);
+      gload4_agpr_again(Bw[g][1], bvoff, wp + ((size_t)kch + g) * 256);
+    }
+    // the panels are older than the slab: landed when at most the slab loads are outstanding (vmcnt tops out at 63)
+#pragma unroll
+    for (int p = 0; p < CH_NP; ++p) {
+      wait_panel<63, NX>(xv[p]);
+      store_panel<CH_NCH, NX>(xv[p], wlane + (unsigned)(tpar & 1) * CH_SET_BYTES + (unsigned)p * WBUF_BYTES);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  if constexpr (PF) stage((int)blockIdx.x * WBM);
   for (int tile = (int)blockIdx.x; tile < nrt; tile += (int)gridDim.x) {
     const int row0 = tile * WBM;
-    // ---- the chain's input tile (four panels) and the first layer's slab
-    {
-      const LinArgs& a0 = ca.L[0];
-      const unsigned ldx4 = (unsigned)a0.src[0].ld * 4u;
-      const i32x4 rX = make_rsrc(a0.src[0].x, (unsigned)a0.M * ldx4);
-      const unsigned xvoff = (unsigned)(tid / PG::C4) * ldx4 + (unsigned)(tid % PG::C4) * 16u;
-      const unsigned xstep = (unsigned)PG::RPP * ldx4;
-      f32x4 xv[CH_NP][NX];
-#pragma unroll
-      for (int p = 0; p < CH_NP; ++p)
-#pragma unroll
-        for (int u = 0; u < NX; ++u) bload4<0>(xv[p][u], xvoff, rX, (unsigned)row0 * ldx4 + (unsigned)p * 256u + (unsigned)u * xstep);
-      const float* wp = a0.src[0].wp + (size_t)(wave * CH_NJ) * kch * 256;
-#pragma unroll
-      for (int g = 0; g < CH_G; ++g) {
-        gload4_agpr_again(Bw[g][0], bvoff, wp + (size_t)g * 256);
-        gload4_agpr_again(Bw[g][1], bvoff, wp + ((size_t)kch + g) * 256);
-      }
-      // the panels are older than the slab: landed when at most the slab loads are outstanding (vmcnt tops out at 63)
-#pragma unroll
-      for (int p = 0; p < CH_NP; ++p) {
-        wait_panel<63, NX>(xv[p]);
-        store_panel<CH_NCH, NX>(xv[p], wlane + (unsigned)p * WBUF_BYTES);
-      }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    const bool more = tile + (int)gridDim.x < nrt;
+    if constexpr (!PF) stage(row0);
     PrevOut prev{};
     // one layer: K loop (+ the previous layer's stores, this layer's operands, the next layer's slab), epilogue, hand-over
-    auto layer = [&](auto epi_tag, auto hn_tag, auto pnst_tag, int l) {
+    auto layer = [&](auto epi_tag, auto hn_tag, auto nt_tag, auto pnst_tag, int l) {
       using EPI_T = typename decltype(epi_tag)::type;
-      constexpr bool HN = decltype(hn_tag)::value;
+      constexpr bool HN = decltype(hn_tag)::value, NT = decltype(nt_tag)::value;
       constexpr int PNST = decltype(pnst_tag)::value;
       const LinArgs& a = ca.L[l];
       EPI_T epi(a, lane);
       epi.column_operands(colw, lane);
-      const unsigned rset = rlane + (unsigned)(l & 1) * CH_SET_BYTES;
+      const unsigned rset = rlane + (unsigned)((l + tpar) & 1) * CH_SET_BYTES;
       lds_read4<0>(A[0][0], rset);
       lds_read4<32 * WLDW * 4>(A[0][1], rset);
-      const float* wnext = HN ? ca.L[l + 1].src[0].wp + (size_t)(wave * CH_NJ) * kch * 256 : a.src[0].wp;
+      const float* wnext = (HN ? ca.L[l + 1].src[0].wp : a0.src[0].wp) + (size_t)(wave * CH_NJ) * kch * 256;
       f32x16 acc[2][CH_NJ];
-      const ChainCtx<EPI_T> x{epi, prev, rset, bvoff, wnext, kch, row0, colw};
-      chain_chunks<0, HN, PNST, EPI_T>(acc, A, Bw, l0, l1, rb, x);
-      if constexpr (HN) {   // the last chunk's fragment of the next slab
+      f32x4 xv[NX];
+      // (no next tile: the staging loads re-touch this tile's rows and are never used)
+      const ChainCtx<EPI_T> x{epi, prev, rset, bvoff, wnext, kch, row0, colw, rX, xvoff, xstep, (unsigned)(more ? row0 + (int)gridDim.x * WBM : row0) * ldx4,
+                              wlane + (unsigned)((l + 1 + tpar) & 1) * CH_SET_BYTES};
+      chain_chunks<0, HN, NT, PNST, EPI_T>(acc, A, Bw, xv, l0, l1, rb, x);
+      if constexpr (HN || NT) {   // the last chunk's fragment of the next slab
         gload4_agpr_again(Bw[CH_G - 1][0], bvoff, wnext + (size_t)(CH_G - 1) * 256);
         gload4_agpr_again(Bw[CH_G - 1][1], bvoff, wnext + ((size_t)kch + CH_G - 1) * 256);
       }
@@ -271,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void linear_chain_kernel(const ChainArgs ca
       epi.template run<0, !HN>(acc, l0, l1, rb, lane, row0, colw, tile);
       if constexpr (HN) {
         // the result is the next layer's input: accumulator layout -> A image of the other tile set (panel = this wave)
-        hand_over<0, CH_NJ>(l0, hlane + (unsigned)((l + 1) & 1) * CH_SET_BYTES);
+        hand_over<0, CH_NJ>(l0, hlane + (unsigned)((l + 1 + tpar) & 1) * CH_SET_BYTES);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         prev.rY = epi.rY; prev.rY2 = epi.rY2; prev.vY = epi.vY; prev.vY2 = epi.vY2; prev.sY = epi.sY; prev.sY2 = epi.sY2;
@@ -279,10 +315,11 @@ __global__ __launch_bounds__(256, 1) void linear_chain_kernel(const ChainArgs ca
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    layer(TypeTag<EPI_FIRST>{}, T_{}, std::integral_constant<int, 0>{}, 0);
-    for (int l = 1; l + 1 < nl; ++l) layer(TypeTag<EPI_MID>{}, T_{}, std::integral_constant<int, NST_MID>{}, l);
-    layer(TypeTag<EPI_LAST>{}, F_{}, std::integral_constant<int, NST_MID>{}, nl - 1);
-    if (tile + (int)gridDim.x < nrt) {   // another tile: everybody is done with the tile sets before they are refilled
+    layer(TypeTag<EPI_FIRST>{}, T_{}, F_{}, std::integral_constant<int, 0>{}, 0);
+    for (int l = 1; l + 1 < nl; ++l) layer(TypeTag<EPI_MID>{}, T_{}, F_{}, std::integral_constant<int, NST_MID>{}, l);
+    layer(TypeTag<EPI_LAST>{}, F_{}, std::integral_constant<bool, PF>{}, std::integral_constant<int, NST_MID>{}, nl - 1);
+    if constexpr (PF) tpar = (tpar + nl) & 1;   // the free set of the last layer is where the next tile starts
+    if (more) {   // another tile: everybody is done with the tile sets (and the prefetched panels are in place) before they are used
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }

@@ -903,3 +903,83 @@ def test_auxconv_nrow_sampler_fused_two_head_tail_vs_oracle(B, nz):
     assert z.shape == (B, nz, mc.z_dim)
     assert rel_l2(z.reshape(B * nz, -1), ref) < 2e-5
     assert float((z.reshape(B * nz, -1).cpu() - ref).abs().max()) < 1e-3
+
+
+def _oracle_opt_state(ckpt, names, keys):
+    """torch.optim-style per-parameter state of an engine checkpoint -> the oracle's {name: {...}} form."""
+    out = {}
+    for i, n in enumerate(names):
+        if i in ckpt["optimizer"]["state"]:
+            s = ckpt["optimizer"]["state"][i]
+            out[n] = dict({"step": int(s["step"])}, **{k: s[k].detach().cpu().clone() for k in keys})
+    return out
+
+
+@pytest.mark.parametrize("kind", ["mnist", "toy"])
+def test_engine_trajectory_production_shapes_vs_live_oracle(kind):
+    """Twenty consecutive train steps at PRODUCTION kernel shapes (32 images x 256 samples = 8192 rows: software-pipelined N-row
+    kernels, 256 x 256 / 256 x 32 weight gradients), every step against the live oracle.
+
+      mnist: BASELINE config #2 - MNISTIPVAE 784 / 100 / h 256 / z 32 + mlp-grad h 256 L 3 (models/ivae/mnist.py, graddae/mlp.py)
+      toy:   BASELINE config #1 - ToyIPVAE z 2, relu, ContextConcatMLP sampler (two-source 266-wide layers, models/layers.py:681-724),
+             cDAE first layers with K = 2
+
+    The oracle is TEACHER-FORCED: before every step it takes the engine's parameters and optimiser state (RMSprop square_avg /
+    momentum_buffer, Adam exp_avg / exp_avg_sq / step - through the reference-format checkpoint dicts), runs the same step with the same
+    images and the same injected noise, and the two are compared: losses at 1e-4 relative (north star; measured 5e-7), recon / prior 2e-5,
+    and the parameter UPDATE of that step.  Only the very first update is sign-like (RMSprop / Adam normalise a gradient at the fp32
+    noise floor to a full-size step: relative L2 2.5-4e-2 at step 0, the median element still agrees to 1e-6); once the second-moment
+    estimates carry history the update is continuous in the gradient: from step 1 on the relative L2 of the update must be below 1e-2
+    (measured at steps 1 / 5 / 10 / 15 / 19: model 4e-4 ... 8e-6, cDAE 2e-3 (mnist) / 2-5e-4 (toy) - the cDAE's is its gradient
+    error, cf. test_cdae_gpu.py; about 3 % of the cDAE's elements, those whose gradient is fp32 noise, still differ by more than 1e-2
+    of their own tiny update, which is why the element-wise criterion of assert_update_close is used for step 0 only).  A free-running
+    comparison would only measure how chaotic the training dynamics are (the toy problem's loss swings 22 -> 347 -> 42 in its first
+    steps): after 20 steps the free-running oracle's cDAE loss differs by 0.2 % (mnist) / 5 % (toy) while every single step agrees to 1e-7."""
+    if kind == "mnist":
+        mc, cc = O.ModelCfg("mnist", 784, 100, 256, 32, 2, "softplus"), O.CdaeCfg("grad", 32, 32, 256, 3)
+    else:
+        mc, cc = O.ModelCfg("toy", 2, 10, 256, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 256, 3)
+    B, NZ, STEPS = 32, 256, 20
+    tc = O.TrainCfg(nz_cdae=NZ)
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc))
+    pc = O.init_params(O.cdae_param_spec(cc), 1)
+    gen = torch.Generator().manual_seed(11)
+
+    def batch():
+        if kind == "mnist":
+            return torch.bernoulli(torch.full((B, 784), 0.2), generator=gen)
+        return torch.randn(B, 2, generator=gen) * 0.3 + torch.randint(-2, 3, (B, 2), generator=gen).float() * 2      # the 25-Gaussians grid
+
+    model, cdae = build(mc, cc)
+    model.load_state_dict(pm); cdae.load_state_dict(pc)
+    model, cdae = model.to("cuda"), cdae.to("cuda")
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=B)
+    mnames, cnames = [n for n, _ in O.model_param_spec(mc)], [n for n, _ in O.cdae_param_spec(cc)]
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    worst = {"loss": 0.0, "late_m": 0.0, "late_c": 0.0}
+    for t in range(STEPS):
+        x1, x2, noise = batch(), batch(), O.draw_step_noise(mc, tc, B, gen)
+        mck, cck = eng.model_checkpoint(), eng.cdae_checkpoint()
+        rm = {n: mck["state_dict"][n].detach().cpu().clone() for n in mnames}
+        rc = {n: cck["state_dict"][n].detach().cpu().clone() for n in cnames}
+        st_m = _oracle_opt_state(mck, mnames, ("exp_avg", "exp_avg_sq"))
+        st_c = _oracle_opt_state(cck, cnames, ("square_avg", "momentum_buffer"))
+        before_m = torch.cat([rm[n].reshape(-1) for n in mnames]); before_c = torch.cat([rc[n].reshape(-1) for n in cnames])
+        eng.step(x1.cuda(), x2.cuda(), noise={k: v.cuda().contiguous() for k, v in noise.items()})
+        got = eng.stats()
+        ref = O.train_step(mc, cc, tc, rm, rc, st_m, st_c, x1, x2, noise)
+        for k in ("cdae_loss", "model_loss"):
+            assert rel(got[k], ref[k]) < 1e-4, (t, k, got[k], float(ref[k]))
+            worst["loss"] = max(worst["loss"], rel(got[k], ref[k]))
+        for k in ("recon", "prior"):
+            assert rel(got[k], ref[k]) < 2e-5, (t, k)
+        after_m, after_c = model.flat_params().cpu(), cdae.flat_params().cpu()
+        ref_m = torch.cat([rm[n].reshape(-1) for n in mnames]); ref_c = torch.cat([rc[n].reshape(-1) for n in cnames])
+        if t >= 1:       # the optimisers' second moments carry history: the update is continuous in the gradient
+            um, uc = rel_l2(after_m - before_m, ref_m - before_m), rel_l2((after_c - before_c)[:-1], (ref_c - before_c)[:-1])
+            worst["late_m"], worst["late_c"] = max(worst["late_m"], um), max(worst["late_c"], uc)
+            assert um < 1e-2 and uc < 1e-2, (t, um, uc)
+        else:            # the very first step: sign-like updates (median element + loose L2, see assert_update_close)
+            assert_update_close(after_c[:-1], before_c[:-1], ref_c[:-1], f"cdae update, step {t}")
+            assert_update_close(after_m, before_m, ref_m, f"model update, step {t}")
+    print(f"{kind}: worst loss error {worst['loss']:.1e}, worst late-step update error model {worst['late_m']:.1e} cdae {worst['late_c']:.1e}")
