@@ -29,6 +29,7 @@ int wide_panels(const LinArgs& a, int& nch, int& nj) {
   if (a.src[0].K == 256) { nch = 8; nj = 2; return 4; }
   if (a.src[0].K == 32) { nch = 4; nj = 2; return 1; }
   if (a.src[0].K == 512) { nch = 8; nj = 1; return 8; }
+  if (a.src[0].K == 1024) { nch = 8; nj = 1; return 16; }   // rolling slab window (instantiated for config #5's epilogues only: linear_wide_eligible)
   return 0;
 }
 
@@ -36,6 +37,10 @@ template <int EPI, int ACT, bool F1, bool F2>
 int launch_wide_nch(const LinArgs& a, hipStream_t st) {
   int nch = 0, nj = 0;
   const int np = wide_panels(a, nch, nj);
+  if (np == 16) {
+    if constexpr (ACT == ACT_SOFTPLUS && !F1 && (EPI == EPI_ACT || (EPI == EPI_DACT && !F2))) return launch_wide<8, 16, 1, EPI, ACT, F1, F2>(a, st);
+    ARDAE_CHECK_ARG(false, "linear_wide: K = 1024 is instantiated for softplus ACT / DACT-without-Q epilogues only");
+  }
   if (np == 8) return launch_wide<8, 8, 1, EPI, ACT, F1, F2>(a, st);
   if (nch == 4) return launch_wide<4, 1, 2, EPI, ACT, F1, F2>(a, st);
   return launch_wide<8, 4, 2, EPI, ACT, F1, F2>(a, st);
@@ -70,6 +75,10 @@ bool linear_wide_eligible(const LinArgs& a, int epi) {
     if ((int64_t)a.src[s].ld * a.M * 4 >= (int64_t)1 << 32) return false;   // 32-bit buffer offsets
   }
   if (epi == EPI_DAE_LOSS) return false;   // Nout = z_dim there (narrow geometry)
+  if (a.src[0].K == 1024) {               // the instantiated K = 1024 epilogues: softplus forward layers (no score seed), DACT without Q
+    if (a.act != ACT_SOFTPLUS) return false;
+    if (!((epi == EPI_ACT && !a.Y2) || (epi == EPI_DACT && !a.Q))) return false;
+  }
   // instantiated for the activations of the shipped recipes; elu / tanh / leaky_relu layers run on the generic kernel
   if (a.act != ACT_NONE && a.act != ACT_RELU && a.act != ACT_SOFTPLUS) return false;
   if (epi == EPI_CHAIN && a.act != ACT_SOFTPLUS) return false;

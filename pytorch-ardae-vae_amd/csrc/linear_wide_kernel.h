@@ -177,10 +177,18 @@ __device__ __forceinline__ void mfma_vab(f32x16& acc, float a, float b) {
 // (NJ = 32-column blocks per wave: 2 for K <= 256, 1 for K = 512 - the wave's slab is 32 NJ columns x K = at most 256 registers)
 // Stores come first (chunks [0, GS)), operand loads after them (chunks [GS, GE)), in half-block order, into the registers
 // the stores have just read; the last GE .. G chunks carry none, so that the last operand has landed when the K loop ends.
+// chunks of the weight slab the AGPR file holds at a time (all of them, or a rolling window of 64 / NJ: see Sched::ROLL)
+constexpr int wide_slots(int NCH, int NP, int NJ) { return (NJ * NCH * NP * 4 <= 256) ? NCH * NP : 64 / NJ; }
+
 template <int NCH, int NP, int NJ, int NLT, int NST, bool HP>
 struct Sched {
   static constexpr int NX = PanelGeo<NCH>::NX;
   static constexpr int G = NP * NCH;
+  // ROLL (K = 1024: the slab, 32 NJ columns x K, is twice the AGPR file): the AGPRs hold a WINDOW of SLOTS chunks; chunk g reads slot
+  // g % SLOTS and, one chunk later, that slot is reloaded with chunk g + SLOTS's fragment (of this tile's second half, or the next
+  // tile's first) - NJ loads per chunk behind the MFMAs, as linear_chain_kernel reloads its next layer's slab
+  static constexpr int SLOTS = wide_slots(NCH, NP, NJ);
+  static constexpr bool ROLL = SLOTS < G;
   static constexpr bool DEFER = NP >= 2;                       // with a single panel per tile the epilogue stores at once
   static constexpr int NSTO = (DEFER && HP) ? 32 * NJ * NST : 0;    // HP: there is a previous tile whose results wait in registers
   static constexpr int NLD = 32 * NJ * NLT;
@@ -194,7 +202,8 @@ struct Sched {
   static constexpr int ld_lo(int g) { return g < GS ? 0 : g >= GE ? NLD : NLD * (g - GS) / DL; }
   static constexpr int ld_hi(int g) { return g < GS ? 0 : g >= GE ? NLD : NLD * (g - GS + 1) / DL; }
   static constexpr int n_rb(int g) { return g == GRB ? NJ : 0; }
-  static constexpr int vmem(int g) { return (st_hi(g) - st_lo(g)) + n_rb(g) + (ld_hi(g) - ld_lo(g)); }   // without the panel loads
+  static constexpr int n_sl(int g) { return ROLL ? NJ : 0; }   // slab-window reloads (chunk g reloads the slot of chunk g - 1)
+  static constexpr int vmem(int g) { return (st_hi(g) - st_lo(g)) + n_rb(g) + (ld_hi(g) - ld_lo(g)) + n_sl(g); }   // without the panel loads
   // vector-memory operations younger than the panel loads of chunk (p, 0) when chunk (p, XW) moves them to LDS
   static constexpr int vm_panel(int p) {
     int n = 0;
@@ -205,7 +214,8 @@ struct Sched {
   // slab fragment of chunk g = (p, c) when that chunk starts.  vmcnt retires in order, so capping at 63 only waits longer.
   static constexpr int vm_slab(int p, int c) {
     const int g = p * NCH + c;
-    int n = (G - 1 - g) * NJ + NX * (c > 0 ? p + 1 : p);
+    int n = ((ROLL ? SLOTS : G) - 1 - g) * NJ + NX * (c > 0 ? p + 1 : p);
+    if (n < 0) n = 0;
     for (int k = 0; k < g; ++k) n += vmem(k);
     return n > 63 ? 63 : n;
   }
@@ -382,6 +392,9 @@ struct PanelCtx {
   unsigned xvoff, xstep, xsoff_next;     // per-lane offset, bytes between the NX row groups of a panel, scalar offset of the NEXT panel
   unsigned raddr, raddr_next, waddr_next;
   int row0, colw, prev_row0;             // prev_row0 < 0: no previous tile (nothing to store yet)
+  const float* wslab;                    // ROLL: this wave's slab in the packed image (chunk-major), lane part in bvoff
+  unsigned bvoff;
+  int kch;
 };
 
 // One chunk: wait for its A fragments (LDS), then 8 NJ MFMAs with the chunk's memory instructions spread evenly behind them
@@ -394,8 +407,10 @@ struct ChunkOps {
   static constexpr int NLT = EPI_T::NLT, NST = EPI_T::NST, NJ = EPI_T::NJ, NMF = 8 * EPI_T::NJ;   // NMF: MFMAs per chunk
   static constexpr int GC = P * NCH + C;
   static constexpr int n_a = 2, n_x = C == 0 ? NX : 0, n_w = C == SC::XW ? NX : 0, n_st = SC::st_hi(GC) - SC::st_lo(GC), n_rb = SC::n_rb(GC),
-                       n_op = SC::ld_hi(GC) - SC::ld_lo(GC);
-  static constexpr int o_a = 0, o_x = o_a + n_a, o_w = o_x + n_x, o_st = o_w + n_w, o_rb = o_st + n_st, o_op = o_rb + n_rb, total = o_op + n_op;
+                       n_op = SC::ld_hi(GC) - SC::ld_lo(GC), n_sl = SC::n_sl(GC);
+  static constexpr int o_a = 0, o_x = o_a + n_a, o_w = o_x + n_x, o_st = o_w + n_w, o_rb = o_st + n_st, o_op = o_rb + n_rb, o_sl = o_op + n_op,
+                       total = o_sl + n_sl;
+  static constexpr int SLOTS = SC::SLOTS;
   static constexpr int PER = (total + NMF - 1) / NMF;   // instructions behind each MFMA
 
   // running scalar byte offsets of the store / operand streams (bumped by one row per instruction)
@@ -404,10 +419,14 @@ struct ChunkOps {
   };
 
   template <int K>
-  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
+  static __device__ __forceinline__ void op(f32x4 (&A)[2][2], f32x4 (&Bw)[SC::SLOTS][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[EPI_T::NJ],
+                                            const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     using PG = PanelGeo<NCH>;
     const EPI_T& ep = x.epi;
-    if constexpr (K < o_x) {   // fragment read of the next chunk (chunk 0 of the next panel after the last one)
+    if constexpr (K >= o_sl) {   // ROLL: the slot chunk GC - 1 has just read gets the fragment SLOTS chunks ahead (wrapping into the next tile)
+      constexpr int j = K - o_sl, GP = (GC + SC::G - 1) % SC::G, GN = (GP + SLOTS) % SC::G;
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+a"(Bw[GP % SLOTS][j]) : "v"(x.bvoff), "s"(x.wslab + ((size_t)j * x.kch + GN) * 256) : "memory");
+    } else if constexpr (K < o_x) {   // fragment read of the next chunk (chunk 0 of the next panel after the last one)
       constexpr int i = K - o_a;
       if constexpr (C + 1 < NCH) lds_read4<(C + 1) * 32 + i * 32 * WLDW * 4>(A[(C + 1) & 1][i], x.raddr);
       else lds_read4<i * 32 * WLDW * 4>(A[0][i], x.raddr_next);
@@ -437,7 +456,7 @@ struct ChunkOps {
       constexpr int k = K - o_rb;
       if constexpr (k == 0) ep.template issue_rowbias_one<0>(rb[0], x.row0, x.colw);
       else ep.template issue_rowbias_one<1>(rb[NJ - 1], x.row0, x.colw);
-    } else {
+    } else if constexpr (K < o_sl) {
       constexpr int idx = SC::ld_lo(GC) + (K - o_op);                     // index in the tile's operand-load sequence
       constexpr int HB = idx / (8 * NLT), tns = (idx / 8) % NLT, e = idx % 8;
       constexpr int J = HB >> 2, I = (HB >> 1) & 1, H = HB & 1;
@@ -460,29 +479,34 @@ struct ChunkOps {
 
   // the instructions behind MFMA S
   template <int S, int R = 0>
-  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
+  static __device__ __forceinline__ void slot(f32x4 (&A)[2][2], f32x4 (&Bw)[SC::SLOTS][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1, float (&rb)[EPI_T::NJ],
+                                              const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     if constexpr (R < PER && S * PER + R < total) {
-      op<S * PER + R>(A, xv, l0, l1, rb, x, q);
-      slot<S, R + 1>(A, xv, l0, l1, rb, x, q);
+      op<S * PER + R>(A, Bw, xv, l0, l1, rb, x, q);
+      slot<S, R + 1>(A, Bw, xv, l0, l1, rb, x, q);
     }
   }
 
   template <int S>
-  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
+  static __device__ __forceinline__ void steps(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[wide_slots(NCH, NP, EPI_T::NJ)][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
                                                float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x, Ptrs& q) {
     if constexpr (S < NMF) {
       constexpr int kq = S / (2 * NJ), i = (S / NJ) & 1, j = S % NJ;
-      mfma_vab<GC == 0 && kq == 0, GC == NP * NCH - 1 && S == NMF - 1>(acc[i][j], A[C & 1][i][kq], Bw[GC][j][kq]);
-      slot<S>(A, xv, l0, l1, rb, x, q);
+      mfma_vab<GC == 0 && kq == 0, GC == NP * NCH - 1 && S == NMF - 1>(acc[i][j], A[C & 1][i][kq], Bw[GC % SLOTS][j][kq]);
+      slot<S>(A, Bw, xv, l0, l1, rb, x, q);
       steps<S + 1>(acc, A, Bw, xv, l0, l1, rb, x, q);
     }
   }
 
-  static __device__ __forceinline__ void run(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[wide_slots(NCH, NP, EPI_T::NJ)][EPI_T::NJ], f32x4 (&xv)[NX], f32x2* l0, f32x2* l1,
                                              float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x) {
     // this chunk's fragments (and, at XW + 1, this wave's panel writes) have landed in / left for LDS
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[C & 1][0]), "+v"(A[C & 1][1]) : : "memory");
-    if constexpr (FT) wait_slab<SC::vm_slab(P, C), NJ>(Bw[GC]);
+    // the chunk's weight fragment: still landing behind the prologue on the first tile; under ROLL every other chunk reads a slot that
+    // was reloaded SLOTS - 1 chunks ago - at least 63 younger vector-memory operations (one reload per chunk and the panel loads), so
+    // vmcnt(63) proves it has landed (vmcnt retires in order)
+    if constexpr (FT && GC < SLOTS) wait_slab<SC::vm_slab(P, C), NJ>(Bw[GC % SLOTS]);
+    else if constexpr (SC::ROLL) wait_slab<63, NJ>(Bw[GC % SLOTS]);
     if (C == SC::BAR) __builtin_amdgcn_s_barrier();
     Ptrs q{0u, 0u, 0u, 0u};
     steps<0>(acc, A, Bw, xv, l0, l1, rb, x, q);
@@ -490,7 +514,7 @@ struct ChunkOps {
 };
 
 template <int P, int NCH, int NP, bool HP, bool FT, class EPI_T>
-__device__ __forceinline__ void panel(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], f32x2* l0, f32x2* l1,
+__device__ __forceinline__ void panel(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[wide_slots(NCH, NP, EPI_T::NJ)][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], f32x2* l0, f32x2* l1,
                                       float (&rb)[EPI_T::NJ], const PanelCtx<NCH, EPI_T>& x) {
   ChunkOps<0, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
   ChunkOps<1, P, NCH, NP, HP, FT, EPI_T>::run(acc, A, Bw, xv, l0, l1, rb, x);
@@ -507,17 +531,19 @@ __device__ __forceinline__ void panel(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2]
 // panels P .. NP-1 of one tile, straight-line: values defined by the asm loads must never meet at a control-flow join
 // (the compiler would reconcile them with register copies - of registers whose loads are still in flight)
 template <int P, int NCH, int NP, bool HP, bool FT, class EPI_T, class PX>
-__device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[NP * NCH][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], f32x2* l0,
+__device__ __forceinline__ void tile_panels(f32x16 (&acc)[2][EPI_T::NJ], f32x4 (&A)[2][2], f32x4 (&Bw)[wide_slots(NCH, NP, EPI_T::NJ)][EPI_T::NJ], f32x4 (&xv)[PanelGeo<NCH>::NX], f32x2* l0,
                                             f32x2* l1, float (&rb)[EPI_T::NJ], const EPI_T& epi, const i32x4& rX, unsigned xvoff, unsigned xstep, int& buf,
-                                            unsigned rlane, unsigned wlane, int row0, int colw, int prev_row0, int tile, int tnext, const PX& panel_x) {
+                                            unsigned rlane, unsigned wlane, int row0, int colw, int prev_row0, int tile, int tnext, const PX& panel_x,
+                                            const float* wslab, unsigned bvoff, int kch) {
   if constexpr (P < NP) {
     constexpr bool lastp = P + 1 == NP;
     const int bnext = buf + 1 == NBUF ? 0 : buf + 1;
     const PanelCtx<NCH, EPI_T> x{epi, rX, xvoff, xstep, panel_x(lastp ? tnext : tile, lastp ? 0 : P + 1), rlane + buf * WBUF_BYTES, rlane + bnext * WBUF_BYTES,
-                                 wlane + bnext * WBUF_BYTES, row0, colw, prev_row0};
+                                 wlane + bnext * WBUF_BYTES, row0, colw, prev_row0, wslab, bvoff, kch};
     panel<P, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, x);
     buf = bnext;
-    tile_panels<P + 1, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
+    tile_panels<P + 1, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x, wslab,
+                                        bvoff, kch);
   }
 }
 
@@ -533,7 +559,8 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   using SC = Sched<NCH, NP, NJ, EPI_T::NLT, EPI_T::NST, true>;
   constexpr int NX = PG::NX, G = NP * NCH;
   static_assert(NCH % 2 == 0 && NCH >= 4, "fragment double buffer / XW, BAR chunks");
-  static_assert(NJ * G * 4 <= 256, "the weight slab must fit the AGPR file");
+  constexpr int SLOTS = wide_slots(NCH, NP, NJ);   // chunks of the slab resident at a time (G, or a rolling window: Sched::ROLL)
+  static_assert(NJ * SLOTS * 4 <= 256 && G % SLOTS == 0, "the slab window must fit the AGPR file");
   __shared__ float lds[NBUF * WBM * WLDW];
 
 #ifdef ARDAE_STAMPS
@@ -572,28 +599,29 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
   };
   auto panel_x = [&](int rt, int p) -> unsigned { return (unsigned)tile_row0(rt) * ldx4 + (unsigned)(p * 8 * NCH) * 4u; };
 
-  f32x4 A[2][2], Bw[G][NJ], xv[NX];
+  f32x4 A[2][2], Bw[SLOTS][NJ], xv[NX];
   f32x2 l0[16 * NJ], l1[16 * NJ];
   float rb[NJ];
 #pragma unroll
   for (int i = 0; i < 16 * NJ; ++i) l0[i] = l1[i] = f32x2{0.f, 0.f};   // the slots' registers exist from here on (tied asm operands read them)
   int tile = rt0;   // row tile
   // ---- prologue: the wave's weight slab into its AGPRs, first panel into LDS buffer 0, fragment set 0 in flight
+  const unsigned bvoff = (unsigned)lane * 16u;
+  const int kch = a.src[0].K >> 3;
+  const float* wslab = a.src[0].wp + (size_t)(cp * 4 * NJ + wave * NJ) * kch * 256;
   {
-    const unsigned bvoff = (unsigned)lane * 16u;
-    const int kch = a.src[0].K >> 3;
-    const float* wp = a.src[0].wp + (size_t)(cp * 4 * NJ + wave * NJ) * kch * 256;
+    const float* wp = wslab;
     const unsigned x0 = panel_x(tile, 0);
 #pragma unroll
     for (int u = 0; u < NX; ++u) bload4<0>(xv[u], xvoff, rX, x0 + (unsigned)u * xstep);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < SLOTS; ++g) {
       gload4_agpr(Bw[g][0], bvoff, wp + (size_t)g * 256);
       if constexpr (NJ == 2) gload4_agpr(Bw[g][1], bvoff, wp + ((size_t)kch + g) * 256);
     }
-    // the panel is older than the slab: it has landed when at most the NJ G slab loads are outstanding; the slab keeps
+    // the panel is older than the slab: it has landed when at most the NJ SLOTS slab loads are outstanding; the slab keeps
     // landing behind the first tile's MFMAs (ChunkOps<.., FT = true> waits per chunk)
-    wait_panel<(NJ * G > 63 ? 63 : NJ * G), NX>(xv);
+    wait_panel<(NJ * SLOTS > 63 ? 63 : NJ * SLOTS), NX>(xv);
     store_panel<NCH, NX>(xv, wlane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -617,7 +645,8 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
     const int row0 = tile_row0(tr);
     const int tnext = tile + rts < nrt ? tile + rts : tile;   // none: re-touch this tile (never used)
     f32x16 acc[2][NJ];
-    tile_panels<0, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x);
+    tile_panels<0, NCH, NP, HP, FT>(acc, A, Bw, xv, l0, l1, rb, epi, rX, xvoff, xstep, buf, rlane, wlane, row0, colw, prev_row0, tile, tnext, panel_x, wslab, bvoff,
+                                    kch);
 #ifdef ARDAE_STAMPS
     const unsigned long long T1 = __builtin_amdgcn_s_memtime();
     t_k += T1 - T0;
@@ -691,6 +720,12 @@ int launch_wide(const LinArgs& a, hipStream_t st) {
 #define ARDAE_WIDE_FOR_DACT_FLAGS(X, ACT)          \
   ARDAE_WIDE_FOR_GEOS(X, EPI_DACT, ACT, false, false) \
   ARDAE_WIDE_FOR_GEOS(X, EPI_DACT, ACT, true, false)
+// K = 1024 (rolling slab window): the N-row layers of config #5 (mlp-res h 1024: forward layers incl. the one with the per-image
+// row bias + sigma term, backward DACT without Q), softplus
+#define ARDAE_WIDE_FOR_K1024(X)                        \
+  X(8, 16, 1, EPI_ACT, ACT_SOFTPLUS, false, false)     \
+  X(8, 16, 1, EPI_ACT, ACT_SOFTPLUS, false, true)      \
+  X(8, 16, 1, EPI_DACT, ACT_SOFTPLUS, false, false)
 #define ARDAE_WIDE_EXTERN(NCH, NP, NJ, EPI, ACT, F1, F2) extern template int launch_wide<NCH, NP, NJ, EPI, ACT, F1, F2>(const LinArgs&, hipStream_t);
 #define ARDAE_WIDE_INSTANTIATE(NCH, NP, NJ, EPI, ACT, F1, F2) template int launch_wide<NCH, NP, NJ, EPI, ACT, F1, F2>(const LinArgs&, hipStream_t);
 #ifndef ARDAE_WIDE_INST_TU
@@ -701,6 +736,7 @@ ARDAE_WIDE_FOR_DACT_FLAGS(ARDAE_WIDE_EXTERN, ACT_NONE)
 ARDAE_WIDE_FOR_DACT_FLAGS(ARDAE_WIDE_EXTERN, ACT_RELU)
 ARDAE_WIDE_FOR_DACT_FLAGS(ARDAE_WIDE_EXTERN, ACT_SOFTPLUS)
 ARDAE_WIDE_FOR_GEOS(ARDAE_WIDE_EXTERN, EPI_CHAIN, ACT_SOFTPLUS, false, false)
+ARDAE_WIDE_FOR_K1024(ARDAE_WIDE_EXTERN)
 #endif
 
 }  // namespace wide

@@ -101,6 +101,33 @@ def test_linear_transposed_pack_and_two_sources():
     assert relerr(Y, X1.double() @ Wt.double()) < 2e-5
 
 
+@pytest.mark.parametrize("M,Nout", [(2048, 1024), (8192, 1024), (6144, 512), (20480, 128)])
+@pytest.mark.parametrize("epi", ["dact", "act_rowbias"])
+def test_linear_wide_kernel_k1024_rolling_slab(M, Nout, epi):
+    """K = 1024 (config #5's mlp-res h 1024 layers): the wave's slab, 32 columns x 1024, is twice its AGPR file, so the kernel keeps a
+    rolling WINDOW of 64 chunks - every slot is reloaded one chunk after the MFMAs that read it, with the fragment 64 chunks ahead
+    (this tile's second half, then the next tile's first).  One tile per workgroup (2048 rows x 8 column panels), four, a ragged
+    number of tiles per workgroup and a single column panel; against float64.  The instantiated epilogues: forward with bias /
+    per-image row bias + sigma term, backward DACT."""
+    K = 1024
+    g = torch.Generator().manual_seed(M + Nout)
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5
+    v = X.double() @ W.double().T
+    wpk = pack(W.cuda())
+    Y = torch.full((M, Nout), float("nan"), device="cuda")
+    if epi == "dact":
+        S = torch.nn.functional.softplus(torch.randn(M, Nout, generator=g) * 3)
+        run_linear(L.EPI_DACT, M, Nout, [(X.cuda(), wpk)], act=2, S=S.cuda(), Y=Y)
+        ref = v * d1("softplus", S.double())
+    else:
+        rpg = 256
+        rb, sig, ws = torch.randn(M // rpg, Nout, generator=g), torch.randn(M, generator=g).abs(), torch.randn(Nout, generator=g)
+        run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), wpk)], act=2, rowbias=rb.cuda(), rows_per_group=rpg, rowscale=sig.cuda(), rowscale_w=ws.cuda(), Y=Y)
+        ref = torch.nn.functional.softplus(v + rb.double().repeat_interleave(rpg, 0) + sig.double()[:, None] * ws.double()[None, :])
+    assert not torch.isnan(Y).any()
+    assert relerr(Y, ref) < 2e-5
+
+
 @pytest.mark.parametrize("M,K,Nout", [(8192, 256, 256), (24576, 256, 256), (65536, 256, 256), (16384, 32, 256),
                                       (8192, 512, 512), (20480, 512, 512), (4096, 512, 1024), (8192, 32, 512), (12288, 512, 128),
                                       (65536, 32, 256), (40960, 32, 512)])
