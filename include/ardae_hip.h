@@ -223,7 +223,10 @@ typedef struct ardae_model_desc {
   int flags;    /* kinds 5 / 6: ARDAE_MODEL_NO_CENTER = do_center False (--model resconv-res / auxresconv: the trunk sees x, not 2x - 1;
                  * ivae/resconv.py:131-132, vae/auxresconv.py:56-58); 0 elsewhere */
 } ardae_model_desc;
-enum { ARDAE_MODEL_NO_CENTER = 1 };
+enum { ARDAE_MODEL_NO_CENTER = 1,
+       /* kind 5 (ResConvIPVAE): the sampler head `encode.fc` (models/ivae/resconv.py:101-116, ivae_ardae.py:323-442), flags bits 1-3:
+        * 0 'res-wn-mlp' (--model resconv[ct]-res), 1 'mlp' (resconv[ct]), 2 'res-mlp' (-res2), 3 'res-wn-mlp-lin' (-res3), 4 'res-mlp-lin' (-res4) */
+       ARDAE_MODEL_HEAD_SHIFT = 1, ARDAE_MODEL_HEAD_MASK = 7 << 1 };
 size_t ardae_model_param_floats(const ardae_model_desc* d);
 size_t ardae_model_packed_floats(const ardae_model_desc* d);
 /* mode 0: encode only; mode 1: vae_forward + vae_backward; mode 2: decode only (B = rows, nz = 1); mode 3: encode_pair */

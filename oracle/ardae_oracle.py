@@ -60,6 +60,8 @@ class ModelCfg:
     n_layers: int = 2            # --model-n-layers
     nonlin: str = "softplus"
     do_center: bool = True       # residual-conv kinds: the trunk sees 2x - 1 (--model resconvct-res / auxresconvct) or x (resconv-res / auxresconv)
+    enc_type: str = "res-wn-mlp"  # "resconv" only: the sampler head (models/ivae/resconv.py:101-116): 'mlp' (--model resconv / resconvct), 'res-wn-mlp'
+                                 # (-res), 'res-mlp' (-res2), 'res-wn-mlp-lin' (-res3), 'res-mlp-lin' (-res4); n_layers = --model-n-layers
 
 
 @dataclass
@@ -182,9 +184,8 @@ def model_param_spec(c: ModelCfg):
         for i, (o, inn) in zip((0, 2, 4, 6, 8), ((16, 1), (16, 16), (32, 16), (32, 32), (32, 32))):
             s += block(f"{tp}{i}.", o, inn, True)
         s += block(f"{tp}11.", cdim, 512, False)
-        if c.kind == "resconv":     # ResMLP(c_dim + noise -> h_dim -> z), n_layers = 1 (models/ivae/resconv.py:112-113)
-            assert c.n_layers == 1
-            s += block("encode.fc.layers.0.", c.h_dim, cdim + c.noise_dim, False) + block("encode.fc.fc.", c.z_dim, c.h_dim, False)
+        if c.kind == "resconv":     # encode.fc (models/ivae/resconv.py:101-116)
+            s += _resconv_head_spec(c.enc_type, c.n_layers, cdim + c.noise_dim, c.h_dim, c.z_dim)
         else:
             s += [("encode.aux_encode.reparam.mean_fn.weight", (c.noise_dim, cdim)), ("encode.aux_encode.reparam.mean_fn.bias", (c.noise_dim,)),
                   ("encode.aux_encode.reparam.logvar_fn.weight", (c.noise_dim, cdim)), ("encode.aux_encode.reparam.logvar_fn.bias", (c.noise_dim,)),
@@ -323,6 +324,63 @@ def ctxcat_mlp(p, prefix, x, ctx, n_hidden, nonlin):
     return F.linear(torch.cat([h, ctx], 1), p[f"{prefix}fc.weight"], p[f"{prefix}fc.bias"])
 
 
+def _resconv_head_spec(enc_type, n_layers, cin, h_dim, z_dim):
+    """`encode.fc` of ResConvIPVAE in registration order (models/ivae/resconv.py:101-116): MLP (models/layers.py:477-515), ResMLP of ResLinear
+    blocks with WeightNormalizedLinear(norm=False) or nn.Linear operators (:25-85,559-622; no dot_01 when a block keeps its width), or
+    Sequential(ResMLP(..., n_layers - 1 hidden, output h_dim, activated), Linear(h_dim, z_dim))."""
+    assert enc_type in ("mlp", "res-wn-mlp", "res-mlp", "res-wn-mlp-lin", "res-mlp-lin")
+    lin = lambda pre, out, inn: [(pre + "weight", (out, inn)), (pre + "bias", (out,))]
+    oper = lambda pre, out, inn, wn: ([(pre + "direction", (out, inn)), (pre + "scale", (out,)), (pre + "bias", (out,))] if wn else lin(pre, out, inn))
+    res = lambda pre, out, inn, wn: (oper(pre + "dot_0h.", out, inn, wn) + oper(pre + "dot_h1.", out, out, wn)
+                                     + ([] if inn == out else oper(pre + "dot_01.", out, inn, wn)))
+    s = []
+    if enc_type == "mlp":
+        for i in range(n_layers):
+            s += lin(f"encode.fc.layers.{i}.", h_dim, cin if i == 0 else h_dim)
+        return s + lin("encode.fc.fc.", z_dim, h_dim)
+    wn = enc_type.startswith("res-wn")
+    if enc_type in ("res-wn-mlp", "res-mlp"):
+        for i in range(n_layers):
+            s += res(f"encode.fc.layers.{i}.", h_dim, cin if i == 0 else h_dim, wn)
+        return s + res("encode.fc.fc.", z_dim, h_dim, wn)
+    for i in range(n_layers - 1):
+        s += res(f"encode.fc.0.layers.{i}.", h_dim, cin if i == 0 else h_dim, wn)
+    return s + res("encode.fc.0.fc.", h_dim, cin if n_layers == 1 else h_dim, wn) + lin("encode.fc.1.", z_dim, h_dim)
+
+
+def _head_oper(p, pre, x, wn):
+    """An operator of ResMLP: WeightNormalizedLinear(norm=False) (weight = scale * direction, models/layers.py:47-53) or nn.Linear."""
+    return F.linear(x, _wn_weight(p, pre, False) if wn else p[pre + "weight"], p[pre + "bias"])
+
+
+def _head_res_linear(p, pre, x, wn):
+    """ResLinear (models/layers.py:66-85): dot_h1(relu(dot_0h(x))) + (x if same_dim else dot_01(x))."""
+    skip = _head_oper(p, pre + "dot_01.", x, wn) if (pre + "dot_01.bias") in p else x
+    return _head_oper(p, pre + "dot_h1.", F.relu(_head_oper(p, pre + "dot_0h.", x, wn)), wn) + skip
+
+
+def resconv_head(c, p, hin):
+    """ResConvIPVAE's `encode.fc` on hin = [trunk output | noise] (models/ivae/resconv.py:101-116,150-157), every enc_type; ELU between
+    the operators (get_nonlinear_func(nonlinearity), models/layers.py:510,617)."""
+    et, nl = c.enc_type, c.n_layers
+    if et == "mlp":
+        h = hin
+        for i in range(nl):
+            h = F.elu(F.linear(h, p[f"encode.fc.layers.{i}.weight"], p[f"encode.fc.layers.{i}.bias"]))
+        return F.linear(h, p["encode.fc.fc.weight"], p["encode.fc.fc.bias"])
+    wn = et.startswith("res-wn")
+    if et in ("res-wn-mlp", "res-mlp"):
+        h = hin
+        for i in range(nl):
+            h = F.elu(_head_res_linear(p, f"encode.fc.layers.{i}.", h, wn))
+        return _head_res_linear(p, "encode.fc.fc.", h, wn)
+    h = hin
+    for i in range(nl - 1):
+        h = F.elu(_head_res_linear(p, f"encode.fc.0.layers.{i}.", h, wn))
+    h = F.elu(_head_res_linear(p, "encode.fc.0.fc.", h, wn))
+    return F.linear(h, p["encode.fc.1.weight"], p["encode.fc.1.bias"])
+
+
 def _wn_weight(p, pre, norm):
     """Effective weight of a weight-normalised operator: scale * direction / ||direction||  (norm over everything but the output
     index; layers2.py:73-83,255-265) or scale * direction (models/layers.py:47-53 with norm=False, as ResMLP builds them)."""
@@ -423,10 +481,9 @@ def encode(c: ModelCfg, p, x, noise, nz):
         z = ctxcat_mlp(p, "encode.fc.", expand_rows(inp, nz), noise, c.n_layers, c.nonlin)
     elif c.kind in ("auxmnist", "auxconv"):
         z = aux_encode(c, p, x, noise, nz)["z"]
-    elif c.kind == "resconv":      # ivae/resconv.py:141-159, enc_type 'res-wn-mlp': ResMLP with ELU between its two ResLinears
+    elif c.kind == "resconv":      # ivae/resconv.py:141-159
         inp = resconv_trunk(c, p, x)
-        t = F.elu(res_linear(p, "encode.fc.layers.0.", torch.cat([expand_rows(inp, nz), noise], 1), False))
-        z = res_linear(p, "encode.fc.fc.", t, False)
+        z = resconv_head(c, p, torch.cat([expand_rows(inp, nz), noise], 1))
     elif c.kind == "auxresconv":
         z = auxres_encode(c, p, x, noise, nz)["z"]
     else:

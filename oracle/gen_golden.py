@@ -67,7 +67,7 @@ def build_reference(net, mc, cc, pm, pc, dtype):
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "resconv":   # ivae_ardae.py:359-370 (--model resconvct-res)
         model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
-                                 noise_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type="res-wn-mlp")
+                                 noise_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type=mc.enc_type)
     elif mc.kind == "auxresconv":   # ivae_ardae.py:493-505 (--model auxresconvct)
         model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim,
                                          nonlinearity=mc.nonlin, do_center=mc.do_center)
@@ -478,6 +478,17 @@ def main():
              B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
     run_case(net, rutils, "auxresconv_nocenter_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False), ares_c, ares_t,
              B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    # the other sampler heads of ResConvIPVAE (ivae_ardae.py:323-346,371-442: --model resconv / resconvct 'mlp', -res2 'res-mlp', -res3
+    # 'res-wn-mlp-lin', -res4 'res-mlp-lin'), centred and not, one and two hidden layers (two: ResLinear blocks with identity skips)
+    for nm, et, nl, ctr in (("resconv_mlp_b4_nz8", "mlp", 1, True), ("resconv_mlp2_nocenter_b4_nz8", "mlp", 2, False),
+                            ("resconv_res2_b4_nz8", "res-mlp", 1, False), ("resconv_res2x2_b4_nz8", "res-mlp", 2, True),
+                            ("resconv_res3_b4_nz8", "res-wn-mlp-lin", 1, True), ("resconv_res3x2_b4_nz8", "res-wn-mlp-lin", 2, False),
+                            ("resconv_res4_b4_nz8", "res-mlp-lin", 1, False), ("resconv_resx2_b4_nz8", "res-wn-mlp", 2, True)):
+        run_case(net, rutils, nm, O.ModelCfg("resconv", 784, 100, 512, 32, nl, "elu", do_center=ctr, enc_type=et), res_c, res_t,
+                 B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    run_case(net, rutils, "resconv_res2_b4_nz8_f64", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", do_center=False, enc_type="res-mlp"), res_c, res_t,
+             B=4, steps=1, dtype=f64, store_full=False)
+    run_iwae_case(net, "iwae_resconv_mlp", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", enc_type="mlp"), B=2, k=64, dtype=f64, store_params=False)
     run_iwae_case(net, "iwae_resconv", res_m, B=2, k=64, dtype=f64, store_params=False)
     run_iwae_case(net, "iwae_auxresconv", ares_m, B=2, k=64, dtype=f64, store_params=False)
     # reference-written checkpoint (model / cDAE state_dict + utils.Adam / torch.optim.RMSprop state_dict) and the step after it

@@ -79,6 +79,7 @@ class ModelDesc(ctypes.Structure):
 
 
 MODEL_NO_CENTER = 1      # ardae_model_desc.flags (residual-conv kinds: do_center=False)
+MODEL_HEAD_SHIFT = 1     # kind 5: sampler-head type in flags bits 1-3 (layout.RESCONV_HEADS)
 
 
 # utils/models.py:14-32 (get_nonlinear_func); 'csoftplus' = log(exp(x) + 1) is softplus (evaluated in its accurate form); 'swish' is not offered

@@ -140,6 +140,7 @@ size_t workspace_floats(const CdaeLayout& P, int B, int S, bool need_grads) {
   t += (size_t)(need_grads ? 8 : 4) * P.L * al(N * h);                   // a,hh,e,r (+ tau,taup,pbar,qbar)
   t += 2 * al(N * P.z);                                                  // gbar, g
   t += al((size_t)linear_row_tiles((int)N, P.z) * linear_col_panels((int)N, P.z));
+  t += al(3 * ((N + 31) / 32));                                          // row-block counters of the per-image chain launch (score pass)
   if (need_grads) {
     t += al((size_t)B * h) + (size_t)P.L * al((size_t)B * h);            // Qsum, chat_l
     t += al((size_t)linear_row_tiles((int)N, P.h) * h);                  // colsum of tau'_L
@@ -236,26 +237,49 @@ int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed
   float* gbuf = ws.take((size_t)N * z);
   const int ltiles = linear_row_tiles(N, z) * linear_col_panels(N, z);
   float* tile_loss = ws.take(ltiles);
+  float* chain_cnt = ws.take(3 * ((size_t)(N + 31) / 32));
   float* g = score_out ? score_out : gbuf;
 
   const float* W1s = packed + K.w1s;
-  // ------------------------------------------------------------------ forward: ctx (B rows, once per image)
-  for (int l = 1; l <= L; ++l) {
-    LinArgs A{}; A.bias = params + P.ctx[l - 1].b; A.Y = cL[l]; A.ldY = h;
-    ARDAE_TRY(lin(EPI_ACT, act, B, h, l == 1 ? ctx : cL[l - 1], l == 1 ? P.c : h, P.ctx[l - 1].in, packed + K.ctx_f[l - 1], A, st));
+  // ------------------------------------------------------------------ forward: ctx (B rows, once per image) and inp (N rows)
+  auto ctx_layer = [&](int l) { LinArgs A{}; A.bias = params + P.ctx[l - 1].b; A.Y = cL[l]; A.ldY = h;
+                                return lin_args(act, B, h, l == 1 ? ctx : cL[l - 1], l == 1 ? P.c : h, P.ctx[l - 1].in, packed + K.ctx_f[l - 1], A); };
+  auto inp_layer = [&](int l) { LinArgs A{}; A.bias = params + P.inp[l - 1].b; A.Y = a[l]; A.ldY = h;
+                                return lin_args(act, N, h, l == 1 ? xbar : a[l - 1], l == 1 ? z : h, P.inp[l - 1].in, packed + K.inp_f[l - 1], A); };
+  const float* wfc0 = params + P.neg[L].w;
+  if (!need_grads && P.kind == 0 && N == B && linear_small_eligible(inp_layer(1), EPI_ACT)) {
+    // The sigma = 0 score pass of the VAE update (glogprob on B rows, models/graddae/mlp.py:446-483): 4 L + 2 per-image problems, every one
+    // a link of a dependent chain - ONE launch walks them level by level (linear_small_chain_kernel): [ctx_l | inp_l] l = 1..L, the
+    // per-image bias of the first energy layer, the energy layers, the score layers, g.
+    std::vector<LinArgs> pr; std::vector<int> ep, lv;
+    int level = 0;
+    auto add = [&](const LinArgs& A, int epi, int lev) { pr.push_back(A); ep.push_back(epi); lv.push_back(lev); };
+    for (int l = 1; l <= L; ++l, ++level) { add(ctx_layer(l), EPI_ACT, level); add(inp_layer(l), EPI_ACT, level); }
+    { LinArgs A{}; A.bias = params + P.neg[0].b; A.Y = cb; A.ldY = h; add(lin_args(ACT_NONE, B, h, cL[L], h, h, packed + K.w1c_f, A), EPI_ACT, level++); }
+    for (int l = 1; l <= L; ++l) {
+      LinArgs A{}; A.Y = hh[l]; A.ldY = h;
+      if (l == 1) { A.rowbias = cb; A.rowbias_ld = h; A.rows_per_group = S; A.rowscale = sigma; A.rowscale_w = W1s; } else A.bias = params + P.neg[l - 1].b;
+      if (l == L) { A.Y2 = e[L]; A.ldY2 = h; A.R = wfc0; }
+      add(lin_args(act, N, h, l == 1 ? a[L] : hh[l - 1], h, h, l == 1 ? packed + K.w1a_f : packed + K.neg_f[l - 1], A), EPI_ACT, level++);
+    }
+    for (int l = L; l >= 2; --l) { LinArgs A{}; A.S = hh[l - 1]; A.ldS = h; A.Y = e[l - 1]; A.ldY = h; add(lin_args(act, N, h, e[l], h, h, packed + K.neg_b[l - 1], A), EPI_DACT, level++); }
+    { LinArgs A{}; A.S = a[L]; A.ldS = h; A.Y = r[L]; A.ldY = h; add(lin_args(act, N, h, e[1], h, h, packed + K.w1a_b, A), EPI_DACT, level++); }
+    for (int l = L; l >= 2; --l) { LinArgs A{}; A.S = a[l - 1]; A.ldS = h; A.Y = r[l - 1]; A.ldY = h; add(lin_args(act, N, h, r[l], h, h, packed + K.inp_b[l - 1], A), EPI_DACT, level++); }
+    { LinArgs A{}; A.Y = g; A.ldY = z; add(lin_args(ACT_NONE, N, z, r[1], h, h, packed + K.inp_b[0], A), EPI_ACT, level++); }
+    return launch_linear_small_chain(pr.data(), ep.data(), lv.data(), (int)pr.size(), chain_cnt, st);
+  }
+  if (linear_small_eligible(inp_layer(1), EPI_ACT)) {
+    // few rows: the two encoders are independent chains of per-image launches - level l of both in ONE launch
+    for (int l = 1; l <= L; ++l) ARDAE_TRY(launch_linear_pair(ctx_layer(l), inp_layer(l), EPI_ACT, st));
+  } else {
+    for (int l = 1; l <= L; ++l) ARDAE_TRY(launch_linear(ctx_layer(l), EPI_ACT, st));
+    LayerRun run(EPI_ACT, st);
+    for (int l = 1; l <= L; ++l) run.v.push_back(inp_layer(l));
+    ARDAE_TRY(run.flush());
   }
   {  // per-image bias of the first energy layer: cb = W1c c_L + d_1
     LinArgs A{}; A.bias = params + P.neg[0].b; A.Y = cb; A.ldY = h;
     ARDAE_TRY(lin(EPI_ACT, ACT_NONE, B, h, cL[L], h, h, packed + K.w1c_f, A, st));
-  }
-  // ------------------------------------------------------------------ forward: inp + energy MLP (N rows)
-  {
-    LayerRun run(EPI_ACT, st);
-    for (int l = 1; l <= L; ++l) {
-      LinArgs A{}; A.bias = params + P.inp[l - 1].b; A.Y = a[l]; A.ldY = h;
-      run.add(act, N, h, l == 1 ? xbar : a[l - 1], l == 1 ? z : h, P.inp[l - 1].in, packed + K.inp_f[l - 1], A);
-    }
-    ARDAE_TRY(run.flush());
   }
   const float* wfc = params + P.neg[L].w;   // grad kind: w [1,h]
   {

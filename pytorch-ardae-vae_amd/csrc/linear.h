@@ -36,6 +36,11 @@ int launch_pack_batch(const PackItem* items, int n, hipStream_t st);
 // split-K 32 x 32 kernel for the per-image (B-row) problems (linear_small.hip): latency, not throughput
 bool linear_small_eligible(const LinArgs& a, int epi);
 int launch_linear_small(const LinArgs& a, int epi, hipStream_t st);
+// two INDEPENDENT per-image problems of one epilogue kind in one launch where both run on the split-K kernel (else two launches)
+int launch_linear_pair(const LinArgs& a0, const LinArgs& a1, int epi, hipStream_t st);
+// a dependent CHAIN of per-image levels (one or two independent problems each, probs[i] on level level_of[i], levels ascending) in
+// ONE launch with a row-block counter hand-over between the levels (linear_small.hip); counters: 3 ceil(M / 32) floats of scratch
+int launch_linear_small_chain(const LinArgs* probs, const int* epis, const int* level_of, int nprob, float* counters, hipStream_t st);
 // streaming kernel for N-row layers with Nout <= 32 and K = 256 (linear_narrow.hip): HBM-bound
 bool linear_narrow_eligible(const LinArgs& a, int epi);
 int launch_linear_narrow(const LinArgs& a, int epi, hipStream_t st);

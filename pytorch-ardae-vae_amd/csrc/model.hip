@@ -93,11 +93,11 @@ int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 6,
                   "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE), 3 (MNISTAuxIPVAE), 4 (MNISTConvAuxIPVAE), 5 (ResConvIPVAE) or "
                   "6 (MNISTResConvAuxIPVAE)");
-  ARDAE_CHECK_ARG((d->flags & ~ARDAE_MODEL_NO_CENTER) == 0 && (d->kind >= 5 || d->flags == 0),
-                  "model: unknown flags %d (ARDAE_MODEL_NO_CENTER exists for the residual-conv kinds 5 / 6 only)", d->flags);
+  ARDAE_CHECK_ARG((d->flags & ~(ARDAE_MODEL_NO_CENTER | ARDAE_MODEL_HEAD_MASK)) == 0 && (d->kind >= 5 || d->flags == 0),
+                  "model: unknown flags %d (ARDAE_MODEL_NO_CENTER / the sampler-head bits exist for the residual-conv kinds 5 / 6 only)", d->flags);
   if (d->kind >= 5) {
-    ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1 && d->h_dim >= 1 && d->act == ACT_ELU && (d->kind == 6 || d->n_layers == 1),
-                    "model: the residual-conv models are 28x28x1, ELU, and (kind 5) one ResMLP layer");
+    ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1 && d->h_dim >= 1 && d->act == ACT_ELU && (d->kind == 6 || (d->n_layers >= 1 && d->n_layers <= 4)),
+                    "model: the residual-conv models are 28x28x1, ELU, and (kind 5) 1 .. 4 hidden layers in the sampler head");
     return 0;
   }
   if (d->kind == 2 || d->kind == 4) {

@@ -244,31 +244,38 @@ __global__ void spm4_kernel(const float* __restrict__ x, const float* __restrict
   } while (0)
 
 // ------------------------------------------------------------------------------------------------ layout
-struct WN { size_t dir, scale, bias; int O, I; bool norm; };                      // flat-parameter offsets; I = fan-in (C*9 for a conv)
+// plain: the operator is an nn.Linear (weight at `dir`, no scale, effective weight = weight): ResMLP(layer='linear')
+struct WN { size_t dir, scale, bias; int O, I; bool norm; bool plain; };          // flat-parameter offsets; I = fan-in (C*9 for a conv)
 struct Lin { size_t w, b; int out, in; };
-struct Blk { WN a, h, s; bool conv; int Cin, Cout, stride, Hin, Hout; };           // a = *_0h, h = *_h1, s = *_01 (skip)
+struct Blk { WN a, h, s; bool conv; int Cin, Cout, stride, Hin, Hout; bool same; };   // a = *_0h, h = *_h1, s = *_01 (skip; absent when same: identity)
+// One operator of ResConvIPVAE's sampler head `encode.fc` (models/ivae/resconv.py:101-116) on the B nz rows: a ResLinear (inner ReLU) or a
+// plain Linear, reading [trunk output | noise] (concat: the first one) or its predecessor's output, with ELU behind it or not
+struct HeadOp { bool res; Blk b; Lin l; int in, out; bool concat; int act; };
+// desc.flags bits 1-3 of kind 5: which head (ivae_ardae.py:323-442)
+enum { HEAD_RES_WN_MLP = 0, HEAD_MLP = 1, HEAD_RES_MLP = 2, HEAD_RES_WN_MLP_LIN = 3, HEAD_RES_MLP_LIN = 4 };
 
 struct ResLayout {
   int kind, nd, zd, cdim, hdim;
   bool center;                   // do_center: the trunk sees 2x - 1 (desc.flags without ARDAE_MODEL_NO_CENTER)
   std::vector<Blk> trunk, dec;   // trunk: 5 conv + ResLinear(512 -> cdim); dec: 2 ResLinear + 5 conv
-  Blk fc0, fc1;                  // kind 5: encode.fc.layers.0 (cdim + nd -> hdim), encode.fc.fc (hdim -> zd), un-normalised
+  std::vector<HeadOp> head;      // kind 5: encode.fc (the shipped recipe: ResLinear(cdim + nd -> hdim), ELU, ResLinear(hdim -> zd), un-normalised WN operators)
   Lin mu0, lv0, efc, mu, lv;     // kind 6: aux_encode.reparam.{mean,logvar}_fn, encode.fc.0, encode.reparam.{mean,logvar}_fn
   size_t total = 0;
 
   explicit ResLayout(const ardae_model_desc& d)
       : kind(d.kind), nd(d.noise_dim), zd(d.z_dim), cdim(d.kind == 5 ? 512 : d.h_dim), hdim(d.h_dim), center(!(d.flags & ARDAE_MODEL_NO_CENTER)) {
     size_t off = 0;
-    auto wn = [&](int O, int I, bool norm) {
-      WN w; w.O = O; w.I = I; w.norm = norm;
-      w.dir = off; off += (size_t)O * I; w.scale = off; off += O; w.bias = off; off += O;
+    auto wn = [&](int O, int I, bool norm, bool plain = false) {
+      WN w; w.O = O; w.I = I; w.norm = norm; w.plain = plain;
+      w.dir = off; off += (size_t)O * I; w.scale = off; if (!plain) off += O; w.bias = off; off += O;
       return w;
     };
-    auto block = [&](int Cout, int Cin, bool conv, int stride, int Hin, bool norm) {
-      Blk b; b.conv = conv; b.Cin = Cin; b.Cout = Cout; b.stride = stride; b.Hin = Hin;
+    auto block = [&](int Cout, int Cin, bool conv, int stride, int Hin, bool norm, bool plain = false, bool same = false) {
+      Blk b; b.conv = conv; b.Cin = Cin; b.Cout = Cout; b.stride = stride; b.Hin = Hin; b.same = same;
       b.Hout = conv ? (Hin + 2 - 3) / stride + 1 : 1;
       const int I = conv ? Cin * 9 : Cin, Ih = conv ? Cout * 9 : Cout;
-      b.a = wn(Cout, I, norm); b.h = wn(Cout, Ih, norm); b.s = wn(Cout, I, norm);
+      b.a = wn(Cout, I, norm, plain); b.h = wn(Cout, Ih, norm, plain);
+      if (same) { b.s = b.h; b.s.O = 0; } else b.s = wn(Cout, I, norm, plain);
       return b;
     };
     auto lin = [&](int out, int in) { Lin l; l.out = out; l.in = in; l.w = off; off += (size_t)out * in; l.b = off; off += out; return l; };
@@ -279,8 +286,30 @@ struct ResLayout {
     trunk.push_back(block(32, 32, true, 2, 7, true));    // 7 -> 4
     trunk.push_back(block(cdim, 512, false, 1, 1, true));
     if (kind == 5) {
-      fc0 = block(hdim, cdim + nd, false, 1, 1, false);
-      fc1 = block(zd, hdim, false, 1, 1, false);
+      // encode.fc in the reference's parameter order (models/ivae/resconv.py:101-116, models/layers.py:477-515,559-622)
+      const int ht = (d.flags >> 1) & 7, nl = d.n_layers, cin = cdim + nd;
+      auto res_op = [&](int out, int in, bool plain, int act, bool concat) {
+        HeadOp o; o.res = true; o.b = block(out, in, false, 1, 1, false, plain, in == out); o.in = in; o.out = out; o.concat = concat; o.act = act;
+        o.l = Lin{0, 0, 0, 0};
+        head.push_back(o);
+      };
+      auto lin_op = [&](int out, int in, int act, bool concat) {
+        HeadOp o; o.res = false; o.l = lin(out, in); o.in = in; o.out = out; o.concat = concat; o.act = act; o.b = Blk{};
+        head.push_back(o);
+      };
+      if (ht == HEAD_MLP) {                       // MLP(cin -> hdim x nl -> zd), ELU after the hidden layers
+        for (int i = 0; i < nl; ++i) lin_op(hdim, i == 0 ? cin : hdim, ACT_ELU, i == 0);
+        lin_op(zd, hdim, ACT_NONE, false);
+      } else if (ht == HEAD_RES_WN_MLP || ht == HEAD_RES_MLP) {   // ResMLP(cin -> hdim x nl -> zd): ResLinear blocks, ELU between them
+        const bool plain = ht == HEAD_RES_MLP;
+        for (int i = 0; i < nl; ++i) res_op(hdim, i == 0 ? cin : hdim, plain, ACT_ELU, i == 0);
+        res_op(zd, hdim, plain, ACT_NONE, false);
+      } else {                                    // Sequential(ResMLP(cin -> hdim x (nl - 1) -> hdim, ELU on its output), Linear(hdim -> zd))
+        const bool plain = ht == HEAD_RES_MLP_LIN;
+        for (int i = 0; i < nl - 1; ++i) res_op(hdim, i == 0 ? cin : hdim, plain, ACT_ELU, i == 0);
+        res_op(hdim, nl - 1 == 0 ? cin : hdim, plain, ACT_ELU, nl - 1 == 0);
+        lin_op(zd, hdim, ACT_NONE, false);
+      }
     } else {
       mu0 = lin(nd, cdim); lv0 = lin(nd, cdim); efc = lin(cdim, cdim + nd); mu = lin(zd, cdim); lv = lin(zd, cdim);
     }
@@ -301,7 +330,8 @@ struct BlkPk { WNPk a, h, s; size_t bsum; size_t a_fi, a_fn, a_bi, s_fi, s_fn, s
 struct LinPk { size_t f, b, fi, fn, bi, bn; };   // fi / fn: image / noise columns forward; bi / bn: their transposes
 struct ResPacked {
   std::vector<BlkPk> trunk, dec;
-  BlkPk fc0, fc1;
+  struct HeadPk { BlkPk k; LinPk lk; };
+  std::vector<HeadPk> head;
   LinPk mu0, lv0, efc, mu, lv;
   size_t total = 0;
   explicit ResPacked(const ResLayout& P) {
@@ -309,9 +339,9 @@ struct ResPacked {
     auto take = [&](size_t n) { size_t o = off; off += al64(n); return o; };
     auto wn = [&](const WN& w) { WNPk k; k.weff = take((size_t)w.O * w.I); k.inv = take(w.O); k.f = take(packed_floats(w.O, w.I)); k.b = take(packed_floats(w.I, w.O)); return k; };
     auto blk = [&](const Blk& b, int split) {
-      BlkPk k; k.a = wn(b.a); k.h = wn(b.h); k.s = wn(b.s); k.bsum = take(b.Cout);
+      BlkPk k; k.a = wn(b.a); k.h = wn(b.h); k.s = b.same ? k.h : wn(b.s); k.bsum = take(b.Cout);
       k.a_fi = k.a_fn = k.a_bi = k.s_fi = k.s_fn = k.s_bi = 0;
-      if (split) {   // concat input [image part (split columns) | noise part]
+      if (split) {   // concat input [image part (split columns) | noise part]  (a concat block always has its projected skip: cdim + nd != Cout)
         const int nn = b.a.I - split;
         k.a_fi = take(packed_floats(b.a.O, split)); k.a_fn = take(packed_floats(b.a.O, nn)); k.a_bi = take(packed_floats(split, b.a.O));
         k.s_fi = take(packed_floats(b.s.O, split)); k.s_fn = take(packed_floats(b.s.O, nn)); k.s_bi = take(packed_floats(split, b.s.O));
@@ -327,8 +357,13 @@ struct ResPacked {
       return k;
     };
     for (auto& b : P.trunk) trunk.push_back(blk(b, 0));
-    if (P.kind == 5) { fc0 = blk(P.fc0, P.cdim); fc1 = blk(P.fc1, 0); }
-    else { mu0 = lin(P.mu0, 0); lv0 = lin(P.lv0, 0); efc = lin(P.efc, P.cdim); mu = lin(P.mu, 0); lv = lin(P.lv, 0); }
+    if (P.kind == 5) {
+      for (auto& o : P.head) {
+        HeadPk hp{};
+        if (o.res) hp.k = blk(o.b, o.concat ? P.cdim : 0); else hp.lk = lin(o.l, o.concat ? P.cdim : 0);
+        head.push_back(hp);
+      }
+    } else { mu0 = lin(P.mu0, 0); lv0 = lin(P.lv0, 0); efc = lin(P.efc, P.cdim); mu = lin(P.mu, 0); lv = lin(P.lv, 0); }
     for (auto& b : P.dec) dec.push_back(blk(b, 0));
     total = off;
   }
@@ -347,7 +382,13 @@ struct Bump {
 int res_desc_ok(const ardae_model_desc& d) {
   ARDAE_CHECK_ARG(d.input_dim == 784 && d.noise_dim >= 1 && d.z_dim >= 1 && d.h_dim >= 1, "model: the residual-conv models are hard-wired to 28x28x1 inputs");
   ARDAE_CHECK_ARG(d.act == ACT_ELU, "model: the residual-conv models use ELU (--model-nonlin elu; models/ivae/auxresconv.py:69 asserts it)");
-  ARDAE_CHECK_ARG(d.kind != 5 || d.n_layers == 1, "model: ResConvIPVAE is built for --model-n-layers 1 (the shipped recipe)");
+  ARDAE_CHECK_ARG(d.kind != 5 || (d.n_layers >= 1 && d.n_layers <= 4), "model: ResConvIPVAE takes --model-n-layers 1 .. 4");
+  ARDAE_CHECK_ARG(d.kind != 5 || ((d.flags >> 1) & 7) <= HEAD_RES_MLP_LIN, "model: unknown sampler head %d (desc.flags bits 1-3)", (d.flags >> 1) & 7);
+  ARDAE_CHECK_ARG(d.kind == 5 || (d.flags >> 1) == 0, "model: the sampler-head bits of desc.flags belong to kind 5");
+  if (d.kind == 5) {   // a concat block needs its projected skip (same_dim would make the skip the 612-wide concat itself)
+    const int ht = (d.flags >> 1) & 7;
+    ARDAE_CHECK_ARG(ht == HEAD_MLP || 512 + d.noise_dim != d.h_dim, "model: ResConvIPVAE with c_dim + noise_dim == h_dim (identity skip over the concat input) is not built");
+  }
   return 0;
 }
 
@@ -406,7 +447,7 @@ int blk_fwd(const Blk& b, const BlkPk& k, const float* params, const float* pack
 
 // scratch of one block's backward (reused from block to block) and the gradient destinations of its three operators
 struct BwdScratch { float *g, *dh, *dcols; };
-struct WnGrad { float* dW; float* db; };
+struct WnGrad { float* dW; float* db; float beta; };   // beta: accumulate into the destination (plain operators write the gradient buffer itself)
 struct BlkGrad { WnGrad a, h, s; };
 
 void push_wgrad(std::vector<WgradProblem>& probs, std::vector<std::pair<size_t, size_t>>& need, int M, int O, int I, const float* G, const float* X, int ldX,
@@ -494,7 +535,8 @@ struct ResWs {
   float* x2; std::vector<BlkBuf> tb; float *flat, *inp;             // 2x-1, block buffers, NCHW-flattened conv output [B,512], trunk output [B,cdim]
   // sampler (R = B*nz rows)
   float *zero;                                                      // zero noise for encode(std=0)
-  float *rb0, *rb1, *h0, *t1, *h1, *z;                              // kind 5: row biases [B,hdim] x2, fc0 hidden / output [R,hdim], fc1 hidden [R,zd], z [R,zd]
+  struct HeadBuf { float *rba, *rbs, *hmid, *out; };                // kind 5, per head operator: per-image row biases [B,out] (concat), ResLinear hidden [R,out], output [R,out]
+  std::vector<HeadBuf> hb; float* z;                                // z [R,zd]
   float *mu0, *lv0r, *lv0, *z0, *rbh, *hh, *mu, *lvr, *lv;          // kind 6
   // decoder (R images)
   std::vector<BlkBuf> db; float *d4, *u8, *c7, *u14, *u28;          // block buffers; NHWC 4x4x32, upsampled / cropped maps
@@ -518,8 +560,15 @@ void res_carve(const ResLayout& P, Bump& ws, int B, int nz, int mode, ResWs& W) 
     W.inp = W.tb.back().out;
     W.zero = ws.take(R * (P.nd + P.zd));
     if (P.kind == 5) {
-      W.rb0 = ws.take((size_t)B * P.hdim); W.rb1 = ws.take((size_t)B * P.hdim);
-      W.h0 = ws.take(R * P.hdim); W.t1 = ws.take(R * P.hdim); W.h1 = ws.take(R * P.zd); W.z = ws.take(R * P.zd);
+      W.hb.resize(P.head.size());
+      for (size_t i = 0; i < P.head.size(); ++i) {
+        const HeadOp& o = P.head[i];
+        W.hb[i].rba = o.concat ? ws.take((size_t)B * o.out) : nullptr;
+        W.hb[i].rbs = (o.concat && o.res) ? ws.take((size_t)B * o.out) : nullptr;
+        W.hb[i].hmid = o.res ? ws.take(R * o.out) : nullptr;
+        W.hb[i].out = ws.take(R * o.out);
+      }
+      W.z = ws.take(R * P.zd);
     } else {
       W.mu0 = ws.take((size_t)B * P.nd); W.lv0r = ws.take((size_t)B * P.nd); W.lv0 = ws.take((size_t)B * P.nd); W.z0 = ws.take(R * P.nd);
       W.rbh = ws.take((size_t)B * P.cdim); W.hh = ws.take(R * P.cdim); W.mu = ws.take(R * P.zd); W.lvr = ws.take(R * P.zd); W.lv = ws.take(R * P.zd);
@@ -556,8 +605,14 @@ void res_carve(const ResLayout& P, Bump& ws, int B, int nz, int mode, ResWs& W) 
     };
     for (auto& b : P.trunk) wupd(b, B);
     for (auto& b : P.dec) wupd(b, R);
-    // sampler tail: up to six problems in one batch
+    // sampler tail: all problems of a head operator in one batch
     const int Ri = (int)R;
+    for (auto& o : P.head) {
+      const int cin = o.concat ? P.nd : o.in;
+      size_t need = 3 * wgrad_scratch_floats(Ri, o.out, std::max(cin, o.out));
+      if (o.concat) need += 2 * wgrad_scratch_floats(B, o.out, P.cdim);
+      wsf = max_sz(wsf, need);
+    }
     wsf = max_sz(wsf, 2 * (wgrad_scratch_floats(Ri, P.hdim, P.hdim) + wgrad_scratch_floats(Ri, P.hdim, P.cdim + P.nd) + wgrad_scratch_floats(Ri, P.zd, P.hdim)) +
                           3 * wgrad_scratch_floats(B, P.nd, P.cdim) + 2 * wgrad_scratch_floats(B, P.hdim, P.cdim));
     W.wscratch_floats = wsf + 1024;
@@ -590,19 +645,48 @@ int sampler_fwd(const ResLayout& P, const ResPacked& K, const float* params, con
                 float* hidden_out, hipStream_t st) {
   const int R = B * nz;
   if (P.kind == 5) {
-    const Blk &b0 = P.fc0, &b1 = P.fc1;
-    const BlkPk &k0 = K.fc0, &k1 = K.fc1;
-    // per-image halves of the concat input as row biases: rb0 = W0h[:, :c] inp + b0h, rb1 = W01[:, :c] inp + (bh1 + b01)
-    { LinArgs A{}; A.bias = params + b0.a.bias; A.Y = W.rb0; A.ldY = P.hdim; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.hdim, W.inp, P.cdim, P.cdim, packed + k0.a_fi, A, st)); }
-    { LinArgs A{}; A.bias = packed + k0.bsum; A.Y = W.rb1; A.ldY = P.hdim; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.hdim, W.inp, P.cdim, P.cdim, packed + k0.s_fi, A, st)); }
-    { LinArgs A{}; A.rowbias = W.rb0; A.rowbias_ld = P.hdim; A.rows_per_group = nz; A.Y = W.h0; A.ldY = P.hdim;
-      ARDAE_TRY(lin1(EPI_ACT, ACT_RELU, R, P.hdim, noise, P.nd, P.nd, packed + k0.a_fn, A, st)); }
-    { LinArgs A{}; A.rowbias = W.rb1; A.rowbias_ld = P.hdim; A.rows_per_group = nz; A.Y = W.t1; A.ldY = P.hdim;
-      ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, P.hdim, W.h0, P.hdim, P.hdim, packed + k0.h.f, noise, P.nd, P.nd, packed + k0.s_fn, A, st)); }
-    RES_LAUNCH(act_inplace_kernel, (int64_t)R * P.hdim, W.t1, (int)ACT_ELU, (int64_t)R * P.hdim);
-    { LinArgs A{}; A.bias = params + b1.a.bias; A.Y = W.h1; A.ldY = P.zd; ARDAE_TRY(lin1(EPI_ACT, ACT_RELU, R, P.zd, W.t1, P.hdim, P.hdim, packed + k1.a.f, A, st)); }
-    { LinArgs A{}; A.bias = packed + k1.bsum; A.Y = z_out; A.ldY = P.zd;
-      ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, P.zd, W.h1, P.zd, P.zd, packed + k1.h.f, W.t1, P.hdim, P.hdim, packed + k1.s.f, A, st)); }
+    // encode.fc operator by operator; the per-image half of a concat input enters as a row bias (computed once per image)
+    const float* x = nullptr;
+    for (size_t i = 0; i < P.head.size(); ++i) {
+      const HeadOp& o = P.head[i];
+      const ResPacked::HeadPk& hk = K.head[i];
+      ResWs::HeadBuf& u = W.hb[i];
+      float* out = i + 1 == P.head.size() ? z_out : u.out;
+      if (o.res) {
+        const Blk& b = o.b; const BlkPk& k = hk.k;
+        if (o.concat) {
+          // rba = W0h[:, :c] inp + b0h, rbs = W01[:, :c] inp + (bh1 + b01)
+          { LinArgs A{}; A.bias = params + b.a.bias; A.Y = u.rba; A.ldY = o.out; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, o.out, W.inp, P.cdim, P.cdim, packed + k.a_fi, A, st)); }
+          { LinArgs A{}; A.bias = packed + k.bsum; A.Y = u.rbs; A.ldY = o.out; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, o.out, W.inp, P.cdim, P.cdim, packed + k.s_fi, A, st)); }
+          { LinArgs A{}; A.rowbias = u.rba; A.rowbias_ld = o.out; A.rows_per_group = nz; A.Y = u.hmid; A.ldY = o.out;
+            ARDAE_TRY(lin1(EPI_ACT, ACT_RELU, R, o.out, noise, P.nd, P.nd, packed + k.a_fn, A, st)); }
+          { LinArgs A{}; A.rowbias = u.rbs; A.rowbias_ld = o.out; A.rows_per_group = nz; A.Y = out; A.ldY = o.out;
+            ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, o.out, u.hmid, o.out, o.out, packed + k.h.f, noise, P.nd, P.nd, packed + k.s_fn, A, st)); }
+        } else {
+          { LinArgs A{}; A.bias = params + b.a.bias; A.Y = u.hmid; A.ldY = o.out; ARDAE_TRY(lin1(EPI_ACT, ACT_RELU, R, o.out, x, o.in, o.in, packed + k.a.f, A, st)); }
+          if (!b.same) {
+            LinArgs A{}; A.bias = packed + k.bsum; A.Y = out; A.ldY = o.out;
+            ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, o.out, u.hmid, o.out, o.out, packed + k.h.f, x, o.in, o.in, packed + k.s.f, A, st));
+          } else {   // identity skip (ResLinear(same_dim=True), models/layers.py:82-84)
+            LinArgs A{}; A.bias = params + b.h.bias; A.Y = out; A.ldY = o.out;
+            ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, o.out, u.hmid, o.out, o.out, packed + k.h.f, A, st));
+            ARDAE_TRY(launch_axpy(x, (int64_t)R * o.out, 1.f, out, st));
+          }
+        }
+      } else {
+        const Lin& l = o.l; const LinPk& k = hk.lk;
+        if (o.concat) {
+          { LinArgs A{}; A.bias = params + l.b; A.Y = u.rba; A.ldY = o.out; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, o.out, W.inp, P.cdim, P.cdim, packed + k.fi, A, st)); }
+          { LinArgs A{}; A.rowbias = u.rba; A.rowbias_ld = o.out; A.rows_per_group = nz; A.Y = out; A.ldY = o.out;
+            ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, o.out, noise, P.nd, P.nd, packed + k.fn, A, st)); }
+        } else {
+          LinArgs A{}; A.bias = params + l.b; A.Y = out; A.ldY = o.out;
+          ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, o.out, x, o.in, o.in, packed + k.f, A, st));
+        }
+      }
+      if (o.act != ACT_NONE) RES_LAUNCH(act_inplace_kernel, (int64_t)R * o.out, out, o.act, (int64_t)R * o.out);
+      x = out;
+    }
     return 0;
   }
   const int ldn = P.nd + P.zd;
@@ -651,14 +735,16 @@ struct GradMap {
   const ResLayout& P; float* dweff; float* dbias; size_t boff = 0;
   std::vector<WnBwdItem> items;
   const float* params; const float* packed; float* grads;
+  float grads_beta = 0.f;
   WnGrad wn(const WN& w, const WNPk& k) {
-    WnGrad g; g.dW = dweff + w.dir; g.db = dbias + boff; boff += al64(w.O);
+    if (w.plain) return WnGrad{grads + w.dir, grads + w.bias, grads_beta};     // nn.Linear operator: the weight gradient IS the parameter gradient
+    WnGrad g; g.dW = dweff + w.dir; g.db = dbias + boff; g.beta = 0.f; boff += al64(w.O);
     WnBwdItem it; it.dW = g.dW; it.dir = params + w.dir; it.scale = params + w.scale; it.inv = packed + k.inv; it.db = g.db;
     it.gdir = grads + w.dir; it.gscale = grads + w.scale; it.gbias = grads + w.bias; it.O = w.O; it.I = w.I; it.norm = w.norm ? 1 : 0;
     items.push_back(it);
     return g;
   }
-  BlkGrad blk(const Blk& b, const BlkPk& k) { BlkGrad g; g.a = wn(b.a, k.a); g.h = wn(b.h, k.h); g.s = wn(b.s, k.s); return g; }
+  BlkGrad blk(const Blk& b, const BlkPk& k) { BlkGrad g; g.a = wn(b.a, k.a); g.h = wn(b.h, k.h); g.s = b.same ? g.h : wn(b.s, k.s); return g; }
 };
 
 }  // namespace
@@ -677,24 +763,28 @@ int res_model_pack(const ardae_model_desc& d, const float* params, float* packed
   const ResPacked K(P);
   std::vector<PackItem> items;
   std::vector<WnComposeItem> comp;
+  // effective weight of an operator: composed into the packed buffer (weight norm), or the parameter itself (plain nn.Linear operator)
+  auto weff = [&](const WN& w, const WNPk& k) -> const float* { return w.plain ? params + w.dir : packed + k.weff; };
   auto wn = [&](const WN& w, const WNPk& k) -> int {
-    comp.push_back(WnComposeItem{params + w.dir, params + w.scale, packed + k.weff, packed + k.inv, w.O, w.I, w.norm ? 1 : 0, nullptr, nullptr});
-    items.push_back(PackItem{packed + k.weff, w.I, w.O, w.I, 0, packed + k.f});
-    items.push_back(PackItem{packed + k.weff, w.I, w.I, w.O, 1, packed + k.b});
+    if (!w.plain) comp.push_back(WnComposeItem{params + w.dir, params + w.scale, packed + k.weff, packed + k.inv, w.O, w.I, w.norm ? 1 : 0, nullptr, nullptr});
+    items.push_back(PackItem{weff(w, k), w.I, w.O, w.I, 0, packed + k.f});
+    items.push_back(PackItem{weff(w, k), w.I, w.I, w.O, 1, packed + k.b});
     return 0;
   };
   auto blk = [&](const Blk& b, const BlkPk& k, int split) -> int {
-    ARDAE_TRY(wn(b.a, k.a)); ARDAE_TRY(wn(b.h, k.h)); ARDAE_TRY(wn(b.s, k.s));
+    ARDAE_TRY(wn(b.a, k.a)); ARDAE_TRY(wn(b.h, k.h));
+    if (b.same) return 0;          // identity skip: no third operator, the block's bias is b_h1
+    ARDAE_TRY(wn(b.s, k.s));
     // bsum = b_h + b_s rides in the same launch
     comp.push_back(WnComposeItem{nullptr, nullptr, packed + k.bsum, nullptr, b.Cout, 0, 0, params + b.h.bias, params + b.s.bias});
     if (split) {
       const int nn = b.a.I - split;
-      items.push_back(PackItem{packed + k.a.weff, b.a.I, b.a.O, split, 0, packed + k.a_fi});
-      items.push_back(PackItem{packed + k.a.weff + split, b.a.I, b.a.O, nn, 0, packed + k.a_fn});
-      items.push_back(PackItem{packed + k.a.weff, b.a.I, split, b.a.O, 1, packed + k.a_bi});
-      items.push_back(PackItem{packed + k.s.weff, b.s.I, b.s.O, split, 0, packed + k.s_fi});
-      items.push_back(PackItem{packed + k.s.weff + split, b.s.I, b.s.O, nn, 0, packed + k.s_fn});
-      items.push_back(PackItem{packed + k.s.weff, b.s.I, split, b.s.O, 1, packed + k.s_bi});
+      items.push_back(PackItem{weff(b.a, k.a), b.a.I, b.a.O, split, 0, packed + k.a_fi});
+      items.push_back(PackItem{weff(b.a, k.a) + split, b.a.I, b.a.O, nn, 0, packed + k.a_fn});
+      items.push_back(PackItem{weff(b.a, k.a), b.a.I, split, b.a.O, 1, packed + k.a_bi});
+      items.push_back(PackItem{weff(b.s, k.s), b.s.I, b.s.O, split, 0, packed + k.s_fi});
+      items.push_back(PackItem{weff(b.s, k.s) + split, b.s.I, b.s.O, nn, 0, packed + k.s_fn});
+      items.push_back(PackItem{weff(b.s, k.s), b.s.I, split, b.s.O, 1, packed + k.s_bi});
     }
     return 0;
   };
@@ -709,8 +799,12 @@ int res_model_pack(const ardae_model_desc& d, const float* params, float* packed
     }
   };
   for (size_t i = 0; i < P.trunk.size(); ++i) ARDAE_TRY(blk(P.trunk[i], K.trunk[i], 0));
-  if (P.kind == 5) { ARDAE_TRY(blk(P.fc0, K.fc0, P.cdim)); ARDAE_TRY(blk(P.fc1, K.fc1, 0)); }
-  else { lin(P.mu0, K.mu0, 0); lin(P.lv0, K.lv0, 0); lin(P.efc, K.efc, P.cdim); lin(P.mu, K.mu, 0); lin(P.lv, K.lv, 0); }
+  if (P.kind == 5) {
+    for (size_t i = 0; i < P.head.size(); ++i) {
+      const HeadOp& o = P.head[i];
+      if (o.res) ARDAE_TRY(blk(o.b, K.head[i].k, o.concat ? P.cdim : 0)); else lin(o.l, K.head[i].lk, o.concat ? P.cdim : 0);
+    }
+  } else { lin(P.mu0, K.mu0, 0); lin(P.lv0, K.lv0, 0); lin(P.efc, K.efc, P.cdim); lin(P.mu, K.mu, 0); lin(P.lv, K.lv, 0); }
   for (size_t i = 0; i < P.dec.size(); ++i) ARDAE_TRY(blk(P.dec[i], K.dec[i], 0));
   for (size_t i0 = 0; i0 < comp.size(); i0 += WNC_MAX) {
     WnComposeBatch cb;
@@ -781,6 +875,7 @@ int res_model_vae_backward(const ardae_model_desc& d, const float* params, const
   const int R = B * nz;
   const float gscale = dloss / (float)R;
   GradMap gm{P, W.dweff, W.dbias, 0, {}, params, packed, grads};
+  gm.grads_beta = grads_beta;
   // loss gradients: d logits, dz = gscale beta z + dz_extra
   ARDAE_TRY(launch_vae_loss(0, W.db[6].out, nullptr, x, W.z, R, nz, 784, P.zd, beta, 1, gscale, dz_extra, W.rec_row, W.pri_row, W.dlogit, nullptr, W.dzq, st));
   // ---- decoder backward (d_out ping-pongs between W.da and W.dbuf)
@@ -804,32 +899,69 @@ int res_model_vae_backward(const ardae_model_desc& d, const float* params, const
   std::vector<std::pair<size_t, size_t>> dummy;
   std::vector<WnBwdItem> plain;     // plain nn.Linear gradients are written in place by the wgrad kernel (no weight norm)
   if (P.kind == 5) {
-    const Blk &b0 = P.fc0, &b1 = P.fc1;
-    const BlkPk &k0 = K.fc0, &k1 = K.fc1;
-    const BlkGrad g0 = gm.blk(b0, k0), g1 = gm.blk(b1, k1);
-    // fc1: z = W_h1 relu(W_0h t1 + b) + W_01 t1 + bsum   (no activation after it)
-    float* dh1 = W.sc.dh;          // [R, zd]
-    { LinArgs A{}; A.S = W.h1; A.ldS = P.zd; A.Y = dh1; A.ldY = P.zd; ARDAE_TRY(lin1(EPI_DACT, ACT_RELU, R, P.zd, W.dzq, P.zd, P.zd, packed + k1.h.b, A, st)); }
-    push_wgrad(probs, dummy, R, P.zd, P.zd, W.dzq, W.h1, P.zd, g1.h.dW, P.zd, g1.h.db);
-    push_wgrad(probs, dummy, R, P.zd, P.hdim, W.dzq, W.t1, P.hdim, g1.s.dW, P.hdim, g1.s.db);
-    push_wgrad(probs, dummy, R, P.zd, P.hdim, dh1, W.t1, P.hdim, g1.a.dW, P.hdim, g1.a.db);
-    float* dt1 = W.dR0;            // [R, hdim]: d t1 = (W_01^T dz + W_0h^T dh1) * elu'(t1)
-    { LinArgs A{}; A.Y = dt1; A.ldY = P.hdim; ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, P.hdim, W.dzq, P.zd, P.zd, packed + k1.s.b, dh1, P.zd, P.zd, packed + k1.a.b, A, st)); }
-    RES_LAUNCH(mul_dact_kernel, (int64_t)R * P.hdim, dt1, W.t1, (int)ACT_ELU, dt1, (int64_t)R * P.hdim);
-    // fc0: t1_pre = W_h1 h0 + W_01 [inp | noise] + bsum,  h0 = relu(W_0h [inp | noise] + b_0h)
-    float* dh0 = W.dR1;            // [R, hdim]
-    { LinArgs A{}; A.S = W.h0; A.ldS = P.hdim; A.Y = dh0; A.ldY = P.hdim; ARDAE_TRY(lin1(EPI_DACT, ACT_RELU, R, P.hdim, dt1, P.hdim, P.hdim, packed + k0.h.b, A, st)); }
-    ARDAE_TRY(launch_segment_sum(dt1, P.hdim, B, nz, P.hdim, 1.f, W.dB0, P.hdim, st));      // d rb1 [B, hdim]
-    ARDAE_TRY(launch_segment_sum(dh0, P.hdim, B, nz, P.hdim, 1.f, W.dB1, P.hdim, st));      // d rb0 [B, hdim]
-    const int I0 = P.cdim + P.nd;
-    push_wgrad(probs, dummy, R, P.hdim, P.hdim, dt1, W.h0, P.hdim, g0.h.dW, P.hdim, g0.h.db);
-    push_wgrad(probs, dummy, R, P.hdim, P.nd, dt1, noise, P.nd, g0.s.dW + P.cdim, I0, g0.s.db);          // noise columns of W_01
-    push_wgrad(probs, dummy, B, P.hdim, P.cdim, W.dB0, W.inp, P.cdim, g0.s.dW, I0, nullptr);             // image columns of W_01
-    push_wgrad(probs, dummy, R, P.hdim, P.nd, dh0, noise, P.nd, g0.a.dW + P.cdim, I0, g0.a.db);
-    push_wgrad(probs, dummy, B, P.hdim, P.cdim, W.dB1, W.inp, P.cdim, g0.a.dW, I0, nullptr);
-    ARDAE_TRY(flush_wgrad(probs, W.wscratch, W.wscratch_floats, st));
-    { LinArgs A{}; A.Y = W.dinp; A.ldY = P.cdim;
-      ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, B, P.cdim, W.dB0, P.hdim, P.hdim, packed + k0.s_bi, W.dB1, P.hdim, P.hdim, packed + k0.a_bi, A, st)); }
+    // encode.fc backwards, operator by operator: g = dL/d(output of the operator) [R, out]
+    auto pw = [&](int M, int O, int I, const float* G, const float* X, int ldX, const WnGrad& g, int col0, int ldout, bool bias) {
+      push_wgrad(probs, dummy, M, O, I, G, X, ldX, g.dW + col0, ldout, bias ? g.db : nullptr);
+      probs.back().beta = g.beta;
+    };
+    float* g = W.dzq;
+    float* pp[2] = {W.dR0, W.dR1};
+    for (int i = (int)P.head.size() - 1; i >= 0; --i) {
+      const HeadOp& o = P.head[i];
+      const ResPacked::HeadPk& hk = K.head[i];
+      const ResWs::HeadBuf& u = W.hb[i];
+      const float* out = i + 1 == (int)P.head.size() ? W.z : u.out;
+      const float* x = i == 0 ? nullptr : W.hb[i - 1].out;        // the operator's input (post-activation output of its predecessor)
+      float* dx = pp[i & 1];
+      if (o.act != ACT_NONE) RES_LAUNCH(mul_dact_kernel, (int64_t)R * o.out, g, out, o.act, g, (int64_t)R * o.out);
+      if (o.res) {
+        const Blk& b = o.b; const BlkPk& k = hk.k;
+        const BlkGrad gr = gm.blk(b, k);
+        float* dh = W.sc.dh;       // [R, out]: d hmid = (g W_h1) relu'(hmid)
+        { LinArgs A{}; A.S = u.hmid; A.ldS = o.out; A.Y = dh; A.ldY = o.out; ARDAE_TRY(lin1(EPI_DACT, ACT_RELU, R, o.out, g, o.out, o.out, packed + k.h.b, A, st)); }
+        pw(R, o.out, o.out, g, u.hmid, o.out, gr.h, 0, o.out, true);
+        if (o.concat) {
+          const int I0 = P.cdim + P.nd;
+          ARDAE_TRY(launch_segment_sum(g, o.out, B, nz, o.out, 1.f, W.dB0, o.out, st));       // d rbs [B, out]
+          ARDAE_TRY(launch_segment_sum(dh, o.out, B, nz, o.out, 1.f, W.dB1, o.out, st));      // d rba [B, out]
+          pw(R, o.out, P.nd, g, noise, P.nd, gr.s, P.cdim, I0, true);                           // noise columns of W_01 (+ its bias)
+          pw(B, o.out, P.cdim, W.dB0, W.inp, P.cdim, gr.s, 0, I0, false);                       // image columns of W_01
+          pw(R, o.out, P.nd, dh, noise, P.nd, gr.a, P.cdim, I0, true);
+          pw(B, o.out, P.cdim, W.dB1, W.inp, P.cdim, gr.a, 0, I0, false);
+          ARDAE_TRY(flush_wgrad(probs, W.wscratch, W.wscratch_floats, st));
+          LinArgs A{}; A.Y = W.dinp; A.ldY = P.cdim;
+          ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, B, P.cdim, W.dB0, o.out, o.out, packed + k.s_bi, W.dB1, o.out, o.out, packed + k.a_bi, A, st));
+        } else {
+          if (!b.same) pw(R, o.out, o.in, g, x, o.in, gr.s, 0, o.in, true);
+          pw(R, o.out, o.in, dh, x, o.in, gr.a, 0, o.in, true);
+          ARDAE_TRY(flush_wgrad(probs, W.wscratch, W.wscratch_floats, st));
+          LinArgs A{}; A.Y = dx; A.ldY = o.in;
+          if (!b.same) {
+            ARDAE_TRY(lin2(EPI_ACT, ACT_NONE, R, o.in, g, o.out, o.out, packed + k.s.b, dh, o.out, o.out, packed + k.a.b, A, st));
+          } else {   // identity skip: dx = dh W_0h + g
+            ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, o.in, dh, o.out, o.out, packed + k.a.b, A, st));
+            ARDAE_TRY(launch_axpy(g, (int64_t)R * o.in, 1.f, dx, st));
+          }
+        }
+      } else {
+        const Lin& l = o.l; const LinPk& k = hk.lk;
+        const WnGrad gl{grads + l.w, grads + l.b, grads_beta};
+        if (o.concat) {
+          ARDAE_TRY(launch_segment_sum(g, o.out, B, nz, o.out, 1.f, W.dB0, o.out, st));       // d rba [B, out]
+          pw(R, o.out, P.nd, g, noise, P.nd, gl, P.cdim, l.in, true);
+          pw(B, o.out, P.cdim, W.dB0, W.inp, P.cdim, gl, 0, l.in, false);
+          ARDAE_TRY(flush_wgrad(probs, W.wscratch, W.wscratch_floats, st));
+          LinArgs A{}; A.Y = W.dinp; A.ldY = P.cdim;
+          ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.cdim, W.dB0, o.out, o.out, packed + k.bi, A, st));
+        } else {
+          pw(R, o.out, o.in, g, x, o.in, gl, 0, l.in, true);
+          ARDAE_TRY(flush_wgrad(probs, W.wscratch, W.wscratch_floats, st));
+          LinArgs A{}; A.Y = dx; A.ldY = o.in;
+          ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, o.in, g, o.out, o.out, packed + k.b, A, st));
+        }
+      }
+      g = dx;
+    }
   } else {
     const int ldn = P.nd + P.zd;
     auto plain_wgrad = [&](int M, const Lin& l, const float* G, const float* X, int ldX, int col0, int I, bool bias) {

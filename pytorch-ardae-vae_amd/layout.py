@@ -16,7 +16,7 @@ def _mlp(prefix, din, dh, dout, n_hidden, extra_in=0):
     return spec
 
 
-def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers):
+def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers, enc_type="res-wn-mlp"):
     if kind == "mnist":
         s = _mlp("encode.inp_encode.", input_dim, h_dim, h_dim, n_layers + 1)
         s += _mlp("encode.fc.", h_dim + noise_dim, h_dim, z_dim, 1)
@@ -48,7 +48,7 @@ def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers):
             s += block(f"{tp}{i}.", o, inn, True)
         s += block(f"{tp}11.", cdim, 512, False)
         if kind == "resconv":
-            s += block("encode.fc.layers.0.", h_dim, cdim + noise_dim, False) + block("encode.fc.fc.", z_dim, h_dim, False)
+            s += resconv_head_spec(enc_type, n_layers, cdim + noise_dim, h_dim, z_dim)
         else:
             s += [("encode.aux_encode.reparam.mean_fn.weight", (noise_dim, cdim)), ("encode.aux_encode.reparam.mean_fn.bias", (noise_dim,)),
                   ("encode.aux_encode.reparam.logvar_fn.weight", (noise_dim, cdim)), ("encode.aux_encode.reparam.logvar_fn.bias", (noise_dim,)),
@@ -112,3 +112,35 @@ def offsets(spec):
         out[name] = (off, n, shape)
         off += n
     return out, off
+
+
+RESCONV_HEADS = {"res-wn-mlp": 0, "mlp": 1, "res-mlp": 2, "res-wn-mlp-lin": 3, "res-mlp-lin": 4}     # ardae_model_desc.flags bits 1-3
+
+
+def resconv_head_spec(enc_type, n_layers, cin, h_dim, z_dim):
+    """Parameters of ResConvIPVAE's sampler head `encode.fc` in the reference's order (models/ivae/resconv.py:101-116): an MLP
+    ('mlp'), a ResMLP of ResLinear blocks ('res-wn-mlp': un-normalised WeightNormalizedLinear operators direction / scale / bias;
+    'res-mlp': nn.Linear operators weight / bias; models/layers.py:25-85,477-515,559-622) or `Sequential(ResMLP(... -> h_dim, output
+    activated), Linear(h_dim, z_dim))` ('-lin').  A ResLinear whose input and output widths coincide has no skip operator (same_dim)."""
+    if enc_type not in RESCONV_HEADS:
+        raise AssertionError(enc_type)                      # ivae/resconv.py:77
+    lin = lambda pre, out, inn: [(pre + "weight", (out, inn)), (pre + "bias", (out,))]
+
+    def oper(pre, out, inn, wn):
+        return [(pre + "direction", (out, inn)), (pre + "scale", (out,)), (pre + "bias", (out,))] if wn else lin(pre, out, inn)
+
+    def res(pre, out, inn, wn):
+        return oper(pre + "dot_0h.", out, inn, wn) + oper(pre + "dot_h1.", out, out, wn) + ([] if inn == out else oper(pre + "dot_01.", out, inn, wn))
+    s = []
+    if enc_type == "mlp":
+        for i in range(n_layers):
+            s += lin(f"encode.fc.layers.{i}.", h_dim, cin if i == 0 else h_dim)
+        return s + lin("encode.fc.fc.", z_dim, h_dim)
+    wn = enc_type.startswith("res-wn")
+    if enc_type in ("res-wn-mlp", "res-mlp"):
+        for i in range(n_layers):
+            s += res(f"encode.fc.layers.{i}.", h_dim, cin if i == 0 else h_dim, wn)
+        return s + res("encode.fc.fc.", z_dim, h_dim, wn)
+    for i in range(n_layers - 1):
+        s += res(f"encode.fc.0.layers.{i}.", h_dim, cin if i == 0 else h_dim, wn)
+    return s + res("encode.fc.0.fc.", h_dim, cin if n_layers == 1 else h_dim, wn) + lin("encode.fc.1.", z_dim, h_dim)

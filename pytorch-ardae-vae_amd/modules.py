@@ -296,12 +296,14 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self.latent_dim = z_dim
         self.nonlinearity, self.num_hidden_layers, self.init, self.enc_type = nonlinearity, num_hidden_layers, init, enc_type
         flags = L.MODEL_NO_CENTER if self._kind in ("resconv", "auxresconv") and not getattr(self, "do_center", True) else 0
+        flags |= getattr(self, "_flag_extra", 0)
         self._desc = L.ModelDesc(KIND_IDS[self._kind], input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, L.ACT[nonlinearity], flags)
         # floats per row of a sampler draw: the aux models take two draws per call, laid out side by side [eps0 | eps]
         self._noise_width = noise_dim + z_dim if self._kind in AUX_KINDS else noise_dim
         # columns of the `hidden1a` cDAE context (ivae_ardae.py:572-580): cat(h0, h) for the MLP / conv aux models, h alone for auxresconv
         self.hidden_dim = {"auxmnist": 2 * h_dim, "auxconv": 2 * h_dim, "auxresconv": h_dim}.get(self._kind, 0)
-        self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers), {"encode": _EncodeBox})
+        self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, **getattr(self, "_spec_extra", {})),
+                           {"encode": _EncodeBox})
         object.__setattr__(self.encode, "_owner_ref", weakref.ref(self))   # `model.encode(x, std=0)` (ivae_ardae.py:735)
         self.reset_parameters()
 
@@ -551,17 +553,25 @@ class MNISTConvAuxIPVAE(ImplicitPosteriorVAE):
 
 
 class ResConvIPVAE(ImplicitPosteriorVAE):
-    """models/ivae/resconv.py::ImplicitPosteriorVAE as `--model resconvct-res` (do_center=True; ivae_ardae.py:359-370, the shipped "implicit
-    resconv" recipe) and `--model resconv-res` (do_center=False, :347-358) build it: weight-normalised residual-conv trunk and decoder, ResMLP sampler head, ELU, 28x28x1, c_dim 512."""
+    """models/ivae/resconv.py::ImplicitPosteriorVAE as the ten `--model resconv*` choices build it (ivae_ardae.py:323-442): weight-normalised
+    residual-conv trunk and decoder, ELU, 28x28x1, c_dim 512, do_center either way, and every sampler head of `enc_type`:
+    'mlp' (resconv / resconvct), 'res-wn-mlp' (-res: the shipped "implicit resconv" recipe), 'res-mlp' (-res2), 'res-wn-mlp-lin' (-res3),
+    'res-mlp-lin' (-res4), with 1 .. 4 hidden layers (`--model-n-layers`)."""
     _kind = "resconv"
 
     def __init__(self, energy_func=normal_energy_func, input_height=28, input_channels=1, z_dim=32, noise_dim=100, c_dim=512, h_dim=800,
                  num_hidden_layers=1, nonlinearity="elu", do_center=False, do_m5bias=False, enc_noise=False, enc_type="mlp"):
         if input_height != 28 or input_channels != 1:
             raise AssertionError("input_height == 28 and input_channels == 1")           # ivae/resconv.py:218-219
-        if enc_type != "res-wn-mlp" or enc_noise or do_m5bias or c_dim != 512 or num_hidden_layers != 1:
-            raise NotImplementedError("the HIP engine builds ResConvIPVAE as --model resconvct-res / resconv-res do: enc_type='res-wn-mlp', "
-                                      "c_dim=512, one ResMLP layer, no enc_noise / do_m5bias (do_center either way)")
+        assert enc_type in layout.RESCONV_HEADS                                          # ivae/resconv.py:77
+        assert num_hidden_layers > 0                                                     # ivae/resconv.py:73
+        if enc_noise or do_m5bias or c_dim != 512 or num_hidden_layers > 4:
+            raise NotImplementedError("the HIP engine builds ResConvIPVAE as ivae_ardae.py's --model resconv* choices do: c_dim=512, no enc_noise / "
+                                      "do_m5bias, at most 4 hidden layers (any enc_type, do_center either way)")
+        if enc_type != "mlp" and c_dim + noise_dim == h_dim:
+            raise NotImplementedError("c_dim + noise_dim == h_dim makes the first ResLinear's skip the concatenated input itself; not built")
+        self._flag_extra = layout.RESCONV_HEADS[enc_type] << L.MODEL_HEAD_SHIFT
+        self._spec_extra = {"enc_type": enc_type}
         self.input_height, self.input_channels, self.c_dim = input_height, input_channels, c_dim
         self.do_center, self.do_m5bias, self.enc_noise = do_center, do_m5bias, enc_noise
         super().__init__(energy_func, 784, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, "none", "concat")

@@ -46,6 +46,13 @@ def test_model_layout_matches_c_side(kind, args):
     _, total = layout.offsets(spec)
     d = L.ModelDesc({"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4, "resconv": 5, "auxresconv": 6}[kind], *args,
                     3 if "resconv" in kind else 2)
+    if kind == "resconv":       # every sampler head of ivae_ardae.py's --model resconv* choices, one to three hidden layers
+        for et, code in layout.RESCONV_HEADS.items():
+            for nl in (1, 2, 3):
+                _, tot = layout.offsets(layout.model_spec(kind, *args[:4], nl, enc_type=et))
+                dd = L.ModelDesc(5, *args[:4], nl, 3, code << L.MODEL_HEAD_SHIFT)
+                assert L.lib().ardae_model_param_floats(ctypes.byref(dd)) == tot, (et, nl)
+                assert L.lib().ardae_model_workspace_floats(ctypes.byref(dd), 4, 8, 1) > 0
     assert L.lib().ardae_model_param_floats(ctypes.byref(d)) == total
     assert L.lib().ardae_model_packed_floats(ctypes.byref(d)) > total
     assert L.lib().ardae_model_workspace_floats(ctypes.byref(d), 8, 16, 1) > 0

@@ -276,3 +276,25 @@ def test_cdae_cfg2_golden_summaries(golden_dir):
     sc = O.cdae_score(cc, pr, xbar.clone().requires_grad_(True), O.expand_rows(z0, 16), sigma[:, None], create_graph=True)
     g32 = dict(zip(pr.keys(), torch.autograd.grad(torch.nn.functional.mse_loss(sigma[:, None] * sc, -noise["eps"]), list(pr.values()), allow_unused=True)))
     assert_grads_close(g, g32, g64, names)
+
+
+@pytest.mark.parametrize("B,act", [(64, "softplus"), (512, "softplus"), (100, "relu"), (32, "softplus")])
+def test_cdae_score_per_image_chain_launch(B, act):
+    """The sigma = 0 score pass of the VAE update (glogprob on B rows, one row per image: models/graddae/mlp.py:446-483) runs as ONE launch
+    (`linear_small_chain_kernel`: 4 L + 2 per-image problems walked level by level, a row-block counter instead of a kernel boundary
+    between dependent layers; the hand-over stays inside one XCD's L2 when the kernel has verified that a row block's workgroups share
+    an XCD, else agent-scope release / acquire).  A synchronisation bug would show as a stale or torn read now and then: the pass is
+    repeated 25 times at the widths of config #2 and must return the SAME bits every time, equal to the oracle's score to fp32 accuracy;
+    64 rows = the 8-rank shard, 512 = one GPU, 100: a ragged last row block."""
+    cc = O.CdaeCfg("grad", 32, 32, 256, 3, act)
+    pc = O.init_params(O.cdae_param_spec(cc), 3)
+    flat = torch.cat([pc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)])
+    H = CdaeHarness(cc, flat)
+    g = torch.Generator().manual_seed(B)
+    x, ctx, sigma = torch.randn(B, 32, generator=g) * 30, torch.randn(B, 32, generator=g), torch.zeros(B)
+    first = H.score(x, sigma, ctx, B, 1)
+    assert torch.isfinite(first).all()
+    for _ in range(24):
+        assert torch.equal(H.score(x, sigma, ctx, B, 1), first)
+    ref = O.cdae_score(cc, {k: v.double() for k, v in pc.items()}, x.double().requires_grad_(True), ctx.double(), sigma.double()[:, None], create_graph=False)
+    assert rel_l2(first, ref.detach()) < 2e-5

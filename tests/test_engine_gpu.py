@@ -50,13 +50,21 @@ CASES["tiny_mnist_nstd3"] = (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), 
 # --model resconv-res / auxresconv: do_center=False (ivae_ardae.py:347-358,479-492)
 CASES["resconv_nocenter_b4_nz8"] = (O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 32, 64, 2), 8, False)
 CASES["auxresconv_nocenter_b4_nz8"] = (O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 450, 64, 2), 8, False)
+# the other sampler heads of ResConvIPVAE (ivae_ardae.py:323-346,371-442): --model resconv / resconvct ('mlp'), -res2 ('res-mlp'), -res3
+# ('res-wn-mlp-lin'), -res4 ('res-mlp-lin'), one and two hidden layers (two: ResLinear blocks with identity skips), centred and not
+RESCONV_HEAD_CASES = {"resconv_mlp_b4_nz8": ("mlp", 1, True), "resconv_mlp2_nocenter_b4_nz8": ("mlp", 2, False), "resconv_res2_b4_nz8": ("res-mlp", 1, False),
+                      "resconv_res2x2_b4_nz8": ("res-mlp", 2, True), "resconv_res3_b4_nz8": ("res-wn-mlp-lin", 1, True),
+                      "resconv_res3x2_b4_nz8": ("res-wn-mlp-lin", 2, False), "resconv_res4_b4_nz8": ("res-mlp-lin", 1, False),
+                      "resconv_resx2_b4_nz8": ("res-wn-mlp", 2, True)}
+for _nm, (_et, _nl, _ctr) in RESCONV_HEAD_CASES.items():
+    CASES[_nm] = (O.ModelCfg("resconv", 784, 100, 512, 32, _nl, "elu", do_center=_ctr, enc_type=_et), O.CdaeCfg("res", 32, 32, 64, 2), 8, False)
 RES_RECIPE = dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)     # run_vae_dbmnist.sh, the two resconv lines
 
 
 def build(mc, cc):
     if mc.kind == "resconv":
         model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers, noise_dim=mc.noise_dim,
-                                 nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type="res-wn-mlp")
+                                 nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type=mc.enc_type)
     elif mc.kind == "auxresconv":
         model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim, nonlinearity=mc.nonlin,
                                          do_center=mc.do_center)
@@ -725,7 +733,7 @@ def test_iwae_logprob_golden_auxconv(golden_dir):
     assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
 
 
-@pytest.mark.parametrize("name", ["resconv_b4_nz8", "auxresconv_b4_nz8"])
+@pytest.mark.parametrize("name", ["resconv_b4_nz8", "auxresconv_b4_nz8"] + list(RESCONV_HEAD_CASES))
 def test_resconv_vae_phase_grads_vs_oracle(golden_dir, name):
     """The weight-normalised residual-conv families: EVERY gradient tensor of the VAE phase - direction, scale and bias
     of all 45 weight-normalised operators (conv trunk, ResLinear / ResMLP sampler head or the two Gaussian heads with 'spm4' clipping,
@@ -768,11 +776,11 @@ def test_resconv_vae_phase_grads_vs_oracle(golden_dir, name):
     assert rel_l2(zs.reshape(B * 40, -1), O.encode(mc, pm, xv, nref, 40).reshape(B * 40, -1)) < 1e-5
 
 
-@pytest.mark.parametrize("name,kind,h", [("iwae_resconv", "resconv", 512), ("iwae_auxresconv", "auxresconv", 450)])
+@pytest.mark.parametrize("name,kind,h", [("iwae_resconv", "resconv", 512), ("iwae_auxresconv", "auxresconv", 450), ("iwae_resconv_mlp", "resconv", 512)])
 def test_iwae_logprob_golden_resconv(golden_dir, name, kind, h):
     """logprob (ivae/resconv.py:325-380, ivae/auxresconv.py:275-345) of the residual-conv models against the reference's value with injected draws."""
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-    mc = O.ModelCfg(kind, 784, 100, h, 32, 1, "elu")
+    mc = O.ModelCfg(kind, 784, 100, h, 32, 1, "elu", enc_type="mlp" if name.endswith("_mlp") else "res-wn-mlp")
     pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc))
     model, _ = build(mc, O.CdaeCfg("res", 32, 450 if kind == "auxresconv" else 32, 32, 2))
     model.load_state_dict(pm)

@@ -108,7 +108,11 @@ def test_oracle_step_matches_reference_fixture(golden_dir, name):
     # --model resconv-res / auxresconv: the same families with do_center=False
     ("resconv_nocenter_b4_nz8", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 32, 64, 2), "lt0"),
     ("auxresconv_nocenter_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 450, 64, 2), "hidden1a"),
-])
+    # the other sampler heads of ResConvIPVAE (--model resconv / resconvct, -res2, -res3, -res4; one and two hidden layers)
+] + [(nm, O.ModelCfg("resconv", 784, 100, 512, 32, nl, "elu", do_center=ctr, enc_type=et), O.CdaeCfg("res", 32, 32, 64, 2), "lt0") for nm, et, nl, ctr in (
+    ("resconv_mlp_b4_nz8", "mlp", 1, True), ("resconv_mlp2_nocenter_b4_nz8", "mlp", 2, False), ("resconv_res2_b4_nz8", "res-mlp", 1, False),
+    ("resconv_res2x2_b4_nz8", "res-mlp", 2, True), ("resconv_res3_b4_nz8", "res-wn-mlp-lin", 1, True), ("resconv_res3x2_b4_nz8", "res-wn-mlp-lin", 2, False),
+    ("resconv_res4_b4_nz8", "res-mlp-lin", 1, False), ("resconv_resx2_b4_nz8", "res-wn-mlp", 2, True))])
 def test_oracle_step_matches_reference_summaries(golden_dir, name, mc, cc, ctx):
     """Fixtures that hold summaries only (parameters regenerated from the seed): losses, latent statistics and the norm / sum /
     first elements of every gradient of step 0."""
@@ -189,6 +193,7 @@ def test_oracle_iwae_matches_reference_fixture_auxconv(golden_dir):
 
 
 @pytest.mark.parametrize("name,mc", [("iwae_resconv", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu")),
+                                     ("iwae_resconv_mlp", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", enc_type="mlp")),
                                      ("iwae_auxresconv", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu"))])
 def test_oracle_iwae_matches_reference_fixture_resconv(golden_dir, name, mc):
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
