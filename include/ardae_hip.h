@@ -186,6 +186,18 @@ int ardae_cdae_pack(const ardae_cdae_desc* d, const float* params, float* packed
 int ardae_cdae_loss_grads(const ardae_cdae_desc* d, const float* params, const float* packed, const float* xbar,
                           const float* sigma, const float* eps, const float* ctx, int B, int S, float* workspace,
                           size_t workspace_floats, float* loss, float* grads, float* score_out, void* stream);
+/* North star "fused per-sample Gaussian-perturb + sigma-scaling + DAE-forward kernel": ivae_ardae.py:753-776 in one call.  ONE kernel per
+ * image draws xi / eps (Philox, keyed as ardae_latent_perturb_draw), computes the latent statistics, sigma and xbar = u + sigma eps
+ * (graddae/mlp.py:21-23, ivae_ardae.py:753-767) and - the rows still in LDS - the first layer of the score network's input encoder,
+ * a_1 = act(xbar A_1^T + b_1) (graddae/mlp.py:414-434), written into the cDAE workspace; the rest is ardae_cdae_loss_grads from layer 2 on.
+ * xbar / sigma / eps_out / std_b are written as by ardae_latent_perturb_draw (the weight gradient of A_1 and the DAE-loss layer read them).
+ * ardae_cdae_perturb_fused_ok: 1 if the shape qualifies (nstd == 1, the draw kernel's conditions, z % 8 == 0, z <= 64, nz % 32 == 0,
+ * h % 32 == 0, relu / softplus); otherwise call ardae_latent_perturb* and ardae_cdae_loss_grads. */
+int ardae_cdae_perturb_fused_ok(const ardae_cdae_desc* d, int nz, int nstd);
+int ardae_cdae_perturb_loss_grads(const ardae_cdae_desc* d, const float* params, const float* packed, const float* latent, const float* z0,
+                                  const float* ctx, int B, int nz, float std_scale, float delta, uint64_t seed, uint64_t offset_xi,
+                                  uint64_t offset_eps, const void* state, uint64_t first_row, float* xbar, float* sigma, float* eps_out,
+                                  float* std_b, float* workspace, size_t workspace_floats, float* loss, float* grads, void* stream);
 /* ConditionalARDAE.glogprob (graddae/mlp.py:446-483): score at x [B*S,z] for noise level sigma [B*S] */
 int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float* packed, const float* x,
                      const float* sigma, const float* ctx, int B, int S, float* workspace, size_t workspace_floats,

@@ -106,6 +106,9 @@ EXPORTS = {
     "ardae_latent_perturb_draw_ok": (ctypes.c_int, [ctypes.c_int] * 3),
     "ardae_latent_perturb_draw": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [ctypes.c_uint64] * 3 +
                                   [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_void_p] * 5),
+    "ardae_cdae_perturb_fused_ok": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "ardae_cdae_perturb_loss_grads": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 2 + [ctypes.c_float] * 2 + [ctypes.c_uint64] * 3 +
+                                      [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_void_p] * 5 + [ctypes.c_size_t] + [ctypes.c_void_p] * 3),
     "ardae_center_scale": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2),
     "ardae_philox_normal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),
     "ardae_philox_uniform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),

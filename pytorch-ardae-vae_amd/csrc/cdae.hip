@@ -212,9 +212,16 @@ struct LayerRun {
   }
 };
 
+// where cdae_impl's workspace layout puts a_1 [N, h] (behind c_1..c_L and the per-image bias block, [B, h] each)
+float* cdae_a1_slot(const CdaeLayout& P, int B, float* workspace) {
+  Bump ws(workspace, ~size_t(0));
+  for (int l = 0; l <= P.L; ++l) ws.take((size_t)B * P.h);
+  return ws.take(1);
+}
+
 int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed, const float* xbar, const float* sigma,
               const float* eps, const float* ctx, int B, int S, float* workspace, size_t ws_floats, float* loss, float* grads,
-              float* score_out, bool need_grads, hipStream_t st) {
+              float* score_out, bool need_grads, hipStream_t st, bool a1_ready = false) {
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed && xbar && sigma && ctx && workspace, "cdae: null pointer argument");
   ARDAE_CHECK_ARG(B > 0 && S > 0 && (int64_t)B * S < (int64_t)1 << 30, "cdae: bad batch (B=%d, S=%d)", B, S);
@@ -268,13 +275,14 @@ int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed
     { LinArgs A{}; A.Y = g; A.ldY = z; add(lin_args(ACT_NONE, N, z, r[1], h, h, packed + K.inp_b[0], A), EPI_ACT, level++); }
     return launch_linear_small_chain(pr.data(), ep.data(), lv.data(), (int)pr.size(), chain_cnt, st);
   }
-  if (linear_small_eligible(inp_layer(1), EPI_ACT)) {
+  ARDAE_CHECK_ARG(!a1_ready || a[1] == cdae_a1_slot(P, B, workspace), "cdae: a_1 slot moved (workspace layout and cdae_a1_slot disagree)");
+  if (!a1_ready && linear_small_eligible(inp_layer(1), EPI_ACT)) {
     // few rows: the two encoders are independent chains of per-image launches - level l of both in ONE launch
     for (int l = 1; l <= L; ++l) ARDAE_TRY(launch_linear_pair(ctx_layer(l), inp_layer(l), EPI_ACT, st));
   } else {
     for (int l = 1; l <= L; ++l) ARDAE_TRY(launch_linear(ctx_layer(l), EPI_ACT, st));
     LayerRun run(EPI_ACT, st);
-    for (int l = 1; l <= L; ++l) run.v.push_back(inp_layer(l));
+    for (int l = a1_ready ? 2 : 1; l <= L; ++l) run.v.push_back(inp_layer(l));   // a1_ready: the perturbation kernel has written a_1
     ARDAE_TRY(run.flush());
   }
   {  // per-image bias of the first energy layer: cb = W1c c_L + d_1
@@ -480,6 +488,27 @@ int ardae_cdae_loss_grads(const ardae_cdae_desc* d, const float* params, const f
                           size_t workspace_floats, float* loss, float* grads, float* score_out, void* stream) {
   return cdae_impl(d, params, packed, xbar, sigma, eps, ctx, B, S, workspace, workspace_floats, loss, grads, score_out, true,
                    (hipStream_t)stream);
+}
+int ardae_cdae_perturb_fused_ok(const ardae_cdae_desc* d, int nz, int nstd) {
+  if (desc_ok(d) != 0) return 0;
+  const CdaeLayout P(*d);
+  return nstd == 1 && P.inp[0].in == P.z && latent_perturb_draw_fwd_ok(nz, P.z, P.h, P.act) ? 1 : 0;
+}
+int ardae_cdae_perturb_loss_grads(const ardae_cdae_desc* d, const float* params, const float* packed, const float* latent, const float* z0,
+                                  const float* ctx, int B, int nz, float std_scale, float delta, uint64_t seed, uint64_t offset_xi,
+                                  uint64_t offset_eps, const void* state, uint64_t first_row, float* xbar, float* sigma, float* eps_out,
+                                  float* std_b, float* workspace, size_t ws_floats, float* loss, float* grads, void* stream) {
+  ARDAE_TRY(desc_ok(d));
+  ARDAE_CHECK_ARG(ardae_cdae_perturb_fused_ok(d, nz, 1), "cdae_perturb_loss_grads: shape not eligible (nz=%d): use ardae_latent_perturb* + ardae_cdae_loss_grads", nz);
+  ARDAE_CHECK_ARG(params && packed && workspace && B > 0, "cdae_perturb_loss_grads: null pointer argument");
+  const CdaeLayout P(*d);
+  const PackedLayout K(P);
+  ARDAE_CHECK_ARG(ws_floats >= workspace_floats(P, B, nz, true), "cdae_perturb_loss_grads: workspace too small");
+  ARDAE_TRY(launch_latent_perturb_draw_fwd(latent, z0, B, nz, P.z, std_scale, delta, seed, offset_xi, offset_eps, state, first_row, xbar, sigma,
+                                           eps_out, std_b, packed + K.inp_f[0], params + P.inp[0].b, P.h, P.act, cdae_a1_slot(P, B, workspace),
+                                           (hipStream_t)stream));
+  return cdae_impl(d, params, packed, xbar, sigma, eps_out, ctx, B, nz, workspace, ws_floats, loss, grads, nullptr, true, (hipStream_t)stream,
+                   true);
 }
 int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float* packed, const float* x, const float* sigma,
                      const float* ctx, int B, int S, float* workspace, size_t workspace_floats, float* score_out, void* stream) {

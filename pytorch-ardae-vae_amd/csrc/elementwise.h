@@ -16,6 +16,12 @@ bool latent_perturb_draw_ok(int nz, int nstd, int zd);
 int launch_latent_perturb_draw(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float delta, uint64_t seed,
                                uint64_t off_xi, uint64_t off_eps, const void* state, uint64_t first_row, float* xbar, float* sigma,
                                float* eps_out, float* std_b, hipStream_t st);
+// the same with the first layer of the score network's input encoder on the perturbed rows: a_1 = act(xbar A_1^T + b_1) (wp1: packed A_1)
+bool latent_perturb_draw_fwd_ok(int nz, int zd, int h, int act);
+int launch_latent_perturb_draw_fwd(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float delta, uint64_t seed,
+                                   uint64_t off_xi, uint64_t off_eps, const void* state, uint64_t first_row, float* xbar, float* sigma,
+                                   float* eps_out, float* std_b, const float* wp1, const float* bias1, int h, int act, float* a1_out,
+                                   hipStream_t st);
 // u = s (z - z0[b]) only (VAE phase, sigma = 0: ivae_ardae.py:827)
 int launch_center_scale(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float* u,
                         hipStream_t st);

@@ -171,14 +171,24 @@ __global__ __launch_bounds__(256) void latent_perturb_kernel(const float* __rest
 // its image into LDS, from where every thread picks the elements it owns (the same ownership as the injected-noise form, so the
 // statistics are bit-identical for equal numbers); eps is also written out (the DAE-loss layer needs it: rho = sigma g + eps).
 // Keyed exactly like ardae_philox_normal_at: element i of a rank's shard = element first + i of the global draw (seed, offset).
+constexpr int LP_XPAD = 4;            // FWD: the xbar tile's row stride in LDS is z + 4 floats (conflict-free fragment reads)
 struct PerturbDraw {
   uint64_t seed, off_xi, off_eps;     // Philox offsets of the two draws (the step state's base offset is added when state != null)
   const StepState* state;
   uint64_t first_row;                 // this rank's first row of the global [rows] / [rows, z] draws
   float* eps_out;
+  // FWD: the first layer of the score network's input encoder on the rows just perturbed, a_1 = act(xbar A_1^T + b_1), in the same kernel
+  const float* wp1;                   // packed image of A_1 [h, z]
+  const float* bias1;                 // [h]
+  float* a1_out;                      // [rows, h]
+  int h;
 };
 
-template <int NV, bool DRAW>
+// FWD > 0 (the activation id): north star "fused per-sample Gaussian-perturb + sigma-scaling + DAE-forward kernel": after the perturbation the
+// image's rows xbar [nz, z] are still in the workgroup's LDS; its four waves multiply them by A_1 (FP32 MFMA, 32 x 32 blocks, K = z) and write
+// a_1 = act(xbar A_1^T + b_1) [nz, h] (models/graddae/mlp.py:414-434: add_gaussian_noise, then inp_encode's first Linear + activation) - the
+// separate K = z N-row launch and its re-read of xbar are gone.  Same MFMA order over k as the stand-alone layer kernels.
+template <int NV, bool DRAW, int FWD = 0>
 __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __restrict__ latent, const float* __restrict__ z0,
                                                                  const float* __restrict__ xi, const float* __restrict__ eps, int nz,
                                                                  int zd, float std_scale, float delta, float* __restrict__ xbar,
@@ -195,25 +205,33 @@ __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __
   float u[NV], ev[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) u[j] = (t + 256 * j < per_image) ? lat[t + 256 * j] : z0d;
+  // FWD with few images: gridDim.y workgroups share an image - every one computes the image's statistics (from the latent rows alone, in the
+  // same order: identical bits), then draws, perturbs and multiplies only ITS rows, passes j0 <= j < j1 (RG rows each)
+  const int j0 = FWD ? (int)blockIdx.y * (per_image >> 8) / (int)gridDim.y : 0;
+  const int j1 = FWD ? ((int)blockIdx.y + 1) * (per_image >> 8) / (int)gridDim.y : NV;
+  const int RGc = 256 / zd, rows_sl = FWD ? (j1 - j0) * RGc : nz, xi_at = FWD ? rows_sl * (zd + LP_XPAD) : per_image;
   if (DRAW) {
     const uint64_t base_off = dr.state ? dr.state->rng_offset : 0;
     const uint64_t q_eps = (dr.first_row * (uint64_t)zd + base) >> 2;        // first counter of this image's eps block
-    for (int c = t; 4 * c < per_image; c += 256) {
+    const int c_lo = 64 * j0, c_hi = FWD ? 64 * j1 : (per_image + 3) >> 2;   // one pass = 256 elements = 64 counters
+    for (int c = c_lo + t; c < c_hi; c += 256) {
       float v[4];
       philox_normal4(dr.seed, dr.off_eps + base_off, q_eps + (uint64_t)c, v);
-      *reinterpret_cast<f32x4*>(nbuf + 4 * c) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(nbuf + 4 * (c - c_lo)) = f32x4{v[0], v[1], v[2], v[3]};
     }
     const uint64_t q_xi = (dr.first_row + (uint64_t)b * nz) >> 2;
-    for (int c = t; 4 * c < nz; c += 256) {
+    const int x_lo = (RGc * j0) >> 2, x_hi = FWD ? (RGc * j1) >> 2 : (nz + 3) >> 2;
+    for (int c = x_lo + t; c < x_hi; c += 256) {
       float v[4];
       philox_normal4(dr.seed, dr.off_xi + base_off, q_xi + (uint64_t)c, v);
-      *reinterpret_cast<f32x4*>(nbuf + per_image + 4 * c) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(nbuf + xi_at + 4 * (c - x_lo)) = f32x4{v[0], v[1], v[2], v[3]};
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      ev[j] = (t + 256 * j < per_image) ? nbuf[t + 256 * j] : 0.f;
-      if (t + 256 * j < per_image) dr.eps_out[base + t + 256 * j] = ev[j];
+      const bool mine = t + 256 * j < per_image && j >= j0 && j < j1;
+      ev[j] = mine ? nbuf[t + 256 * (j - j0)] : 0.f;
+      if (mine) dr.eps_out[base + t + 256 * j] = ev[j];
     }
   } else {
 #pragma unroll
@@ -256,15 +274,49 @@ __global__ __launch_bounds__(256) void latent_perturb_reg_kernel(const float* __
   }
   __syncthreads();
   const float sb = red[0];
-  if (t == 0) std_b[b] = sb;
+  if (t == 0 && (!FWD || blockIdx.y == 0)) std_b[b] = sb;
   const int r0 = t / zd;
+  if (FWD) __syncthreads();            // everybody has picked its eps values out of nbuf: it now receives the xbar tile
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    if (t + 256 * j < per_image) {
+    if (t + 256 * j < per_image && j >= j0 && j < j1) {
       const size_t row = (size_t)b * nz + r0 + RG * j;
-      const float sg = sb * (DRAW ? nbuf[per_image + r0 + RG * j] : xi[row]);
-      xbar[base + t + 256 * j] = u[j] + sg * ev[j];
+      const float sg = sb * (DRAW ? nbuf[xi_at + r0 + RG * (j - j0)] : xi[row]);
+      const float xb = u[j] + sg * ev[j];
+      xbar[base + t + 256 * j] = xb;
+      if (FWD) nbuf[(r0 + RG * (j - j0)) * (zd + LP_XPAD) + d] = xb;
       if (d == 0) sigma[row] = sg;
+    }
+  }
+  if (FWD) {
+    __syncthreads();
+    // wave w: column blocks w, w + 4, ... of a_1; the block's weight fragments (<= 8 chunks of 8 k) stay in registers over the row blocks
+    const int lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int kch = zd >> 3, nrb = rows_sl >> 5, ncb = dr.h >> 5, ld = zd + LP_XPAD;
+    for (int cb = wave; cb < ncb; cb += 4) {
+      f32x4 bv[8];
+      const float* bp = dr.wp1 + (size_t)cb * kch * 256 + lane * 4;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < kch) bv[c] = *reinterpret_cast<const f32x4*>(bp + (size_t)c * 256);
+      const int col = cb * 32 + l31;
+      const float bc = dr.bias1[col];
+      for (int rb = 0; rb < nrb; ++rb) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* arow = nbuf + (rb * 32 + l31) * ld + 4 * hh;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < kch) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 8 * c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[c][q], acc, 0, 0, 0);
+          }
+        float* yo = dr.a1_out + ((size_t)b * nz + RG * j0 + rb * 32 + 4 * hh) * dr.h + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yo[(size_t)((r & 3) + 8 * (r >> 2)) * dr.h] = act_fwd<FWD>(acc[r] + bc);
+      }
     }
   }
 }
@@ -495,6 +547,44 @@ int launch_latent_perturb_draw(const float* latent, const float* z0, int B, int 
   else if (per_image <= 256 * 16) ARDAE_LP_DRAW(16);
   else ARDAE_LP_DRAW(32);
 #undef ARDAE_LP_DRAW
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+bool latent_perturb_draw_fwd_ok(int nz, int zd, int h, int act) {
+  return latent_perturb_draw_ok(nz, 1, zd) && zd % 8 == 0 && zd <= 64 && nz % 32 == 0 && ((int64_t)nz * zd) % 256 == 0 && h % 32 == 0 &&
+         (act == ACT_RELU || act == ACT_SOFTPLUS) &&
+         ((size_t)nz * (zd + LP_XPAD) + nz) * sizeof(float) <= 64 * 1024;
+}
+
+int launch_latent_perturb_draw_fwd(const float* latent, const float* z0, int B, int nz, int zd, float std_scale, float delta, uint64_t seed,
+                                   uint64_t off_xi, uint64_t off_eps, const void* state, uint64_t first_row, float* xbar, float* sigma,
+                                   float* eps_out, float* std_b, const float* wp1, const float* bias1, int h, int act, float* a1_out,
+                                   hipStream_t st) {
+  ARDAE_CHECK_ARG(latent && z0 && xbar && sigma && eps_out && std_b && wp1 && bias1 && a1_out && B > 0, "latent_perturb_draw_fwd: null pointer");
+  ARDAE_CHECK_ARG(latent_perturb_draw_fwd_ok(nz, zd, h, act), "latent_perturb_draw_fwd: shape not eligible (nz=%d z=%d h=%d act=%d)", nz, zd, h, act);
+  ARDAE_CHECK_ARG((first_row & 3) == 0, "latent_perturb_draw_fwd: first_row must be a multiple of 4 (one Philox counter = 4 normals)");
+  const int64_t per_image = (int64_t)nz * zd;
+  const PerturbDraw dr{seed, off_xi, off_eps, (const StepState*)state, first_row, eps_out, wp1, bias1, a1_out, h};
+  // few images: S workgroups per image, rows split among them (a slice is a whole number of 32-row blocks), until the grid fills the chip
+  const int rg = 256 / zd, passes = (int)(per_image >> 8);
+  int S = 1;
+  while (B * S < 256 && passes % (2 * S) == 0 && (passes / (2 * S)) * rg % 32 == 0) S *= 2;
+  const size_t rows_sl = (size_t)(passes / S) * rg;
+  const size_t lds = (rows_sl * (zd + LP_XPAD) + rows_sl) * sizeof(float);
+#define ARDAE_LP_FWD(NV_, ACT_)                                                                                                            \
+  hipLaunchKernelGGL((latent_perturb_reg_kernel<NV_, true, ACT_>), dim3(B, S), dim3(256), lds, st, latent, z0, nullptr, nullptr, nz, zd,    \
+                     std_scale, delta, xbar, sigma, std_b, dr)
+#define ARDAE_LP_FWD_NV(ACT_)                                                                                                              \
+  do {                                                                                                                                     \
+    if (per_image <= 256 * 8) ARDAE_LP_FWD(8, ACT_);                                                                                       \
+    else if (per_image <= 256 * 16) ARDAE_LP_FWD(16, ACT_);                                                                                \
+    else ARDAE_LP_FWD(32, ACT_);                                                                                                           \
+  } while (0)
+  if (act == ACT_RELU) ARDAE_LP_FWD_NV(ACT_RELU);
+  else ARDAE_LP_FWD_NV(ACT_SOFTPLUS);
+#undef ARDAE_LP_FWD_NV
+#undef ARDAE_LP_FWD
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

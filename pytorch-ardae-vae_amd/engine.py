@@ -189,6 +189,7 @@ class ArdaeEngine:
         self.split_backward = int(md.kind) < 2 and L.debug_knob("ARDAE_SPLIT_BACKWARD", "1") != "0"
         self._side = torch.cuda.Stream(device=self.dev) if self.overlap else None
         self.fused_draws = L.debug_knob("ARDAE_FUSED_DRAW", "1") != "0"     # sigma / eps draws inside the perturbation kernel
+        self.fused_first_layer = L.debug_knob("ARDAE_FUSED_A1", "1") != "0"   # ... and the score network's first layer on the perturbed rows
         self._cap_stream = torch.cuda.Stream(device=self.dev)
         self._stamps = None                             # diagnostics: see enable_stamps()
         self._log = None                                # scalar log channel (scalar_log.ScalarLog), one more launch at the end of the step
@@ -406,6 +407,16 @@ class ArdaeEngine:
         if self.data_ctx:
             self._data_context(x, self.ctx_c)
         self._stamp("  sampler done")
+        if fused and self.fused_first_layer and bool(lib.ardae_cdae_perturb_fused_ok(ctypes.byref(self.cdae._desc), nz, nstd)):
+            # north star's "fused per-sample Gaussian-perturb + sigma-scaling + DAE-forward kernel", then the cDAE from its second layer on
+            L.check(lib.ardae_cdae_perturb_loss_grads(ctypes.byref(self.cdae._desc), L.ptr(self.cdae._flat), L.ptr(self.pk_c), L.ptr(self.latent),
+                                                      L.ptr(self.z0), L.ptr(self.ctx_c), B, nz, cfg.std_scale, cfg.delta,
+                                                      ctypes.c_uint64(rng.get_state()["seed"]), ctypes.c_uint64(d[1]), ctypes.c_uint64(d[2]),
+                                                      ctypes.c_void_p(self.state.data_ptr()), ctypes.c_uint64(self.rank * B * nz),
+                                                      L.ptr(self.xbar), L.ptr(self.sigma), L.ptr(eps), L.ptr(self.std_b), L.ptr(self.ws),
+                                                      self.ws.numel(), L.ptr(self.loss_c), L.ptr(self.grads_c), st),
+                    "ardae_cdae_perturb_loss_grads")
+            return
         if fused:
             L.check(lib.ardae_latent_perturb_draw(L.ptr(self.latent), L.ptr(self.z0), B, nz, z, cfg.std_scale, cfg.delta,
                                                   ctypes.c_uint64(rng.get_state()["seed"]), ctypes.c_uint64(d[1]), ctypes.c_uint64(d[2]),

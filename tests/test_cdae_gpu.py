@@ -298,3 +298,55 @@ def test_cdae_score_per_image_chain_launch(B, act):
         assert torch.equal(H.score(x, sigma, ctx, B, 1), first)
     ref = O.cdae_score(cc, {k: v.double() for k, v in pc.items()}, x.double().requires_grad_(True), ctx.double(), sigma.double()[:, None], create_graph=False)
     assert rel_l2(first, ref.detach()) < 2e-5
+
+
+@pytest.mark.parametrize("B,nz,z,h,act", [(64, 256, 32, 256, "softplus"), (5, 64, 16, 320, "relu"), (3, 1024, 8, 64, "softplus")])
+def test_cdae_fused_perturb_sigma_first_layer_kernel(B, nz, z, h, act):
+    """North star: 'a fused per-sample Gaussian-perturb + sigma-scaling + DAE-forward kernel for the nz_cdae inner Monte-Carlo loop'.
+    ardae_cdae_perturb_loss_grads = ivae_ardae.py:753-776 in one call; its first kernel draws xi / eps, computes the latent statistics,
+    sigma, xbar (graddae/mlp.py:21-23) AND the first layer of the score network's input encoder on the rows it still holds in LDS
+    (graddae/mlp.py:414-434).  Against the separate path (ardae_latent_perturb_draw, then ardae_cdae_loss_grads with its own first-layer
+    launch): xbar / sigma / eps / std_b bit-identical; loss and gradients equal up to the summation order over k of that one layer
+    (measured < 1e-6) - and both within the usual tolerance of the float64 oracle."""
+    lib = L.lib()
+    cc = O.CdaeCfg("grad", z, z, h, 3, act)
+    pc = O.init_params(O.cdae_param_spec(cc), 5)
+    flat_p = torch.cat([pc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)])
+    H = CdaeHarness(cc, flat_p)
+    assert lib.ardae_cdae_perturb_fused_ok(ctypes.byref(H.d), nz, 1) == 1
+    assert lib.ardae_cdae_perturb_fused_ok(ctypes.byref(H.d), nz, 3) == 0 and lib.ardae_cdae_perturb_fused_ok(ctypes.byref(H.d), 625, 1) == 0
+    g = torch.Generator().manual_seed(B + nz)
+    z0 = torch.randn(B, z, generator=g).cuda()
+    latent = (z0[:, None, :].cpu() + 0.05 * torch.randn(B, nz, z, generator=g)).cuda().contiguous()
+    ctx = torch.randn(B, z, generator=g).cuda()
+    seed, k_xi, k_eps, first = 0xBEEF, 7, 8, 4 * B * nz
+    state = torch.zeros(4, dtype=torch.int64, device="cuda")
+    L.check(lib.ardae_step_state_advance(ctypes.c_void_p(state.data_ptr()), ctypes.c_uint64(48), 1e-4, 0.5, 0.999, L.stream_ptr()))
+    new = lambda *s: torch.full(s, float("nan"), device="cuda")
+    u64, N = ctypes.c_uint64, B * nz
+    wsn = lib.ardae_cdae_workspace_floats(ctypes.byref(H.d), B, nz, 1)
+
+    xbar, sigma, std_b, eps = new(N, z), new(N), new(B), new(N, z)
+    L.check(lib.ardae_latent_perturb_draw(L.ptr(latent), L.ptr(z0), B, nz, z, 1.0, 0.1, u64(seed), u64(k_xi), u64(k_eps), ctypes.c_void_p(state.data_ptr()),
+                                          u64(first), L.ptr(xbar), L.ptr(sigma), L.ptr(eps), L.ptr(std_b), L.stream_ptr()))
+    ws, loss, grads = new(wsn), torch.zeros(1, device="cuda"), new(flat_p.numel())
+    L.check(lib.ardae_cdae_loss_grads(ctypes.byref(H.d), L.ptr(H.params), L.ptr(H.packed), L.ptr(xbar), L.ptr(sigma), L.ptr(eps), L.ptr(ctx), B, nz,
+                                      L.ptr(ws), wsn, L.ptr(loss), L.ptr(grads), None, L.stream_ptr()))
+    xbar2, sigma2, std_b2, eps2 = new(N, z), new(N), new(B), new(N, z)
+    ws2, loss2, grads2 = new(wsn), torch.zeros(1, device="cuda"), new(flat_p.numel())
+    L.check(lib.ardae_cdae_perturb_loss_grads(ctypes.byref(H.d), L.ptr(H.params), L.ptr(H.packed), L.ptr(latent), L.ptr(z0), L.ptr(ctx), B, nz, 1.0, 0.1,
+                                              u64(seed), u64(k_xi), u64(k_eps), ctypes.c_void_p(state.data_ptr()), u64(first), L.ptr(xbar2), L.ptr(sigma2),
+                                              L.ptr(eps2), L.ptr(std_b2), L.ptr(ws2), wsn, L.ptr(loss2), L.ptr(grads2), L.stream_ptr()),
+            "ardae_cdae_perturb_loss_grads")
+    torch.cuda.synchronize()
+    assert torch.equal(eps2, eps) and torch.equal(std_b2, std_b) and torch.equal(sigma2, sigma) and torch.equal(xbar2, xbar)
+    grads, grads2 = grads[:-1], grads2[:-1]          # the last entry (bias of the energy's output layer) has no gradient: never written
+    assert torch.isfinite(grads2).all() and torch.isfinite(loss2).all()
+    assert abs(float(loss2) - float(loss)) <= 2e-6 * abs(float(loss))
+    assert rel_l2(grads2.cpu(), grads.cpu()) < 1e-5
+    # and against the float64 oracle on the same perturbed rows
+    names = [n for n, _ in O.cdae_param_spec(cc)]
+    l64, g64, _ = oracle64_grads(cc, pc, xbar.cpu(), sigma.cpu(), eps.cpu(), ctx.cpu(), nz)
+    assert abs(float(loss2) - float(l64)) < 2e-5 * abs(float(l64))
+    ref = torch.cat([(g64[n] if g64[n] is not None else torch.zeros_like(pc[n])).reshape(-1) for n in names])
+    assert rel_l2(grads2.cpu(), ref[:-1]) < 3e-3
