@@ -140,7 +140,7 @@ size_t workspace_floats(const CdaeLayout& P, int B, int S, bool need_grads) {
   t += (size_t)(need_grads ? 8 : 4) * P.L * al(N * h);                   // a,hh,e,r (+ tau,taup,pbar,qbar)
   t += 2 * al(N * P.z);                                                  // gbar, g
   t += al((size_t)linear_row_tiles((int)N, P.z) * linear_col_panels((int)N, P.z));
-  t += al(3 * ((N + 31) / 32));                                          // row-block counters of the per-image chain launch (score pass)
+  t += al((size_t)LINEAR_SMALL_CHAIN_COUNTER_WORDS * ((N + 15) / 16));                                          // row-block counters of the per-image chain launch (score pass)
   if (need_grads) {
     t += al((size_t)B * h) + (size_t)P.L * al((size_t)B * h);            // Qsum, chat_l
     t += al((size_t)linear_row_tiles((int)N, P.h) * h);                  // colsum of tau'_L
@@ -244,7 +244,7 @@ int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed
   float* gbuf = ws.take((size_t)N * z);
   const int ltiles = linear_row_tiles(N, z) * linear_col_panels(N, z);
   float* tile_loss = ws.take(ltiles);
-  float* chain_cnt = ws.take(3 * ((size_t)(N + 31) / 32));
+  float* chain_cnt = ws.take((size_t)LINEAR_SMALL_CHAIN_COUNTER_WORDS * ((N + 15) / 16));
   float* g = score_out ? score_out : gbuf;
 
   const float* W1s = packed + K.w1s;

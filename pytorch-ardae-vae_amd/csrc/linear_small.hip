@@ -181,6 +181,262 @@ __device__ __forceinline__ void small_block(const LinArgs& a, int bx, int by, fl
   }
 }
 
+// The REGULAR case of small_block - one source, K % 8 == 0, 16-byte aligned rows, M % 32 == 0, Nout % 32 == 0 (every per-image layer of the
+// mlp configurations except those touching the 784 / 100-wide data and noise) - without the generic block's clamps, per-lane source
+// selects and scalar-tail loads: those made it ~3000 instructions (190 exec-mask branches) per wave for 32 MFMAs, i.e. the per-image
+// launches were ISSUE-bound (3.7 us of work per 256 x 256 level, measured inside the chain kernel with the hand-over switched off),
+// not latency-bound.  Same chunk ranges per wave, same MFMA order, same reduction tree: bit-identical to small_block.
+// COH: the rows read were written by OTHER workgroups of this launch (linear_small_chain_kernel) - every load of them bypasses the CU's
+// L1 (`nt`; a CU's L1 is never refreshed by another CU's stores), the weights and biases are launch constants and load normally.
+template <bool COH, typename T>
+__device__ __forceinline__ T ld_row(const T* p) {
+  if (COH) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+template <int N>
+struct IntTag { static constexpr int value = N; };
+
+template <int NB>
+struct SmallFrag {            // NB chunks (8 k each) of A and packed-B fragments
+  f32x4 a[NB], b[NB];
+  template <bool COH>
+  __device__ __forceinline__ void load(const f32x4*& ap, const f32x4*& bp) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) { a[u] = ld_row<COH>(ap + 2 * u); b[u] = bp[64 * u]; }
+    ap += 2 * NB; bp += 64 * NB;
+  }
+  __device__ __forceinline__ void mac(f32x16& acc) const {
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], b[u][q], acc, 0, 0, 0);
+  }
+};
+
+template <int EPI, int ACT, bool COH, bool STAMP = false>
+__device__ __forceinline__ void small_block_fast(const LinArgs& a, int bx, int by, float (*red)[16][64], unsigned long long* stamp = nullptr) {
+  auto mark = [&](int i) {      // timing experiment (scratch/exp_small_chain.py, ARDAE_SC_DEBUG=8): wave 0 of one workgroup at one level
+    if (STAMP) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) stamp[i] = __builtin_readcyclecounter();
+    }
+  };
+  mark(0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // uniform: the chunk range below is scalar
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int col = by * 32 + l31, rowb = bx * 32 + 8 * wave + 4 * hh;      // this lane finishes rows rowb .. rowb + 3 of column col
+  float o1[4], o2[4], bcol = 0.f, wsig = 0.f, wv = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o1[i] = 0.f, o2[i] = 0.f;
+  if (EPI == EPI_ACT) {
+    if (a.bias) bcol = a.bias[col];
+    if (a.rowbias) {
+      const int rpg = a.rows_per_group, g0 = rpg == 1 ? rowb : rowb / rpg, rem = rowb - g0 * rpg;      // one division for the four rows
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int g = rpg == 1 ? rowb + i : (rpg >= 4 ? g0 + (rem + i >= rpg ? 1 : 0) : (rowb + i) / rpg);
+        o1[i] = ld_row<COH>(a.rowbias + (size_t)g * a.rowbias_ld + col);
+      }
+    }
+    if (a.rowscale) {
+      wsig = a.rowscale_w[col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o2[i] = ld_row<COH>(a.rowscale + rowb + i);
+    }
+    if (a.Y2) wv = a.R[col];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o1[i] = ld_row<COH>(a.S + (size_t)(rowb + i) * a.ldS + col);
+    if (EPI == EPI_CHAIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o2[i] = ld_row<COH>(a.R + (size_t)(rowb + i) * a.ldR + col);
+    } else if (a.Q) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o2[i] = ld_row<COH>(a.Q + (size_t)(rowb + i) * a.ldQ + col);
+    }
+  }
+
+  const int K = a.src[0].K, T = K >> 3;
+  const int cbeg = (T * wave) >> 2, cend = (T * (wave + 1)) >> 2;
+  const f32x4* ap = reinterpret_cast<const f32x4*>(a.src[0].x + (size_t)(bx * 32 + l31) * a.src[0].ld + 4 * hh) + 2 * cbeg;   // + 2 per chunk
+  const f32x4* bp = reinterpret_cast<const f32x4*>(a.src[0].wp) + ((size_t)by * T + cbeg) * 64 + lane;                             // + 64 per chunk
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  mark(1);      // epilogue operands have landed
+  // whole batches of SB chunks, the next batch's loads in flight behind this one's MFMAs; then the remainder as static batches of 4 / 2 / 1
+  int left = cend - cbeg;
+  if (left >= SB) {
+    SmallFrag<SB> f0, f1;
+    f0.template load<COH>(ap, bp);
+    mark(2);    // first batch of fragments has landed
+    left -= SB;
+    while (left >= 2 * SB) {
+      f1.template load<COH>(ap, bp);
+      f0.mac(acc);
+      f0.template load<COH>(ap, bp);
+      f1.mac(acc);
+      left -= 2 * SB;
+    }
+    if (left >= SB) {
+      f1.template load<COH>(ap, bp);
+      f0.mac(acc);
+      f1.mac(acc);
+      left -= SB;
+    } else {
+      f0.mac(acc);
+    }
+  }
+  if (left & 4) { SmallFrag<4> f; f.template load<COH>(ap, bp); f.mac(acc); }
+  if (left & 2) { SmallFrag<2> f; f.template load<COH>(ap, bp); f.mac(acc); }
+  if (left & 1) { SmallFrag<1> f; f.template load<COH>(ap, bp); f.mac(acc); }
+
+  if (STAMP) {      // behind the last MFMA's 16 passes
+    asm volatile("s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 7" ::: "memory");
+    if (threadIdx.x == 0) stamp[3] = __builtin_readcyclecounter() + (unsigned long long)(acc[0] == 123.456f);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    v[i] = (red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + (red[2][4 * wave + i][lane] + red[3][4 * wave + i][lane]);
+  mark(4);      // partial sums reduced
+  float* yo = a.Y + (size_t)rowb * a.ldY + col;
+  if (EPI == EPI_ACT) {
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = act_fwd<ACT>(v[i] + bcol + o1[i] + o2[i] * wsig);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yo[(size_t)i * a.ldY] = y[i];
+    if (a.Y2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a.Y2[(size_t)(rowb + i) * a.ldY2 + col] = -wv * act_d1<ACT>(y[i]);
+    }
+  } else if (EPI == EPI_DACT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yo[(size_t)i * a.ldY] = v[i] * act_d1<ACT>(o1[i]) + o2[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float em = act_ratio<ACT>(o1[i]);
+      yo[(size_t)i * a.ldY] = v[i] * act_d1<ACT>(o1[i]);
+      a.Y2[(size_t)(rowb + i) * a.ldY2 + col] = v[i] * o2[i] * em;
+    }
+  }
+  mark(5);      // results stored and acknowledged
+}
+
+// FEW rows (at most 64 blocks of 32 x 32 in the layer - the 64 / 128-image shards of the 8 / 4-GPU runs): a 32 x 32 block at K = 256 pulls
+// 64 KiB through ONE CU's 64 B / clk vector-memory path - ~1.7 k of the block's 8.4 k cycles (in-kernel stamps, scratch/exp_small_chain.py) -
+// and runs a chain of 32 dependent 64-cycle MFMAs (another 3 k) while most of the chip idles.  Here a workgroup owns a 16 x 16 block:
+// four times the workgroups, a quarter of the bytes and of the matrix time each (v_mfma_f32_16x16x4_f32, 16 per wave at K = 256).
+// Lane (c = lane % 16, q = lane / 16) of wave w, step g (16 k): ONE float4 of A (row c, k = 16 g + 4 q ..+3: the four q-lanes of a row read
+// 64 contiguous bytes) and ONE float4 of the packed weights (chunk 2 g + q / 2, half q % 2: the same four k), then four MFMAs - MFMA j
+// multiplies k = 16 g + 4 q + j over q = 0..3.  The sum over k therefore runs in a different order than in the 32 x 32 blocks: results
+// agree to rounding, not bit for bit.
+template <int EPI, int ACT, bool COH>
+__device__ __forceinline__ void small_block16(const LinArgs& a, int bx, int by, float (*red)[4][64]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int col = by * 16 + c16, row = bx * 16 + 4 * q + wave;      // this lane finishes (row, col): accumulator register `wave` of lane
+  float o1 = 0.f, o2 = 0.f, bcol = 0.f, wsig = 0.f, wv = 0.f;
+  if (EPI == EPI_ACT) {
+    if (a.bias) bcol = a.bias[col];
+    if (a.rowbias) o1 = ld_row<COH>(a.rowbias + (size_t)(a.rows_per_group == 1 ? row : row / a.rows_per_group) * a.rowbias_ld + col);
+    if (a.rowscale) { wsig = a.rowscale_w[col]; o2 = ld_row<COH>(a.rowscale + row); }
+    if (a.Y2) wv = a.R[col];
+  } else {
+    o1 = ld_row<COH>(a.S + (size_t)row * a.ldS + col);
+    if (EPI == EPI_CHAIN) o2 = ld_row<COH>(a.R + (size_t)row * a.ldR + col);
+    else if (a.Q) o2 = ld_row<COH>(a.Q + (size_t)row * a.ldQ + col);
+  }
+
+  const int K = a.src[0].K, T = K >> 3, G = K >> 4;                   // chunks of 8 k (the packed image's unit), steps of 16 k
+  const int gbeg = (G * wave) >> 2, gend = (G * (wave + 1)) >> 2;
+  const f32x4* ap = reinterpret_cast<const f32x4*>(a.src[0].x + (size_t)(bx * 16 + c16) * a.src[0].ld + 4 * q) + 4 * gbeg;          // + 4 per step
+  const f32x4* bp = reinterpret_cast<const f32x4*>(a.src[0].wp) + ((size_t)(by >> 1) * T + 2 * gbeg + (q >> 1)) * 64 + (by & 1) * 16 + c16 + 32 * (q & 1);   // + 128 per step
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto run = [&](auto nb) {
+    constexpr int NB = decltype(nb)::value;
+    f32x4 av[NB], bv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) { av[u] = ld_row<COH>(ap + 4 * u); bv[u] = bp[128 * u]; }
+    ap += 4 * NB; bp += 128 * NB;
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][j], bv[u][j], acc, 0, 0, 0);
+  };
+  int left = gend - gbeg;
+  for (; left >= 8; left -= 8) run(IntTag<8>{});
+  if (left & 4) run(IntTag<4>{});
+  if (left & 2) run(IntTag<2>{});
+  if (left & 1) run(IntTag<1>{});
+
+  // partial sums of the four waves meet in LDS; wave w finishes accumulator register w of every lane: rows 4 q + w
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  const float v = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+  if (EPI == EPI_ACT) {
+    const float y = act_fwd<ACT>(v + bcol + o1 + o2 * wsig);
+    a.Y[(size_t)row * a.ldY + col] = y;
+    if (a.Y2) a.Y2[(size_t)row * a.ldY2 + col] = -wv * act_d1<ACT>(y);
+  } else if (EPI == EPI_DACT) {
+    a.Y[(size_t)row * a.ldY + col] = v * act_d1<ACT>(o1) + o2;
+  } else {
+    const float em = act_ratio<ACT>(o1);
+    a.Y[(size_t)row * a.ldY + col] = v * act_d1<ACT>(o1);
+    a.Y2[(size_t)row * a.ldY2 + col] = v * o2 * em;
+  }
+}
+
+// what small_block_fast assumes (host side)
+inline bool small_fast_on() {     // ARDAE_SMALL_FAST=0: the generic block everywhere (A/B)
+  static const bool on = !(debug_knob("ARDAE_SMALL_FAST") && atoi(debug_knob("ARDAE_SMALL_FAST")) == 0);
+  return on;
+}
+inline bool small_regular(const LinArgs& a) {
+  return a.nsrc == 1 && a.src[0].K >= 8 && a.src[0].K % 8 == 0 && a.src[0].ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.src[0].x) & 15) == 0 &&
+         a.M % 32 == 0 && a.Nout % 32 == 0;
+}
+
+// what small_block16 assumes, and when it pays: the layer has few 32 x 32 blocks (ARDAE_SMALL16_MAX_BLOCKS, default 64)
+inline bool small_regular16(const LinArgs& a) {
+  static const int max_blocks = debug_knob("ARDAE_SMALL16_MAX_BLOCKS") ? atoi(debug_knob("ARDAE_SMALL16_MAX_BLOCKS")) : 64;
+  return a.nsrc == 1 && a.src[0].K >= 16 && a.src[0].K % 16 == 0 && a.src[0].ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.src[0].x) & 15) == 0 &&
+         a.M % 16 == 0 && a.Nout % 16 == 0 && (int64_t)ceil_div(a.M, 32) * ceil_div(a.Nout, 32) <= max_blocks;
+}
+
+template <int EPI, int ACT>
+__global__ __launch_bounds__(256) void linear_small16_kernel(const LinArgs a) {
+  __shared__ float red[4][4][64];
+  small_block16<EPI, ACT, false>(a, blockIdx.x, blockIdx.y, red);
+}
+template <int EPI, int ACT>
+__global__ __launch_bounds__(256) void linear_small16_pair_kernel(const LinArgs a0, const LinArgs a1) {
+  const LinArgs& a = blockIdx.z ? a1 : a0;
+  if ((int)blockIdx.x * 16 >= a.M || (int)blockIdx.y * 16 >= a.Nout) return;
+  __shared__ float red[4][4][64];
+  small_block16<EPI, ACT, false>(a, blockIdx.x, blockIdx.y, red);
+}
+
+template <int EPI, int ACT>
+__global__ __launch_bounds__(256) void linear_small_fast_kernel(const LinArgs a) {
+  __shared__ float red[4][16][64];
+  small_block_fast<EPI, ACT, false>(a, blockIdx.x, blockIdx.y, red);
+}
+template <int EPI, int ACT>
+__global__ __launch_bounds__(256) void linear_small_fast_pair_kernel(const LinArgs a0, const LinArgs a1) {
+  const LinArgs& a = blockIdx.z ? a1 : a0;
+  if ((int)blockIdx.x * 32 >= a.M || (int)blockIdx.y * 32 >= a.Nout) return;
+  __shared__ float red[4][16][64];
+  small_block_fast<EPI, ACT, false>(a, blockIdx.x, blockIdx.y, red);
+}
+
 template <int EPI, int ACT>
 __global__ __launch_bounds__(256) void linear_small_kernel(const LinArgs a) {
   __shared__ float red[4][16][64];
@@ -208,6 +464,7 @@ __global__ __launch_bounds__(256) void linear_small_pair_kernel(const LinArgs a0
 // j * 8 + rb % 8 puts all nj blocks of row block rb on XCD rb % 8): their hand-over stays inside that XCD's L2.
 // Deadlock freedom: the grid is at most a few hundred workgroups of 256 threads / 16 KiB LDS and waits only for workgroups of its own
 // launch; other kernels finish without it, so every workgroup is scheduled eventually.
+constexpr int SC_CNT_STRIDE = LINEAR_SMALL_CHAIN_COUNTER_WORDS;     // counters of different row blocks never share a cache line
 constexpr int SC_MAXLEV = 16, SC_MAXPROB = 20;     // the argument block stays under the 4 KiB kernel-argument limit
 struct ScProblem {            // what small_block reads of ardae_linear_args, 104 bytes
   const float *x0, *wp0, *x1, *wp1, *bias, *rowbias, *rowscale, *rowscale_w, *S, *Q, *R;
@@ -217,7 +474,8 @@ struct ScProblem {            // what small_block reads of ardae_linear_args, 10
 struct ScLevel { int np, nblk0, nblk; };        // problems, 32-column blocks of problem 0, of both
 struct ScArgs {
   int nlev, M, nj, fast, nrb; // nj: workgroups per row block (max blocks of a level); fast: XCD-local hand-over allowed; nrb: row blocks
-  unsigned* cnt;              // [3 nrb] zeroed before the launch: level counters | XCC masks | arrivals
+  int blk;                    // block edge: 32 (small_block_fast) or 16 (small_block16)
+  unsigned* cnt;              // [nrb][32] zeroed before the launch: a 128-byte line per row block (level counter, XCC mask, arrivals)
   ScLevel lv[SC_MAXLEV];
   ScProblem pr[SC_MAXPROB];
   int first[SC_MAXLEV];       // index of level l's first problem in pr
@@ -240,39 +498,78 @@ __global__ __launch_bounds__(256) void linear_small_chain_kernel(const ScArgs c)
   __shared__ float red[4][16][64];
   const int i = (int)blockIdx.x, nj = c.nj;
   const int rb = (i / (8 * nj)) * 8 + (i & 7), j = (i / 8) % nj;     // see above: row block rb's workgroups share an XCD
-  if (rb * 32 >= c.M) return;
+  if (rb * c.blk >= c.M) return;
   // Is the placement what the fast hand-over assumes?  Every workgroup of the row block reports its XCC id (atomics only, no data
   // involved) and waits for the others: one XCC -> the hand-over may stay inside that XCD's L2 (vmcnt + L1 invalidate); anything else
   // (another dispatch order, a partitioned device) -> agent-scope release / acquire (L2 write-back + invalidate: correct, slow).
+  // the levels' descriptors are read from the kernel-argument segment level by level: touch every line of it now (one round trip for all)
+  // instead of one scalar-cache miss chain per level.  ONE asm statement, loads and their wait together: the destination is a scratch
+  // SGPR the compiler must not hand to anything else while a load is still in flight.
+  {
+    static_assert(sizeof(ScArgs) >= 56 * 64, "prefetch range below");
+    unsigned t;
+#define SC_PF(o) "s_load_dword %0, %1, " #o "\n"
+#define SC_PF8(a, b, c, d, e, f, g, h) SC_PF(a) SC_PF(b) SC_PF(c) SC_PF(d) SC_PF(e) SC_PF(f) SC_PF(g) SC_PF(h)
+    asm volatile(SC_PF8(0x000, 0x040, 0x080, 0x0c0, 0x100, 0x140, 0x180, 0x1c0) SC_PF8(0x200, 0x240, 0x280, 0x2c0, 0x300, 0x340, 0x380, 0x3c0)
+                 SC_PF8(0x400, 0x440, 0x480, 0x4c0, 0x500, 0x540, 0x580, 0x5c0) SC_PF8(0x600, 0x640, 0x680, 0x6c0, 0x700, 0x740, 0x780, 0x7c0)
+                 SC_PF8(0x800, 0x840, 0x880, 0x8c0, 0x900, 0x940, 0x980, 0x9c0) SC_PF8(0xa00, 0xa40, 0xa80, 0xac0, 0xb00, 0xb40, 0xb80, 0xbc0)
+                 SC_PF8(0xc00, 0xc40, 0xc80, 0xcc0, 0xd00, 0xd40, 0xd80, 0xdc0) "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr())
+                 : "memory");
+#undef SC_PF8
+#undef SC_PF
+  }
   bool fast = false;
   {
     __shared__ unsigned s_mask;
     if (threadIdx.x == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      __hip_atomic_fetch_or(c.cnt + c.nrb + rb, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(c.cnt + 2 * c.nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(c.cnt + 2 * c.nrb + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nj) __builtin_amdgcn_s_sleep(1);
-      s_mask = __hip_atomic_load(c.cnt + c.nrb + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_or(c.cnt + SC_CNT_STRIDE * rb + 1, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c.cnt + SC_CNT_STRIDE * rb + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(c.cnt + SC_CNT_STRIDE * rb + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nj) __builtin_amdgcn_s_sleep(1);
+      s_mask = __hip_atomic_load(c.cnt + SC_CNT_STRIDE * rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    fast = c.fast && __builtin_popcount(s_mask) == 1;
+    fast = (c.fast & 1) && __builtin_popcount(s_mask) == 1;
   }
   unsigned target = 0;
   for (int l = 0; l < c.nlev; ++l) {
+    if ((c.fast & 8) && l == 5 && i == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(c.cnt + 8)[7] = __builtin_readcyclecounter();
     const ScLevel lv = c.lv[l];
-    if (j < lv.nblk) {
+    if (j < lv.nblk && !(c.fast & 2)) {
       const bool second = j >= lv.nblk0;
       const LinArgs a = sc_args(c.pr[c.first[l] + (second ? 1 : 0)], c.M);
       const int cb = second ? j - lv.nblk0 : j;
       const int key = a.act * 4 + (int)(c.pr[c.first[l] + (second ? 1 : 0)].epi);
-      switch (key) {
-        case ACT_NONE * 4 + EPI_ACT: small_block<EPI_ACT, ACT_NONE>(a, rb, cb, red); break;
-        case ACT_RELU * 4 + EPI_ACT: small_block<EPI_ACT, ACT_RELU>(a, rb, cb, red); break;
-        case ACT_SOFTPLUS * 4 + EPI_ACT: small_block<EPI_ACT, ACT_SOFTPLUS>(a, rb, cb, red); break;
-        case ACT_NONE * 4 + EPI_DACT: small_block<EPI_DACT, ACT_NONE>(a, rb, cb, red); break;
-        case ACT_RELU * 4 + EPI_DACT: small_block<EPI_DACT, ACT_RELU>(a, rb, cb, red); break;
-        default: small_block<EPI_DACT, ACT_SOFTPLUS>(a, rb, cb, red); break;
+      if (c.blk == 16) {     // few rows: 16 x 16 blocks (small_block16)
+        float (*red16)[4][64] = reinterpret_cast<float (*)[4][64]>(&red[0][0][0]);
+        switch (key) {
+          case ACT_NONE * 4 + EPI_ACT: small_block16<EPI_ACT, ACT_NONE, true>(a, rb, cb, red16); break;
+          case ACT_RELU * 4 + EPI_ACT: small_block16<EPI_ACT, ACT_RELU, true>(a, rb, cb, red16); break;
+          case ACT_SOFTPLUS * 4 + EPI_ACT: small_block16<EPI_ACT, ACT_SOFTPLUS, true>(a, rb, cb, red16); break;
+          case ACT_NONE * 4 + EPI_DACT: small_block16<EPI_DACT, ACT_NONE, true>(a, rb, cb, red16); break;
+          case ACT_RELU * 4 + EPI_DACT: small_block16<EPI_DACT, ACT_RELU, true>(a, rb, cb, red16); break;
+          default: small_block16<EPI_DACT, ACT_SOFTPLUS, true>(a, rb, cb, red16); break;
+        }
+      } else
+      switch (key) {         // regular problems only (launch_linear_small_chain): the lean block, its row loads bypassing the L1
+        case ACT_NONE * 4 + EPI_ACT: small_block_fast<EPI_ACT, ACT_NONE, true>(a, rb, cb, red); break;
+        case ACT_RELU * 4 + EPI_ACT: small_block_fast<EPI_ACT, ACT_RELU, true>(a, rb, cb, red); break;
+        case ACT_SOFTPLUS * 4 + EPI_ACT:
+          if ((c.fast & 8) && l == 5 && i == 0) {
+            unsigned long long* stamp = reinterpret_cast<unsigned long long*>(c.cnt + 8);     // words 8 .. 23 of row block 0's counter line
+            if (c.fast & 16) small_block_fast<EPI_ACT, ACT_SOFTPLUS, false, true>(a, rb, cb, red, stamp);
+            else small_block_fast<EPI_ACT, ACT_SOFTPLUS, true, true>(a, rb, cb, red, stamp);
+            if (threadIdx.x == 0) stamp[6] = __builtin_readcyclecounter();
+          } else {
+            small_block_fast<EPI_ACT, ACT_SOFTPLUS, true>(a, rb, cb, red);
+          }
+          break;
+        case ACT_NONE * 4 + EPI_DACT: small_block_fast<EPI_DACT, ACT_NONE, true>(a, rb, cb, red); break;
+        case ACT_RELU * 4 + EPI_DACT: small_block_fast<EPI_DACT, ACT_RELU, true>(a, rb, cb, red); break;
+        default: small_block_fast<EPI_DACT, ACT_SOFTPLUS, true>(a, rb, cb, red); break;
       }
     }
     if (l + 1 == c.nlev) break;                     // the kernel boundary orders the last level
@@ -280,23 +577,25 @@ __global__ __launch_bounds__(256) void linear_small_chain_kernel(const ScArgs c)
     // release: this workgroup's stores are visible at agent scope before its arrival is; acquire: nothing of the next level is read
     // before every block of this row block has arrived
     // (every wave releases its OWN stores - a workgroup barrier does not wait for another wave's stores to reach the L2)
-    if (fast) {
+    if (c.fast & 4) {              // timing experiment only (scratch/exp_small_chain.py): no hand-over at all
+      __syncthreads();
+    } else if (fast) {
       // all workgroups of the row block share an XCD (verified above), so the hand-over only has to reach that XCD's L2: the L1 is
-      // write-through (a store is complete when the L2 has it: vmcnt), and the consumer drops its CU's L1 lines before reading
+      // write-through (a store is complete when the L2 has it: vmcnt), and the consumer's loads of handed-over rows bypass its CU's L1
+      // (small_block_fast<.., COH = true>; a workgroup-scope fence / `buffer_inv sc0` would invalidate nothing another CU wrote)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) {
-        if (j < lv.nblk) __hip_atomic_fetch_add(c.cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(c.cnt + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        if (j < lv.nblk) __hip_atomic_fetch_add(c.cnt + SC_CNT_STRIDE * rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(c.cnt + SC_CNT_STRIDE * rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
       }
       __syncthreads();
-      asm volatile("buffer_inv sc0" ::: "memory");
     } else {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
       if (threadIdx.x == 0) {
-        if (j < lv.nblk) __hip_atomic_fetch_add(c.cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(c.cnt + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        if (j < lv.nblk) __hip_atomic_fetch_add(c.cnt + SC_CNT_STRIDE * rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(c.cnt + SC_CNT_STRIDE * rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
       }
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -319,7 +618,12 @@ int launch_small_pair(const LinArgs& a0, const LinArgs& a1, hipStream_t st) {
     prof_begin(st, name, fl, by);
   }
   const dim3 grid(std::max(ceil_div(a0.M, 32), ceil_div(a1.M, 32)), std::max(ceil_div(a0.Nout, 32), ceil_div(a1.Nout, 32)), 2);
-  hipLaunchKernelGGL((linear_small_pair_kernel<EPI, ACT>), grid, dim3(256), 0, st, a0, a1);
+  if (small_fast_on() && small_regular16(a0) && small_regular16(a1))
+    hipLaunchKernelGGL((linear_small16_pair_kernel<EPI, ACT>), dim3(std::max(a0.M, a1.M) / 16, std::max(a0.Nout, a1.Nout) / 16, 2), dim3(256), 0, st, a0, a1);
+  else if (small_fast_on() && small_regular(a0) && small_regular(a1))
+    hipLaunchKernelGGL((linear_small_fast_pair_kernel<EPI, ACT>), grid, dim3(256), 0, st, a0, a1);
+  else
+    hipLaunchKernelGGL((linear_small_pair_kernel<EPI, ACT>), grid, dim3(256), 0, st, a0, a1);
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;
@@ -336,7 +640,12 @@ int launch_small(const LinArgs& a, hipStream_t st) {
                            ((EPI == EPI_DACT && a.Q) ? 1 : 0);
     prof_begin(st, name, 2.0 * a.M * (double)a.Nout * ksum, 4.0 * ((double)a.M * ksum + tensors * a.M * (double)a.Nout + ksum * a.Nout));
   }
-  hipLaunchKernelGGL((linear_small_kernel<EPI, ACT>), dim3(ceil_div(a.M, 32), ceil_div(a.Nout, 32)), dim3(256), 0, st, a);
+  if (small_fast_on() && small_regular16(a))
+    hipLaunchKernelGGL((linear_small16_kernel<EPI, ACT>), dim3(a.M / 16, a.Nout / 16), dim3(256), 0, st, a);
+  else if (small_fast_on() && small_regular(a))
+    hipLaunchKernelGGL((linear_small_fast_kernel<EPI, ACT>), dim3(a.M / 32, a.Nout / 32), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((linear_small_kernel<EPI, ACT>), dim3(ceil_div(a.M, 32), ceil_div(a.Nout, 32)), dim3(256), 0, st, a);
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;
@@ -369,7 +678,7 @@ bool sc_fill(const LinArgs& a, int epi, ScProblem& q) {
 }  // namespace
 
 // A chain of per-image levels (each one or two independent problems on the same M rows; level l + 1 reads outputs of levels <= l of
-// its own rows only) in one launch.  counters: 3 ceil(M / 32) unsigned ints of scratch (cleared here with a fill launch).  Falls back to
+// its own rows only) in one launch.  counters: LINEAR_SMALL_CHAIN_COUNTER_WORDS x ceil(M / 16) unsigned ints of scratch (cleared here with a fill launch).  Falls back to
 // one launch per problem when a problem does not qualify for the split-K kernel.
 int launch_linear_small_chain(const LinArgs* probs, const int* epis, const int* level_of, int nprob, float* counters, hipStream_t st) {
   ARDAE_CHECK_ARG(probs && epis && level_of && nprob >= 1 && counters, "linear_small_chain: bad arguments");
@@ -380,20 +689,24 @@ int launch_linear_small_chain(const LinArgs* probs, const int* epis, const int* 
   bool ok = on && nprob <= SC_MAXPROB;
   const int M = probs[0].M;
   int nlev = 0;
+  bool all16 = small_fast_on();
+  for (int i = 0; all16 && i < nprob; ++i) all16 = small_regular16(probs[i]) || (probs[i].Nout <= 32 && probs[i].Nout % 16 == 0 && probs[i].M % 16 == 0 && probs[i].src[0].K % 16 == 0 && probs[i].nsrc == 1);
+  const int blk = all16 ? 16 : 32;
   for (int i = 0; ok && i < nprob; ++i) {
     const int l = level_of[i];
-    ok = probs[i].M == M && l >= 0 && l < SC_MAXLEV && (i == 0 ? l == 0 : (l == level_of[i - 1] || l == level_of[i - 1] + 1)) && sc_fill(probs[i], epis[i], c.pr[i]);
+    ok = probs[i].M == M && l >= 0 && l < SC_MAXLEV && (i == 0 ? l == 0 : (l == level_of[i - 1] || l == level_of[i - 1] + 1)) &&
+         (all16 || small_regular(probs[i])) && sc_fill(probs[i], epis[i], c.pr[i]);
     if (!ok) break;
     if (l + 1 > nlev) { nlev = l + 1; c.first[l] = i; c.lv[l].np = 0; }
     ok = c.lv[l].np < 2;
     if (!ok) break;
-    const int nb = ceil_div(probs[i].Nout, 32);
+    const int nb = ceil_div(probs[i].Nout, blk);
     if (c.lv[l].np == 0) c.lv[l].nblk0 = nb;
     c.lv[l].nblk += nb;
     c.lv[l].np += 1;
     if (c.lv[l].nblk > c.nj) c.nj = c.lv[l].nblk;
   }
-  const int nrb = ceil_div(M, 32);
+  const int nrb = ceil_div(M, blk);
   ok = ok && nlev >= 2 && (int64_t)nrb * c.nj <= 2048;
   if (!ok) {
     for (int i = 0; i < nprob; ++i) ARDAE_TRY(launch_linear(probs[i], epis[i], st));
@@ -401,9 +714,11 @@ int launch_linear_small_chain(const LinArgs* probs, const int* epis, const int* 
   }
   c.nlev = nlev; c.M = M; c.cnt = reinterpret_cast<unsigned*>(counters);
   static const bool fast = !(debug_knob("ARDAE_SMALL_CHAIN_FAST") && atoi(debug_knob("ARDAE_SMALL_CHAIN_FAST")) == 0);
-  c.fast = fast ? 1 : 0;
+  static const int dbg = debug_knob("ARDAE_SC_DEBUG") ? atoi(debug_knob("ARDAE_SC_DEBUG")) : 0;     // 2: no compute, 4: no hand-over, 8: cycle stamps of one block (timing only)
+  c.fast = (fast ? 1 : 0) | (dbg & 30);
   c.nrb = nrb;
-  ARDAE_TRY(launch_fill(counters, 3 * (size_t)nrb, 0.f, st));
+  c.blk = blk;
+  ARDAE_TRY(launch_fill(counters, (size_t)SC_CNT_STRIDE * nrb, 0.f, st));
   if (g_prof_enabled) {
     double fl = 0, by = 0;
     for (int i = 0; i < nprob; ++i) {

@@ -212,7 +212,7 @@ def test_cdae_full_size_additivity_over_images(kind):
         l_i, g_i, sc_i = hn.loss_grads(xbar[r], sigma[r], eps[r], ctx[i * Bs:(i + 1) * Bs], Bs, S)
         acc_l += float(l_i) / parts
         acc_g += g_i[:n_used].double() / parts
-        assert rel_l2(score[r], sc_i) < 1e-6
+        assert rel_l2(score[r], sc_i) < 5e-6      # per-image context layers: 16 x 16 blocks on the quarter, 32 x 32 on the whole (order of the sums over k)
     assert abs(float(loss) - acc_l) <= 1e-5 * abs(acc_l)
     spec = O.cdae_param_spec(cc)
     full, shard = split_flat(grads, spec), split_flat(torch.cat([acc_g.float(), torch.zeros(grads.numel() - n_used)]), spec)
@@ -281,11 +281,13 @@ def test_cdae_cfg2_golden_summaries(golden_dir):
 @pytest.mark.parametrize("B,act", [(64, "softplus"), (512, "softplus"), (100, "relu"), (32, "softplus")])
 def test_cdae_score_per_image_chain_launch(B, act):
     """The sigma = 0 score pass of the VAE update (glogprob on B rows, one row per image: models/graddae/mlp.py:446-483) runs as ONE launch
-    (`linear_small_chain_kernel`: 4 L + 2 per-image problems walked level by level, a row-block counter instead of a kernel boundary
-    between dependent layers; the hand-over stays inside one XCD's L2 when the kernel has verified that a row block's workgroups share
-    an XCD, else agent-scope release / acquire).  A synchronisation bug would show as a stale or torn read now and then: the pass is
-    repeated 25 times at the widths of config #2 and must return the SAME bits every time, equal to the oracle's score to fp32 accuracy;
-    64 rows = the 8-rank shard, 512 = one GPU, 100: a ragged last row block."""
+    (`linear_small_chain_kernel`: 4 L + 2 per-image problems walked level by level, a row-block counter - one cache line per row block -
+    instead of a kernel boundary between dependent layers; the hand-over stays inside one XCD's L2 when the kernel has verified that a row
+    block's workgroups share an XCD - the consumers' loads of handed-over rows bypass their CU's L1 - else agent-scope release / acquire).
+    A synchronisation bug would show as a stale or torn read now and then: the pass is repeated 25 times at the widths of config #2 and
+    must return the SAME bits every time, equal to the oracle's score to fp32 accuracy; 64 rows = the 8-rank shard (16 x 16 blocks),
+    512 = one GPU (32 x 32 blocks), 100: ragged rows - the chain launch refuses them and the problems go out one launch each, 32: one
+    row block pair."""
     cc = O.CdaeCfg("grad", 32, 32, 256, 3, act)
     pc = O.init_params(O.cdae_param_spec(cc), 3)
     flat = torch.cat([pc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)])

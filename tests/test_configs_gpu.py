@@ -94,7 +94,9 @@ def test_cdae_full_shard_additivity(cfg, B, S):
         l_i, g_i, sc_i = hn.loss_grads(xbar[r], sigma[r], eps[r], ctx[i * Bs:(i + 1) * Bs], Bs, S)
         acc_l += float(l_i) / parts
         acc_g += g_i[:n_used].double() / parts
-        assert rel_l2(score[r], sc_i) < 1e-6
+        # row-local N-row kernels give the same bits; the per-image context layers run on 16 x 16 blocks for 64 images and on 32 x 32
+        # blocks for 256 (linear_small.hip): another order of the fp32 sums over k (measured 1.2e-6)
+        assert rel_l2(score[r], sc_i) < 5e-6
     assert abs(float(loss) - acc_l) <= 1e-5 * abs(acc_l)
     spec = O.cdae_param_spec(cc)
     full, shard = split_flat(grads, spec), split_flat(torch.cat([acc_g.float(), torch.zeros(grads.numel() - n_used)]), spec)

@@ -206,12 +206,14 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     assert abs(float(got["loss"]) - float(loss)) <= 1e-5 * abs(float(loss))
     # same arithmetic on the same rows; only the order of the fp32 sums over rows differs (split in two, then averaged)
-    assert rel(got["gc"], gc) < 5e-4
+    assert rel(got["gc"], gc) < 2e-3
     assert rel(got["gm"], gm) < 5e-4
     # the engine's own draws: rank r generated rows [r B/2, (r+1) B/2) of the same global noise tensors
     gc, gm, loss = _grads(x1, x2, None, B)
+    # (half batches run their per-image layers on 16 x 16 blocks, the full batch on 32 x 32: another order of the sums over k as well; the
+    # cDAE gradient amplifies fp32 rounding by ~1e3 - test_cdae_gpu.py::assert_grads_close - measured 8.4e-4)
     assert abs(float(got["loss_own"]) - float(loss)) <= 1e-5 * abs(float(loss))
-    assert rel(got["gc_own"], gc) < 5e-4
+    assert rel(got["gc_own"], gc) < 2e-3
     assert rel(got["gm_own"], gm) < 5e-4
 
 

@@ -207,6 +207,17 @@ def test_linear_big_m_epilogues(M, K, Nout, epi, rpg=16):
         assert relerr(Y2, -w.double() * torch.sigmoid(pre)) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,Nout", [(64, 256, 256),      # 16 blocks of 32 x 32: the 16 x 16 blocks (few rows: small_block16)
+                                      (16, 32, 48), (128, 784, 256), (48, 256, 784),     # K = 32: two waves idle; 784 = 49 blocks of 16 columns
+                                      (512, 256, 256), (256, 784, 256),                 # 32 x 32 lean blocks (small_block_fast), 24.5 chunks per wave
+                                      (100, 256, 256), (64, 100, 256), (64, 256, 100)])  # ragged rows / K / columns: the generic block
+@pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
+def test_linear_per_image_kernels(M, K, Nout, epi):
+    """The latency kernels of the per-image (B-row) layers (linear_small.hip) - 16 x 16 blocks for layers of at most 64 blocks of 32 x 32,
+    the lean 32 x 32 block for regular shapes, the generic block for the rest - all epilogues, against float64."""
+    test_linear_big_m_epilogues(M, K, Nout, epi, rpg=4 if M % 4 == 0 else 1)
+
+
 @pytest.mark.parametrize("act", ["relu", "softplus"])
 def test_linear_dact_and_colsum(act):
     g = torch.Generator().manual_seed(11)
