@@ -173,6 +173,93 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradBatchDev batch
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The per-image problems (M = images of the shard: context encoder, encoder trunk, decoder - a few MFLOP each) in the 128 x 256
+// tiling above are ONE or two workgroups per matrix walking all rows with eight accumulators per wave: 19-22 us per launch, on the
+// critical path of both updates, at any batch size.  Here every WAVE owns one 32 x 32 tile of dW (a workgroup = 2 x 2 of them), reads
+// its G and X columns straight from memory (128 contiguous bytes per half-wave and row, sixteen rows in flight, the next sixteen
+// requested before the MFMAs) and a 256 x 256 matrix spreads over 16 workgroups.  Writes the same partial / partial_vec layout
+// (split s of `splits`), so wgrad_reduce_kernel finishes these problems like all others.
+constexpr int SM_ROWS = 16;      // rows per register batch (8 MFMAs)
+
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradBatchDev batch) {
+  int pi = 0;
+  while (pi + 1 < batch.nprob && (int)blockIdx.x >= batch.wg_begin[pi + 1]) ++pi;
+  const WgradProblem& P = batch.p[pi];
+  const int local = blockIdx.x - batch.wg_begin[pi];
+  const int split = local % P.splits;
+  const int t2 = local / P.splits;
+  const int it = t2 % batch.i_tiles[pi], ot = t2 / batch.i_tiles[pi];       // 64 x 64 workgroup tiles
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int o0 = ot * 64 + (wave >> 1) * 32, i0 = it * 64 + (wave & 1) * 32;
+  if (o0 >= P.O || i0 >= P.I) return;                                         // (uniform per wave; no barriers below)
+  const int rows_per_split = ((P.M + P.splits - 1) / P.splits + 1) / 2 * 2;
+  const int m_begin = split * rows_per_split, m_end = min(P.M, m_begin + rows_per_split);
+  const int oc = min(o0 + l31, P.O - 1), ic = min(i0 + l31, P.I - 1);        // clamped columns: their products are never stored
+  const bool want_vec = P.bias_pair >= 0 && P.partial_vec != nullptr && i0 == 0;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f, rsum = 0.f;
+  for (int pr = 0; pr < P.npairs; ++pr) {
+    const float* __restrict__ G = P.G[pr] + oc;
+    const float* __restrict__ X = P.X[pr] + ic;
+    const size_t ldG = P.ldG[pr], ldX = P.ldX[pr];
+    const bool vec = want_vec && pr == P.bias_pair;
+    float g0[SM_ROWS / 2], x0[SM_ROWS / 2], g1[SM_ROWS / 2], x1[SM_ROWS / 2], rs0[SM_ROWS / 2], rs1[SM_ROWS / 2];
+    auto fetch = [&](int m0, float (&g)[SM_ROWS / 2], float (&x)[SM_ROWS / 2], float (&rs)[SM_ROWS / 2]) {
+#pragma unroll
+      for (int u = 0; u < SM_ROWS / 2; ++u) {
+        const int m = m0 + 2 * u + hh;
+        const bool live = m < m_end;
+        const int mc = live ? m : m_end - 1;
+        const float gv = G[(size_t)mc * ldG], xv = X[(size_t)mc * ldX];
+        g[u] = live ? gv : 0.f;
+        x[u] = xv;                                                          // a dead row has g = 0
+        if (vec && P.rowscale) rs[u] = P.rowscale[mc];
+      }
+    };
+    auto mac = [&](const float (&g)[SM_ROWS / 2], const float (&x)[SM_ROWS / 2], const float (&rs)[SM_ROWS / 2]) {
+#pragma unroll
+      for (int u = 0; u < SM_ROWS / 2; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g[u], x[u], acc, 0, 0, 0);
+        if (vec) {
+          bsum += g[u];
+          if (P.rowscale) rsum += g[u] * rs[u];
+        }
+      }
+    };
+    if (m_begin < m_end) {
+      fetch(m_begin, g0, x0, rs0);
+      for (int m0 = m_begin; m0 < m_end; m0 += 2 * SM_ROWS) {
+        if (m0 + SM_ROWS < m_end) fetch(m0 + SM_ROWS, g1, x1, rs1);
+        mac(g0, x0, rs0);
+        if (m0 + SM_ROWS >= m_end) break;
+        if (m0 + 2 * SM_ROWS < m_end) fetch(m0 + 2 * SM_ROWS, g0, x0, rs0);
+        mac(g1, x1, rs1);
+      }
+    }
+  }
+  float* __restrict__ part = P.partial + (size_t)split * P.O * P.I;
+  if (i0 + l31 < P.I) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (o < P.O) part[(size_t)o * P.I + i0 + l31] = acc[r];
+    }
+  }
+  if (want_vec) {      // the two half-waves hold the sums over even / odd rows
+    bsum += __shfl_xor(bsum, 32);
+    rsum += __shfl_xor(rsum, 32);
+    if (hh == 0 && o0 + l31 < P.O) {
+      P.partial_vec[((size_t)split * 2 + 0) * P.O + o0 + l31] = bsum;
+      P.partial_vec[((size_t)split * 2 + 1) * P.O + o0 + l31] = rsum;
+    }
+  }
+}
+
 // out = beta*out + sum_s partial[s]  (fixed order -> reproducible).  The partial tiles are read exactly once (64 MB per
 // step at config #2), so what matters is memory-level parallelism: four elements per thread as one float4 and four splits
 // per iteration keep 16 values in flight (the one-element, one-split loop took 42 us for 13 us of traffic).
@@ -327,12 +414,44 @@ int launch_wgrad_batch(const WgradProblem* probs, int nprob, hipStream_t st) {
       if (!end) { group[ng++] = i; gt += wide_ntiles[i]; }
     }
   }
-  WgradBatchDev b;   // the remaining problems for wgrad_kernel
+  // per-image problems (few rows): one 32 x 32 tile per wave (wgrad_small_kernel).  ARDAE_WGRAD_SMALL=0: off
+  static const bool small_on = !(debug_knob("ARDAE_WGRAD_SMALL") && atoi(debug_knob("ARDAE_WGRAD_SMALL")) == 0);
+  bool is_small[WGRAD_MAX_PROBLEMS] = {false};
+  WgradBatchDev b;
+  {
+    memset(&b, 0, sizeof(b));
+    int total = 0, ns = 0;
+    double fl = 0, by = 0;
+    for (int i = 0, w = 0; i < nprob; ++i) {
+      if (w < nwide && wide_idx[w] == i) { ++w; continue; }
+      const WgradProblem& p = local[i];
+      if (!small_on || p.M > 1024) continue;
+      is_small[i] = true;
+      b.p[ns] = p;
+      b.o_tiles[ns] = ceil_div(p.O, 64);
+      b.i_tiles[ns] = ceil_div(p.I, 64);
+      b.wg_begin[ns] = total;
+      total += b.o_tiles[ns] * b.i_tiles[ns] * p.splits;
+      fl += 2.0 * p.npairs * (double)p.M * p.O * p.I;
+      by += 4.0 * (p.npairs * (double)p.M * (p.O + p.I) + (double)p.splits * p.O * p.I);
+      ++ns;
+    }
+    b.nprob = ns;
+    b.wg_begin[ns] = total;
+    if (ns > 0) {
+      if (g_prof_enabled) prof_begin(st, "wgrad_small_kernel", fl, by);
+      hipLaunchKernelGGL(wgrad_small_kernel, dim3(total), dim3(256), 0, st, b);
+      prof_end(st);
+      ARDAE_LAUNCH_CHECK();
+    }
+  }
+  // the remaining problems for wgrad_kernel
   memset(&b, 0, sizeof(b));
   int total = 0, nrest = 0;
   double fl = 0, by = 0;
   for (int i = 0, w = 0; i < nprob; ++i) {
     if (w < nwide && wide_idx[w] == i) { ++w; continue; }
+    if (is_small[i]) continue;
     const WgradProblem& p = local[i];
     b.p[nrest] = p;
     b.o_tiles[nrest] = ceil_div(p.O, BO);
