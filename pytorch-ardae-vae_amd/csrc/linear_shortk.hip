@@ -98,11 +98,14 @@ constexpr int ST_LD = 36;   // floats per row of the transpose tile (16-byte ali
 struct TailOut { const float* wp; const float* bias; float* Z; int ldz; };
 
 template <int ACT, int SK_MAXCH, int NOUT2>
-__global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void sampler_tail_kernel(const LinArgs a, const TailOut o0, const TailOut o1, int n2) {
+__global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void sampler_tail_kernel(const LinArgs a, const TailOut o0, const TailOut o1, int n2, int cs) {
+  // cs (1, 2, 4): few rows - the hidden layer's column blocks of a 32-row block are split over cs waves (each a chain of 544 / cs MFMAs
+  // instead of 544), whose partial latent-space sums meet in LDS; the workgroup then holds 4 / cs row blocks
   __shared__ float tile[4][32 * ST_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  const int row0 = (blockIdx.x * 4 + wave) * 32;
+  const int cpart = wave & (cs - 1), rbi = wave / cs;
+  const int row0 = (blockIdx.x * (4 / cs) + rbi) * 32;
   const int K = a.src[0].K, nch = (K + 7) >> 3;
   const int h = a.Nout, nblk = h >> 5, nch2 = h >> 3;
 
@@ -176,15 +179,34 @@ __global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void s
     __builtin_amdgcn_wave_barrier();     // the tile is rewritten by the next block
   };
   (void)nch2;
-  load_b(b0, 0);
-  for (int nb = 0; nb < nblk; nb += 2) {
-    if (nb + 1 < nblk) load_b(b1, nb + 1);
+  const int nb_lo = cpart * (nblk / cs), nb_hi = nb_lo + nblk / cs;
+  load_b(b0, nb_lo);
+  for (int nb = nb_lo; nb < nb_hi; nb += 2) {
+    if (nb + 1 < nb_hi) load_b(b1, nb + 1);
     block(b0, nb);
-    if (nb + 1 >= nblk) break;
-    if (nb + 2 < nblk) load_b(b0, nb + 2);
+    if (nb + 1 >= nb_hi) break;
+    if (nb + 2 < nb_hi) load_b(b0, nb + 2);
     block(b1, nb + 1);
   }
-  if (l31 < n2) {
+  if (cs > 1) {      // partial sums over the column parts: wave (rbi, 0) adds those of (rbi, 1 .. cs - 1), in order
+#pragma unroll
+    for (int o = 0; o < NOUT2; ++o) {
+      if (cpart != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31] = zacc[o][r];
+      }
+      __syncthreads();
+      if (cpart == 0) {
+        for (int c = 1; c < cs; ++c) {
+          const float* Tc = tile[wave + c];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zacc[o][r] += Tc[((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31];
+        }
+      }
+      if (NOUT2 > 1) __syncthreads();
+    }
+  }
+  if (l31 < n2 && cpart == 0) {
 #pragma unroll
     for (int o = 0; o < NOUT2; ++o) {
       const TailOut& out = o == 0 ? o0 : o1;
@@ -206,7 +228,11 @@ int launch_tail_ch(const LinArgs& a, const TailOut& o0, const TailOut& o1, int n
     const double K = a.src[0].K, nc = (double)n2 * NOUT2;
     prof_begin(st, name, 2.0 * a.M * ((double)a.Nout * K + (double)a.Nout * nc), 4.0 * ((double)a.M * K + (double)a.M * nc + K * a.Nout + (double)a.Nout * nc));
   }
-  hipLaunchKernelGGL((sampler_tail_kernel<ACT, MAXCH, NOUT2>), dim3(a.M / 128), dim3(256), 0, st, a, o0, o1, n2);
+  // few rows: split the hidden columns over 2 / 4 waves until the grid fills the chip (ARDAE_TAIL_SPLIT=1: never)
+  static const int max_cs = debug_knob("ARDAE_TAIL_SPLIT") ? atoi(debug_knob("ARDAE_TAIL_SPLIT")) : 4;
+  int cs = 1;
+  while (cs < max_cs && cs < 4 && (a.M / 128) * (2 * cs) <= 256 && (a.Nout / 32) % (2 * cs) == 0) cs *= 2;
+  hipLaunchKernelGGL((sampler_tail_kernel<ACT, MAXCH, NOUT2>), dim3(a.M / 128 * cs), dim3(256), 0, st, a, o0, o1, n2, cs);
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return 0;

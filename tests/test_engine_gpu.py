@@ -794,7 +794,8 @@ def test_iwae_logprob_golden_resconv(golden_dir, name, kind, h):
     assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
 
 
-@pytest.mark.parametrize("B,nz,nonlin", [(128, 256, "softplus"), (64, 625, "relu"), (256, 128, "softplus")])
+@pytest.mark.parametrize("B,nz,nonlin", [(128, 256, "softplus"), (64, 625, "relu"), (256, 128, "softplus"),
+                                         (64, 256, "softplus"), (32, 256, "relu")])      # few rows: hidden columns split over 2 / 4 waves
 def test_nrow_sampler_fused_tail_vs_oracle(B, nz, nonlin):
     """forward_hidden(x, nz) on >= 32768 rows: the mnist-concat sampler's two N-row layers (noise -> h -> z) run as ONE launch that keeps
     the hidden rows on chip (linear_shortk.hip::sampler_tail_kernel); against the float64 oracle at config #2's widths, per-image row
