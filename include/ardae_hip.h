@@ -238,7 +238,11 @@ typedef struct ardae_model_desc {
 enum { ARDAE_MODEL_NO_CENTER = 1,
        /* kind 5 (ResConvIPVAE): the sampler head `encode.fc` (models/ivae/resconv.py:101-116, ivae_ardae.py:323-442), flags bits 1-3:
         * 0 'res-wn-mlp' (--model resconv[ct]-res), 1 'mlp' (resconv[ct]), 2 'res-mlp' (-res2), 3 'res-wn-mlp-lin' (-res3), 4 'res-mlp-lin' (-res4) */
-       ARDAE_MODEL_HEAD_SHIFT = 1, ARDAE_MODEL_HEAD_MASK = 7 << 1 };
+       ARDAE_MODEL_HEAD_SHIFT = 1, ARDAE_MODEL_HEAD_MASK = 7 << 1,
+       /* kind 6: MNISTResConvAuxIPVAEClipped (--model auxresconv-clip / auxresconvct-clip, models/ivae/auxresconv2.py:71-72,91): the two
+        * log-variance heads WITHOUT the 'spm4' clip, and z0 = mu0 + (std exp(lv0 / 2) + 1) eps0 (`min_std = 1.`).  A sampler call with noise
+        * takes it as the unscaled draws (std = 1); a std = 0 pass is a RANDOM draw for this class: ardae_model_encode_hidden_raw */
+       ARDAE_MODEL_CLIPPED = 16 };
 size_t ardae_model_param_floats(const ardae_model_desc* d);
 size_t ardae_model_packed_floats(const ardae_model_desc* d);
 /* mode 0: encode only; mode 1: vae_forward + vae_backward; mode 2: decode only (B = rows, nz = 1); mode 3: encode_pair */
@@ -267,6 +271,11 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
  * Workspace: mode 0 with nz = 1. */
 int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B,
                               float* workspace, size_t workspace_floats, float* z0_out, float* hidden_out, void* stream);
+/* The same for the clipped class (kind 6 + ARDAE_MODEL_CLIPPED): raw0 [B, noise_dim] is the unscaled eps0 its z0 keeps at std = 0
+ * (z0 = mu0 + raw0; NULL: zeros).  The reference's loop makes TWO such calls per phase with separate draws - one for the context, one for the
+ * latent mean (ivae_ardae.py:737-739,748 / 815-817,826) - so z0_out or hidden_out may be NULL here. */
+int ardae_model_encode_hidden_raw(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* raw0, int B,
+                                  float* workspace, size_t workspace_floats, float* z0_out, float* hidden_out, void* stream);
 /* Decoder.forward (ivae/mnist.py:188-199, toy.py:725-737) without the sample: head outputs for z [R, z_dim]:
  * out0 = logits (kind 0) / mean (kind 1) [R, input_dim], out1 = logvar (kind 1) or NULL.  Workspace: mode 2.
  * Used by the IWAE evaluator (ivae/mnist.py:420-425). */

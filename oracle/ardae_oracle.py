@@ -60,6 +60,8 @@ class ModelCfg:
     n_layers: int = 2            # --model-n-layers
     nonlin: str = "softplus"
     do_center: bool = True       # residual-conv kinds: the trunk sees 2x - 1 (--model resconvct-res / auxresconvct) or x (resconv-res / auxresconv)
+    clipped: bool = False        # "auxresconv" only: MNISTResConvAuxIPVAEClipped (--model auxresconv-clip / auxresconvct-clip, ivae/auxresconv2.py):
+                                 # NO 'spm4' clip of the two log-variances and z0 = mu0 + (std exp(lv0 / 2) + 1) eps0 (`min_std=1.`, :91)
     enc_type: str = "res-wn-mlp"  # "resconv" only: the sampler head (models/ivae/resconv.py:101-116): 'mlp' (--model resconv / resconvct), 'res-wn-mlp'
                                  # (-res), 'res-mlp' (-res2), 'res-wn-mlp-lin' (-res3), 'res-mlp-lin' (-res4); n_layers = --model-n-layers
 
@@ -424,15 +426,20 @@ def spm4(lv):
 
 def auxres_encode(c, p, x, noise, nz):
     """MNISTResConvAuxIPVAE's sampler (ivae/auxresconv.py:73-106): heads on the shared trunk, both log-variances clipped 'spm4';
-    noise = (eps0 [B*nz, z0_dim], eps [B*nz, z_dim]) already scaled by std."""
-    eps0, eps = noise
+    noise = (eps0 [B*nz, z0_dim], eps [B*nz, z_dim]) already scaled by std.
+    c.clipped (MNISTResConvAuxIPVAEClipped, ivae/auxresconv2.py:71-72,91): plain log-variances and z0 = mu0 + (std exp(lv0 / 2) + 1) eps0 - the
+    `+ 1 eps0` term needs the UNSCALED draw: noise = (std eps0, std eps, eps0); with two entries the draws are taken as unscaled (std = 1)."""
+    eps0, eps = noise[0], noise[1]
+    clip = (lambda t: t) if c.clipped else spm4
     inp = resconv_trunk(c, p, x)
     mu0 = F.linear(inp, p["encode.aux_encode.reparam.mean_fn.weight"], p["encode.aux_encode.reparam.mean_fn.bias"])
-    lv0 = spm4(F.linear(inp, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"]))
+    lv0 = clip(F.linear(inp, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"]))
     z0 = expand_rows(mu0, nz) + torch.exp(0.5 * expand_rows(lv0, nz)) * eps0
+    if c.clipped:
+        z0 = z0 + (noise[2] if len(noise) > 2 else eps0)
     h = F.elu(F.linear(torch.cat([expand_rows(inp, nz), z0], 1), p["encode.encode.fc.0.weight"], p["encode.encode.fc.0.bias"]))
     mu = F.linear(h, p["encode.encode.reparam.mean_fn.weight"], p["encode.encode.reparam.mean_fn.bias"])
-    lv = spm4(F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"]))
+    lv = clip(F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"]))
     z = mu + torch.exp(0.5 * lv) * eps
     return {"z": z, "h": h, "z0": z0, "inp": inp}
 
@@ -529,14 +536,17 @@ def aux_encode(c: ModelCfg, p, x, noise, nz):
     return {"z": z, "h0": h0, "h": h, "z0": z0, "mu0": mu0, "lv0": lv0, "mu": mu, "lv": lv}
 
 
-def zero_noise(c: ModelCfg, rows, like):
-    """The draws of an encode(x, std=0) call, multiplied by 0."""
+def zero_noise(c: ModelCfg, rows, like, raw0=None):
+    """The draws of an encode(x, std=0) call, multiplied by 0.  raw0 [rows, noise_dim]: the clipped aux-resconv class keeps an unscaled
+    eps0 at std = 0 (ivae/auxresconv2.py:91) - `encode(x, std=0)` is a RANDOM draw there."""
     if c.kind in AUX_KINDS:
+        if c.clipped:
+            return (like.new_zeros(rows, c.noise_dim), like.new_zeros(rows, c.z_dim), like.new_zeros(rows, c.noise_dim) if raw0 is None else raw0)
         return (like.new_zeros(rows, c.noise_dim), like.new_zeros(rows, c.z_dim))
     return like.new_zeros(rows, c.noise_dim)
 
 
-def cdae_context(c: ModelCfg, tc, p, x):
+def cdae_context(c: ModelCfg, tc, p, x, raw0=None):
     """--cdae-ctx-type (ivae_ardae.py:729-741): data -> the (centred) image [B, D]; lt0 -> encode(x, std=0) [B, z]; hidden1a -> cat(h0, h) of the
     std=0 pass [B, 2h]."""
     B = x.size(0)
@@ -548,7 +558,7 @@ def cdae_context(c: ModelCfg, tc, p, x):
     if tc.ctx_type == "hidden1a":
         assert c.kind in AUX_KINDS, "hidden1a is the aux models' context"
         if c.kind == "auxresconv":      # Encoder.forward_hidden returns h alone: 450 columns (ivae/auxresconv.py:125-132, ivae_ardae.py:578-579)
-            return auxres_encode(c, p, x, zero_noise(c, B, x), 1)["h"]
+            return auxres_encode(c, p, x, zero_noise(c, B, x, raw0), 1)["h"]
         a = aux_encode(c, p, x, zero_noise(c, B, x), 1)
         return torch.cat([a["h0"], a["h"]], 1)
     raise NotImplementedError(tc.ctx_type)
@@ -715,11 +725,17 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
     n = {"sampler": torch.randn(N, mc.noise_dim, generator=gen)}          # forward_hidden
     if aux:
         n["sampler_z"] = torch.randn(N, mc.z_dim, generator=gen)
+    if aux and mc.clipped:       # the two std = 0 calls that open the cDAE update keep an unscaled eps0 each (ivae/auxresconv2.py:91)
+        n["ctx_raw"] = torch.randn(B, mc.noise_dim, generator=gen)
+        n["z0_raw"] = torch.randn(B, mc.noise_dim, generator=gen)
     n["sigma"] = torch.randn(B, tc.nz_cdae * tc.nstd, 1, generator=gen)   # stdmat
     n["eps"] = torch.randn(N * tc.nstd, mc.z_dim, generator=gen)          # add_gaussian_noise
     n["vae"] = torch.randn(B * tc.nz_model, mc.noise_dim, generator=gen)
     if aux:
         n["vae_z"] = torch.randn(B * tc.nz_model, mc.z_dim, generator=gen)
+    if aux and mc.clipped:
+        n["vctx_raw"] = torch.randn(B, mc.noise_dim, generator=gen)
+        n["vz0_raw"] = torch.randn(B, mc.noise_dim, generator=gen)
     return n
 
 
@@ -742,8 +758,11 @@ def cdae_update_grads(mc, cc, tc, pm, pc, x, noise):
     Returns loss, grads dict (None for tensors the loss does not reach), std [B,1,1]."""
     B = x.size(0)
     with torch.no_grad():
-        z0 = encode(mc, pm, x, zero_noise(mc, B, x), 1)          # latent_mean (and the context for lt0)
-        ctx = z0 if tc.ctx_type == "lt0" else cdae_context(mc, tc, pm, x).unsqueeze(1)
+        z0 = encode(mc, pm, x, zero_noise(mc, B, x, noise.get("z0_raw")), 1)          # latent_mean (and the context for lt0)
+        if mc.clipped and tc.ctx_type == "lt0":      # the reference's two encode(x, std=0) calls draw separately (ivae_ardae.py:741,748)
+            ctx = encode(mc, pm, x, zero_noise(mc, B, x, noise.get("ctx_raw")), 1)
+        else:
+            ctx = z0 if tc.ctx_type == "lt0" else cdae_context(mc, tc, pm, x, noise.get("ctx_raw")).unsqueeze(1)
         latent = encode(mc, pm, x, sampler_noise(mc, noise, "sampler"), tc.nz_cdae)
         u, std = latent_stats(latent, z0, tc.std_scale, tc.delta)
         stdmat = std * noise["sigma"]
@@ -761,8 +780,11 @@ def vae_update_grads(mc, cc, tc, pm, pc, x, noise, beta=None):
     pm_req = {k: v.detach().requires_grad_(True) for k, v in pm.items()}
     z, loss, rec, pri, _ = vae_forward(mc, pm_req, x, sampler_noise(mc, noise, "vae"), beta, tc.nz_model)
     with torch.no_grad():
-        z0 = encode(mc, pm, x, zero_noise(mc, B, x), 1)
-        ctx = z0 if tc.ctx_type == "lt0" else cdae_context(mc, tc, pm, x).unsqueeze(1)
+        z0 = encode(mc, pm, x, zero_noise(mc, B, x, noise.get("vz0_raw")), 1)
+        if mc.clipped and tc.ctx_type == "lt0":
+            ctx = encode(mc, pm, x, zero_noise(mc, B, x, noise.get("vctx_raw")), 1)
+        else:
+            ctx = z0 if tc.ctx_type == "lt0" else cdae_context(mc, tc, pm, x, noise.get("vctx_raw")).unsqueeze(1)
     u = (tc.std_scale * (z - z0)).detach()
     stdmat = x.new_zeros(B, tc.nz_model, 1)
     g = cdae_glogprob(cc, pc, u, ctx, stdmat)

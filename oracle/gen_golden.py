@@ -68,8 +68,8 @@ def build_reference(net, mc, cc, pm, pc, dtype):
     elif mc.kind == "resconv":   # ivae_ardae.py:359-370 (--model resconvct-res)
         model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
                                  noise_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type=mc.enc_type)
-    elif mc.kind == "auxresconv":   # ivae_ardae.py:493-505 (--model auxresconvct)
-        model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim,
+    elif mc.kind == "auxresconv":   # ivae_ardae.py:493-505 (--model auxresconvct); :507-534 (--model auxresconv-clip / auxresconvct-clip)
+        model = (net.MNISTResConvAuxIPVAEClipped if mc.clipped else net.MNISTResConvAuxIPVAE)(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim,
                                          nonlinearity=mc.nonlin, do_center=mc.do_center)
     elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
@@ -160,13 +160,18 @@ def replay_noise(mc, tc, B_c, B_v, seed, dtype):
             e = torch.randn(B * nz, 1, mc.z_dim)
             torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * nz, mc.z_dim, dtype=dtype)   # randn_like(std): the model's dtype
             return e0, e.reshape(B * nz, mc.z_dim)
-        fwd(B_c, 1)                                          # context: forward_hidden(std=0)
-        fwd(B_c, 1)                                          # latent_mean: encode(std=0)
         n = {}
+        ctx_raw = fwd(B_c, 1)[0]                             # context: forward_hidden(std=0)
+        z0_raw = fwd(B_c, 1)[0]                              # latent_mean: encode(std=0)
         n["sampler"], n["sampler_z"] = fwd(B_c, tc.nz_cdae)
         n["sigma"] = torch.randn(B_c, tc.nz_cdae * tc.nstd, 1, dtype=dtype)
         n["eps"] = torch.randn(B_c * tc.nz_cdae * tc.nstd, mc.z_dim, dtype=dtype)
         n["vae"], n["vae_z"] = fwd(B_v, tc.nz_model)
+        if mc.clipped:      # the std = 0 calls keep an unscaled eps0 (ivae/auxresconv2.py:91): these draws are used
+            n["ctx_raw"], n["z0_raw"] = ctx_raw, z0_raw
+            torch.rand(B_v * tc.nz_model, mc.input_dim, dtype=dtype)     # the decoder's unused relaxed-Bernoulli sample (models/reparam.py:113)
+            n["vctx_raw"] = fwd(B_v, 1)[0]                   # ivae_ardae.py:815-817
+            n["vz0_raw"] = fwd(B_v, 1)[0]                    # :826
         return {k: v.to(dtype) for k, v in n.items()}
     if tc.ctx_type != "data":
         torch.randn(B_c, mc.noise_dim)                   # context encode (x0); --cdae-ctx-type data takes the image: no draw
@@ -491,6 +496,14 @@ def main():
     run_iwae_case(net, "iwae_resconv_mlp", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", enc_type="mlp"), B=2, k=64, dtype=f64, store_params=False)
     run_iwae_case(net, "iwae_resconv", res_m, B=2, k=64, dtype=f64, store_params=False)
     run_iwae_case(net, "iwae_auxresconv", ares_m, B=2, k=64, dtype=f64, store_params=False)
+    # --model auxresconv-clip / auxresconvct-clip (ivae_ardae.py:507-534): MNISTResConvAuxIPVAEClipped - unclipped log-variances, z0 keeps an
+    # unscaled eps0 (min_std = 1), so the std = 0 calls of the loop are random draws and their eps0 are part of the fixture's noise
+    clip_m = O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", clipped=True)
+    run_case(net, rutils, "auxresconv_clip_b4_nz8_f64", clip_m, ares_c, ares_t, B=4, steps=1, dtype=f64, store_full=False)
+    run_case(net, rutils, "auxresconv_clip_b4_nz8", clip_m, ares_c, ares_t, B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    run_case(net, rutils, "auxresconv_clip_nocenter_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False, clipped=True), ares_c,
+             ares_t, B=4, steps=2, dtype=f32, store_full=False, tol32=5e-4)
+    run_iwae_case(net, "iwae_auxresconv_clip", clip_m, B=2, k=64, dtype=f64, store_params=False)
     # reference-written checkpoint (model / cDAE state_dict + utils.Adam / torch.optim.RMSprop state_dict) and the step after it
     run_ckpt_case(net, rutils, "ckpt_tiny_mnist_grad", tiny_m, tiny_c, tc, B=4, k_steps=2)
 

@@ -80,6 +80,7 @@ class ModelDesc(ctypes.Structure):
 
 MODEL_NO_CENTER = 1      # ardae_model_desc.flags (residual-conv kinds: do_center=False)
 MODEL_HEAD_SHIFT = 1     # kind 5: sampler-head type in flags bits 1-3 (layout.RESCONV_HEADS)
+MODEL_CLIPPED = 16       # kind 6: MNISTResConvAuxIPVAEClipped (no 'spm4' clip, z0 keeps an unscaled eps0)
 
 
 # utils/models.py:14-32 (get_nonlinear_func); 'csoftplus' = log(exp(x) + 1) is softplus (evaluated in its accurate form); 'swish' is not offered
@@ -138,6 +139,8 @@ EXPORTS = {
                                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "ardae_model_encode_hidden": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "ardae_model_encode_hidden_raw": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_model_decode": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ardae_model_loss_rows": (ctypes.c_int, [ctypes.POINTER(ModelDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int,

@@ -20,8 +20,11 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
                            hipStream_t st);
 // the two reparameterisation steps shared with the hierarchical conv model (csrc/convmodel.hip)
 //   out[r][c] = mu[g][c] + exp(lv[g][c] / 2) * eps[r * ld_eps + c],  g = r / rows_per_group   (mu, lv: [rows / rpg, cols])
+// min_std / raw (the clipped aux-resconv class, ivae/auxresconv2.py:29-36,91): out = mu + exp(lv / 2) eps + min_std (raw ? raw : eps) - `eps` carries
+// std * draw, the extra term the UNSCALED draw (raw [rows, cols], row stride ld_raw; NULL: eps itself, i.e. std = 1)
 int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int ld_eps, int64_t rows, int cols, int rows_per_group, float* out,
-                       hipStream_t st);
-//   dlv[r][c] = dz[r][c] * (z[r][c] - mu[g][c]) / 2
-int launch_reparam_bwd(const float* dz, const float* z, const float* mu, int64_t rows, int cols, int rows_per_group, float* dlv, hipStream_t st);
+                       hipStream_t st, float min_std = 0.f, const float* raw = nullptr, int ld_raw = 0);
+// dlv = dz (z - mu - min_std eps) / 2   (eps: the draw of the forward call, needed only with min_std != 0)
+int launch_reparam_bwd(const float* dz, const float* z, const float* mu, int64_t rows, int cols, int rows_per_group, float* dlv, hipStream_t st,
+                       float min_std = 0.f, const float* eps = nullptr, int ld_eps = 0);
 }  // namespace ardae

@@ -151,21 +151,27 @@ size_t workspace_floats(const AuxLayout& P, int B, int nz, int mode) {
 
 // out[r][c] = mu[g][c] + exp(lv[g][c] / 2) * eps[r][c],  g = r / rows_per_group  (models/ivae/auxmnist.py:33-41)
 __global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, int ld_stat, const float* __restrict__ eps,
-                                   int ld_eps, int64_t rows, int cols, int rows_per_group, float* __restrict__ out) {
+                                   int ld_eps, int64_t rows, int cols, int rows_per_group, float* __restrict__ out, float min_std,
+                                   const float* __restrict__ raw, int ld_raw) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cols;
     const int c = (int)(i - r * cols);
     const int64_t g = r / rows_per_group;
-    out[i] = mu[g * ld_stat + c] + __expf(0.5f * lv[g * ld_stat + c]) * eps[r * ld_eps + c];
+    const float e = eps[r * ld_eps + c];
+    float v = mu[g * ld_stat + c] + __expf(0.5f * lv[g * ld_stat + c]) * e;
+    if (min_std != 0.f) v += min_std * (raw ? raw[r * ld_raw + c] : e);
+    out[i] = v;
   }
 }
-// dlv[r][c] = dz[r][c] * (z[r][c] - mu[g][c]) / 2    (z - mu = exp(lv / 2) eps: d z / d lv = (z - mu) / 2)
+// dlv[r][c] = dz[r][c] * (z[r][c] - mu[g][c]) / 2    (z - mu = exp(lv / 2) eps: d z / d lv = (z - mu) / 2; with min_std: z - mu - min_std eps)
 __global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ mu, int64_t rows,
-                                   int cols, int rows_per_group, float* __restrict__ dlv) {
+                                   int cols, int rows_per_group, float* __restrict__ dlv, float min_std, const float* __restrict__ eps, int ld_eps) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cols;
     const int c = (int)(i - r * cols);
-    dlv[i] = 0.5f * dz[i] * (z[i] - mu[(r / rows_per_group) * cols + c]);
+    float d = z[i] - mu[(r / rows_per_group) * cols + c];
+    if (min_std != 0.f) d -= min_std * eps[r * ld_eps + c];
+    dlv[i] = 0.5f * dz[i] * d;
   }
 }
 int grid_of(int64_t n) {
@@ -173,13 +179,16 @@ int grid_of(int64_t n) {
   return (int)(g < 4096 ? g : 4096);
 }
 }  // namespace
-int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int ld_eps, int64_t rows, int cols, int rpg, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, mu, lv, cols, eps, ld_eps, rows, cols, rpg, out);
+int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int ld_eps, int64_t rows, int cols, int rpg, float* out, hipStream_t st,
+                       float min_std, const float* raw, int ld_raw) {
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, mu, lv, cols, eps, ld_eps, rows, cols, rpg, out, min_std, raw, ld_raw);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }
-int launch_reparam_bwd(const float* dz, const float* z, const float* mu, int64_t rows, int cols, int rpg, float* dlv, hipStream_t st) {
-  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, dz, z, mu, rows, cols, rpg, dlv);
+int launch_reparam_bwd(const float* dz, const float* z, const float* mu, int64_t rows, int cols, int rpg, float* dlv, hipStream_t st, float min_std,
+                       const float* eps, int ld_eps) {
+  ARDAE_CHECK_ARG(min_std == 0.f || eps, "reparam_bwd: min_std needs the forward draw");
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, dz, z, mu, rows, cols, rpg, dlv, min_std, eps, ld_eps);
   ARDAE_LAUNCH_CHECK();
   return 0;
 }

@@ -93,8 +93,8 @@ int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 6,
                   "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE), 3 (MNISTAuxIPVAE), 4 (MNISTConvAuxIPVAE), 5 (ResConvIPVAE) or "
                   "6 (MNISTResConvAuxIPVAE)");
-  ARDAE_CHECK_ARG((d->flags & ~(ARDAE_MODEL_NO_CENTER | ARDAE_MODEL_HEAD_MASK)) == 0 && (d->kind >= 5 || d->flags == 0),
-                  "model: unknown flags %d (ARDAE_MODEL_NO_CENTER / the sampler-head bits exist for the residual-conv kinds 5 / 6 only)", d->flags);
+  ARDAE_CHECK_ARG((d->flags & ~(ARDAE_MODEL_NO_CENTER | ARDAE_MODEL_HEAD_MASK | ARDAE_MODEL_CLIPPED)) == 0 && (d->kind >= 5 || d->flags == 0),
+                  "model: unknown flags %d (ARDAE_MODEL_NO_CENTER / the sampler-head bits / ARDAE_MODEL_CLIPPED exist for the residual-conv kinds 5 / 6 only)", d->flags);
   if (d->kind >= 5) {
     ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1 && d->h_dim >= 1 && d->act == ACT_ELU && (d->kind == 6 || (d->n_layers >= 1 && d->n_layers <= 4)),
                     "model: the residual-conv models are 28x28x1, ELU, and (kind 5) 1 .. 4 hidden layers in the sampler head");
@@ -395,6 +395,13 @@ int ardae_model_encode_pair(const ardae_model_desc* d, const float* params, cons
   return 0;
 }
 
+int ardae_model_encode_hidden_raw(const ardae_model_desc* d, const float* params, const float* packed, const float* x, const float* raw0, int B,
+                                  float* workspace, size_t workspace_floats_, float* z0_out, float* hidden_out, void* stream) {
+  ARDAE_TRY(model_common(d, params, packed, x, B, 1, workspace, workspace_floats_, 0));
+  ARDAE_CHECK_ARG(d->kind == 6 && (d->flags & ARDAE_MODEL_CLIPPED), "model_encode_hidden_raw: the clipped aux-resconv class only (kind 6 + ARDAE_MODEL_CLIPPED)");
+  ARDAE_CHECK_ARG(z0_out || hidden_out, "model_encode_hidden_raw: nothing to return");
+  return res_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, (hipStream_t)stream, raw0);
+}
 int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B, float* workspace,
                               size_t workspace_floats_, float* z0_out, float* hidden_out, void* stream) {
   ARDAE_TRY(model_common(d, params, packed, x, B, 1, workspace, workspace_floats_, 0));

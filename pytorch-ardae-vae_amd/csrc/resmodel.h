@@ -11,7 +11,7 @@ size_t res_model_packed_floats(const ardae_model_desc& d);
 size_t res_model_workspace_floats(const ardae_model_desc& d, int B, int nz, int mode);
 int res_model_pack(const ardae_model_desc& d, const float* params, float* packed, hipStream_t st);
 int res_model_encode(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,
-                     float* workspace, size_t wsf, float* z_out, float* hidden_out, hipStream_t st);
+                     float* workspace, size_t wsf, float* z_out, float* hidden_out, hipStream_t st, const float* raw0 = nullptr);
 int res_model_decode(const ardae_model_desc& d, const float* params, const float* packed, const float* z, int R, float* workspace, size_t wsf,
                      float* out0, hipStream_t st);
 int res_model_vae_forward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,

@@ -229,9 +229,11 @@ __global__ void nhwc_nchw_kernel(const float* __restrict__ in, int HW, int C, fl
   if (to_nhwc) out[e] = in[nchw]; else out[nchw] = in[e];
 }
 // NormalDistribution.clip_logvar 'spm4' (models/reparam.py:30-31): y = softplus(x + 4) - 4; backward: dx = dy * sigmoid(x + 4)
-__global__ void spm4_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ y, int64_t n) {
+// identity != 0 (the clipped class of ivae/auxresconv2.py:71-72 builds its heads WITHOUT the clip): y = x, dx = dy
+__global__ void spm4_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ y, int64_t n, int identity) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
+  if (identity) { y[e] = dy ? dy[e] : x[e]; return; }
   const float u = x[e] + 4.f;
   if (dy) y[e] = dy[e] / (1.f + expf(-u));
   else y[e] = (u > 20.f ? u : log1pf(expf(u))) - 4.f;
@@ -257,13 +259,15 @@ enum { HEAD_RES_WN_MLP = 0, HEAD_MLP = 1, HEAD_RES_MLP = 2, HEAD_RES_WN_MLP_LIN 
 struct ResLayout {
   int kind, nd, zd, cdim, hdim;
   bool center;                   // do_center: the trunk sees 2x - 1 (desc.flags without ARDAE_MODEL_NO_CENTER)
+  bool clipped;                  // kind 6 + ARDAE_MODEL_CLIPPED: MNISTResConvAuxIPVAEClipped (no 'spm4' clip, z0 keeps an unscaled eps0)
   std::vector<Blk> trunk, dec;   // trunk: 5 conv + ResLinear(512 -> cdim); dec: 2 ResLinear + 5 conv
   std::vector<HeadOp> head;      // kind 5: encode.fc (the shipped recipe: ResLinear(cdim + nd -> hdim), ELU, ResLinear(hdim -> zd), un-normalised WN operators)
   Lin mu0, lv0, efc, mu, lv;     // kind 6: aux_encode.reparam.{mean,logvar}_fn, encode.fc.0, encode.reparam.{mean,logvar}_fn
   size_t total = 0;
 
   explicit ResLayout(const ardae_model_desc& d)
-      : kind(d.kind), nd(d.noise_dim), zd(d.z_dim), cdim(d.kind == 5 ? 512 : d.h_dim), hdim(d.h_dim), center(!(d.flags & ARDAE_MODEL_NO_CENTER)) {
+      : kind(d.kind), nd(d.noise_dim), zd(d.z_dim), cdim(d.kind == 5 ? 512 : d.h_dim), hdim(d.h_dim), center(!(d.flags & ARDAE_MODEL_NO_CENTER)),
+        clipped(d.kind == 6 && (d.flags & ARDAE_MODEL_CLIPPED)) {
     size_t off = 0;
     auto wn = [&](int O, int I, bool norm, bool plain = false) {
       WN w; w.O = O; w.I = I; w.norm = norm; w.plain = plain;
@@ -384,7 +388,8 @@ int res_desc_ok(const ardae_model_desc& d) {
   ARDAE_CHECK_ARG(d.act == ACT_ELU, "model: the residual-conv models use ELU (--model-nonlin elu; models/ivae/auxresconv.py:69 asserts it)");
   ARDAE_CHECK_ARG(d.kind != 5 || (d.n_layers >= 1 && d.n_layers <= 4), "model: ResConvIPVAE takes --model-n-layers 1 .. 4");
   ARDAE_CHECK_ARG(d.kind != 5 || ((d.flags >> 1) & 7) <= HEAD_RES_MLP_LIN, "model: unknown sampler head %d (desc.flags bits 1-3)", (d.flags >> 1) & 7);
-  ARDAE_CHECK_ARG(d.kind == 5 || (d.flags >> 1) == 0, "model: the sampler-head bits of desc.flags belong to kind 5");
+  ARDAE_CHECK_ARG(d.kind == 5 || ((d.flags >> 1) & 7) == 0, "model: the sampler-head bits of desc.flags belong to kind 5");
+  ARDAE_CHECK_ARG(d.kind == 6 || !(d.flags & ARDAE_MODEL_CLIPPED), "model: ARDAE_MODEL_CLIPPED belongs to kind 6");
   if (d.kind == 5) {   // a concat block needs its projected skip (same_dim would make the skip the 612-wide concat itself)
     const int ht = (d.flags >> 1) & 7;
     ARDAE_CHECK_ARG(ht == HEAD_MLP || 512 + d.noise_dim != d.h_dim, "model: ResConvIPVAE with c_dim + noise_dim == h_dim (identity skip over the concat input) is not built");
@@ -641,8 +646,9 @@ int trunk_fwd(const ResLayout& P, const ResPacked& K, const float* params, const
 }
 
 // sampler tail on R = B*nz rows; noise [R, nd] (kind 5) or [R, nd + zd] rows [eps0 | eps] (kind 6); z -> z_out
+// raw0 (clipped class, std = 0 pass only - `noise` is then the zero block): the unscaled eps0 [R, nd] z0 keeps, or NULL (zeros)
 int sampler_fwd(const ResLayout& P, const ResPacked& K, const float* params, const float* packed, const float* noise, int B, int nz, ResWs& W, float* z_out,
-                float* hidden_out, hipStream_t st) {
+                float* hidden_out, hipStream_t st, const float* raw0 = nullptr, bool std0 = false) {
   const int R = B * nz;
   if (P.kind == 5) {
     // encode.fc operator by operator; the per-image half of a concat input enters as a row bias (computed once per image)
@@ -692,8 +698,10 @@ int sampler_fwd(const ResLayout& P, const ResPacked& K, const float* params, con
   const int ldn = P.nd + P.zd;
   { LinArgs A{}; A.bias = params + P.mu0.b; A.Y = W.mu0; A.ldY = P.nd; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.nd, W.inp, P.cdim, P.cdim, packed + K.mu0.f, A, st)); }
   { LinArgs A{}; A.bias = params + P.lv0.b; A.Y = W.lv0r; A.ldY = P.nd; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.nd, W.inp, P.cdim, P.cdim, packed + K.lv0.f, A, st)); }
-  RES_LAUNCH(spm4_kernel, (int64_t)B * P.nd, W.lv0r, (const float*)nullptr, W.lv0, (int64_t)B * P.nd);
-  ARDAE_TRY(launch_reparam_fwd(W.mu0, W.lv0, noise, ldn, R, P.nd, nz, W.z0, st));
+  RES_LAUNCH(spm4_kernel, (int64_t)B * P.nd, W.lv0r, (const float*)nullptr, W.lv0, (int64_t)B * P.nd, (int)P.clipped);
+  // clipped: z0 = mu0 + (std exp(lv0 / 2) + 1) eps0; the std = 0 pass (noise = zeros) takes its unscaled draw from raw0 (none: z0 = mu0)
+  if (P.clipped && !(std0 && !raw0)) ARDAE_TRY(launch_reparam_fwd(W.mu0, W.lv0, noise, ldn, R, P.nd, nz, W.z0, st, 1.f, std0 ? raw0 : nullptr, P.nd));
+  else ARDAE_TRY(launch_reparam_fwd(W.mu0, W.lv0, noise, ldn, R, P.nd, nz, W.z0, st));
   { LinArgs A{}; A.bias = params + P.efc.b; A.Y = W.rbh; A.ldY = P.cdim; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.cdim, W.inp, P.cdim, P.cdim, packed + K.efc.fi, A, st)); }
   { LinArgs A{}; A.rowbias = W.rbh; A.rowbias_ld = P.cdim; A.rows_per_group = nz; A.Y = W.hh; A.ldY = P.cdim;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.cdim, W.z0, P.nd, P.nd, packed + K.efc.fn, A, st)); }
@@ -701,7 +709,7 @@ int sampler_fwd(const ResLayout& P, const ResPacked& K, const float* params, con
   if (hidden_out) ARDAE_TRY(launch_copy(W.hh, (size_t)R * P.cdim, hidden_out, st));
   { LinArgs A{}; A.bias = params + P.mu.b; A.Y = W.mu; A.ldY = P.zd; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.hh, P.cdim, P.cdim, packed + K.mu.f, A, st)); }
   { LinArgs A{}; A.bias = params + P.lv.b; A.Y = W.lvr; A.ldY = P.zd; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.hh, P.cdim, P.cdim, packed + K.lv.f, A, st)); }
-  RES_LAUNCH(spm4_kernel, (int64_t)R * P.zd, W.lvr, (const float*)nullptr, W.lv, (int64_t)R * P.zd);
+  RES_LAUNCH(spm4_kernel, (int64_t)R * P.zd, W.lvr, (const float*)nullptr, W.lv, (int64_t)R * P.zd, (int)P.clipped);
   return launch_reparam_fwd(W.mu, W.lv, noise + P.nd, ldn, R, P.zd, 1, z_out, st);
 }
 
@@ -821,7 +829,7 @@ int res_model_pack(const ardae_model_desc& d, const float* params, float* packed
 }
 
 int res_model_encode(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,
-                     float* workspace, size_t wsf, float* z_out, float* hidden_out, hipStream_t st) {
+                     float* workspace, size_t wsf, float* z_out, float* hidden_out, hipStream_t st, const float* raw0) {
   const ResLayout P(d);
   const ResPacked K(P);
   Bump ws(workspace, wsf);
@@ -833,7 +841,8 @@ int res_model_encode(const ardae_model_desc& d, const float* params, const float
   const float* nzp = noise_or_zero(P, noise, B * nz, W, st, rc);
   ARDAE_TRY(rc);
   ARDAE_TRY(trunk_fwd(P, K, params, packed, x, B, W, st));
-  return sampler_fwd(P, K, params, packed, nzp, B, nz, W, z_out ? z_out : W.z, hidden_out, st);
+  ARDAE_CHECK_ARG(!raw0 || (P.clipped && !noise), "res model: raw0 is the clipped class's unscaled eps0 of a std = 0 pass (noise NULL)");
+  return sampler_fwd(P, K, params, packed, nzp, B, nz, W, z_out ? z_out : W.z, hidden_out, st, raw0, noise == nullptr);
 }
 
 int res_model_decode(const ardae_model_desc& d, const float* params, const float* packed, const float* z, int R, float* workspace, size_t wsf,
@@ -971,7 +980,7 @@ int res_model_vae_backward(const ardae_model_desc& d, const float* params, const
     // z = mu + exp(lv/2) eps,  lv = spm4(lvr)
     float* dlv = W.sc.g;           // [R, zd]
     ARDAE_TRY(launch_reparam_bwd(W.dzq, W.z, W.mu, R, P.zd, 1, dlv, st));
-    RES_LAUNCH(spm4_kernel, (int64_t)R * P.zd, W.lvr, (const float*)dlv, dlv, (int64_t)R * P.zd);
+    RES_LAUNCH(spm4_kernel, (int64_t)R * P.zd, W.lvr, (const float*)dlv, dlv, (int64_t)R * P.zd, (int)P.clipped);
     plain_wgrad(R, P.mu, W.dzq, W.hh, P.cdim, 0, P.cdim, true);
     plain_wgrad(R, P.lv, dlv, W.hh, P.cdim, 0, P.cdim, true);
     float* dhh = W.dR0;            // [R, cdim]
@@ -984,10 +993,10 @@ int res_model_vae_backward(const ardae_model_desc& d, const float* params, const
     { LinArgs A{}; A.Y = dz0; A.ldY = P.nd; ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.nd, dhh, P.cdim, P.cdim, packed + K.efc.bn, A, st)); }
     // z0 = mu0[b] + exp(lv0[b] / 2) eps0,  lv0 = spm4(lv0r): reduce over the nz rows of an image first
     float* dlv0_rows = W.sc.dh;    // [R, nd]
-    ARDAE_TRY(launch_reparam_bwd(dz0, W.z0, W.mu0, R, P.nd, nz, dlv0_rows, st));
+    ARDAE_TRY(launch_reparam_bwd(dz0, W.z0, W.mu0, R, P.nd, nz, dlv0_rows, st, P.clipped ? 1.f : 0.f, noise, ldn));
     ARDAE_TRY(launch_segment_sum(dz0, P.nd, B, nz, P.nd, 1.f, W.dB1, P.nd, st));            // d mu0 [B, nd]
     ARDAE_TRY(launch_segment_sum(dlv0_rows, P.nd, B, nz, P.nd, 1.f, W.dB2, P.nd, st));      // d lv0 [B, nd]
-    RES_LAUNCH(spm4_kernel, (int64_t)B * P.nd, W.lv0r, (const float*)W.dB2, W.dB2, (int64_t)B * P.nd);
+    RES_LAUNCH(spm4_kernel, (int64_t)B * P.nd, W.lv0r, (const float*)W.dB2, W.dB2, (int64_t)B * P.nd, (int)P.clipped);
     plain_wgrad(B, P.mu0, W.dB1, W.inp, P.cdim, 0, P.cdim, true);
     plain_wgrad(B, P.lv0, W.dB2, W.inp, P.cdim, 0, P.cdim, true);
     ARDAE_TRY(flush_wgrad(probs, W.wscratch, W.wscratch_floats, st));

@@ -143,6 +143,11 @@ class ArdaeEngine:
             raise NotImplementedError("hidden1a is the aux models' context (ivae_ardae.py:572-580)")
         self.hidden_ctx = cfg.cdae_ctx_type == "hidden1a"
         self.data_ctx = cfg.cdae_ctx_type == "data"
+        # MNISTResConvAuxIPVAEClipped: the two std = 0 calls that open each phase are RANDOM draws (z0 keeps an unscaled eps0,
+        # ivae/auxresconv2.py:91) - one for the context, one for the latent mean - so they cannot share a pass
+        self.clipped = bool(getattr(model, "_clipped", False))
+        if self.clipped and not self.hidden_ctx:
+            raise NotImplementedError("MNISTResConvAuxIPVAEClipped is built with --cdae-ctx-type hidden1a (the aux models' context, ivae_ardae.py:572-580)")
         ctx_dim = model.hidden_dim if self.hidden_ctx else int(model.input_dim) if self.data_ctx else z
         if int(cdae.context_dim) != ctx_dim:
             raise ValueError(f"cdae.context_dim = {cdae.context_dim}, but the {cfg.cdae_ctx_type} context has {ctx_dim} columns")
@@ -161,6 +166,8 @@ class ArdaeEngine:
         self.xbar, self.sigma, self.std_b = f(B * S, z), f(B * S), f(B)
         self.noise_v, self.zv, self.z0v, self.u, self.g = f(B * nzm, nd), f(B * nzm, z), f(B, z), f(B * nzm, z), f(B * nzm, z)
         self.sigma0 = torch.zeros(B * nzm, device=self.dev)
+        if self.clipped:        # [context draw | latent-mean draw] of a phase's two std = 0 calls, [2, B, z0_dim]
+            self.raw_c, self.raw_v = f(2, B, model.noise_dim), f(2, B, model.noise_dim)
         self.ctx_c, self.ctx_v = (f(B, ctx_dim), f(B, ctx_dim)) if (self.hidden_ctx or self.data_ctx) else (self.z0, self.z0v)
         if self.data_ctx:      # 2x - 1 = 2 (x - 1/2) through ardae_center_scale; uncentred: x - 0
             self._ctx_half = torch.full((B, ctx_dim), 0.5 if cfg.ctx_data_center else 0.0, device=self.dev)
@@ -233,8 +240,16 @@ class ArdaeEngine:
                                             L.ptr(noise) if noise is not None else None, self.B, nz, L.ptr(ws), ws.numel(),
                                             L.ptr(out), L.stream_ptr()), "ardae_model_encode")
 
-    def _hidden(self, x, z0_out, out, ws):
-        """The std = 0 pass of an aux sampler: latent mean z0 AND the hidden1a context in one go."""
+    def _hidden(self, x, z0_out, out, ws, raws=None):
+        """The std = 0 pass of an aux sampler: latent mean z0 AND the hidden1a context in one go.  raws [2, B, z0_dim] (clipped class):
+        two passes - the context with draw 0, the latent mean with draw 1."""
+        if self.clipped:
+            md, st = self.model._desc, L.stream_ptr()
+            for k, (zo, ho) in enumerate(((None, out), (z0_out, None))):
+                L.check(self.lib.ardae_model_encode_hidden_raw(ctypes.byref(md), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), L.ptr(raws[k]), self.B,
+                                                               L.ptr(ws), ws.numel(), None if zo is None else L.ptr(zo), None if ho is None else L.ptr(ho), st),
+                        "ardae_model_encode_hidden_raw")
+            return
         L.check(self.lib.ardae_model_encode_hidden(ctypes.byref(self.model._desc), L.ptr(self.model._flat), L.ptr(self.pk_m), L.ptr(x), self.B,
                                                    L.ptr(ws), ws.numel(), L.ptr(z0_out), L.ptr(out), L.stream_ptr()), "ardae_model_encode_hidden")
 
@@ -397,7 +412,13 @@ class ArdaeEngine:
         if self.hidden_ctx:
             # aux models: hidden = model.encode.forward_hidden(x, std=0) and latent_mean = model.encode(x, std=0) are ONE std = 0 pass
             # (ivae_ardae.py:737-739,748), then the N-row pass
-            self._hidden(x, self.z0, self.ctx_c, self.ws_small)
+            raws = None
+            if self.clipped:
+                if noise:
+                    raws = torch.stack([noise["ctx_raw"].reshape(B, -1), noise["z0_raw"].reshape(B, -1)]).float().contiguous()
+                else:      # one Philox draw for both (index 9 + update: behind the 3 x 3 draws of up to three cDAE updates)
+                    raws = self._normal(self.raw_c, None if draw0 is None else 9 + draw0 // 3)
+            self._hidden(x, self.z0, self.ctx_c, self.ws_small, raws)
             self._encode(x, ns, nz, self.latent, self.ws)
         else:
             # context == latent_mean == encode(x, std=0) (lt0) and forward_hidden(x, nz) share the per-image trunk: one pass
@@ -456,7 +477,13 @@ class ArdaeEngine:
                                             float(beta), L.ptr(self.ws_vae), self.ws_vae.numel(), L.ptr(self.zv), L.ptr(self.losses_m), st),
                 "ardae_model_vae_forward")
         if self.hidden_ctx:      # context and latent mean of the VAE batch: one std = 0 pass (ivae_ardae.py:815-817,826)
-            self._hidden(x, self.z0v, self.ctx_v, self.ws_small_v)
+            raws = None
+            if self.clipped:
+                if noise:
+                    raws = torch.stack([noise["vctx_raw"].reshape(B, -1), noise["vz0_raw"].reshape(B, -1)]).float().contiguous()
+                else:
+                    raws = self._normal(self.raw_v, None if draw is None else 12)
+            self._hidden(x, self.z0v, self.ctx_v, self.ws_small_v, raws)
         else:
             self._encode(x, None, 1, self.z0v, self.ws_small_v)
         if self.data_ctx:
@@ -564,6 +591,8 @@ class ArdaeEngine:
         self._check_batch(x_vae, "step(x_vae)")
         if 3 * len(xs) >= self.RNG_STRIDE:
             raise ValueError("at most %d cDAE updates per step (Philox offsets reserved per step)" % ((self.RNG_STRIDE - 1) // 3))
+        if self.clipped and len(xs) > 3:
+            raise ValueError("at most 3 cDAE updates per step with MNISTResConvAuxIPVAEClipped (its std = 0 draws use Philox offsets 9 .. 12)")
         if self.use_graph and noise is None:
             b = float(self.cfg.beta if beta is None else beta)
             # static copies of the batches (one per DISTINCT batch object: --num-cdae-updates k on one tensor shares its copy)

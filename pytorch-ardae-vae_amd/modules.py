@@ -593,6 +593,43 @@ class MNISTResConvAuxIPVAE(ImplicitPosteriorVAE):
         super().__init__(energy_func, 784, z0_dim, c_dim, z_dim, nonlinearity, 1, "none", "concat")
 
 
+class MNISTResConvAuxIPVAEClipped(MNISTResConvAuxIPVAE):
+    """models/ivae/auxresconv2.py::ImplicitPosteriorVAE (`--model auxresconv-clip` / `auxresconvct-clip`, ivae_ardae.py:507-534): the
+    same networks with the two log-variance heads built WITHOUT the 'spm4' clip (:71-72) and z0 = mu0 + (std exp(lv0 / 2) + 1) eps0
+    (`sample_gaussian(..., min_std=1.)`, :29-36,91).  Consequence the training loop inherits: `encode(x, std=0)` /
+    `forward_hidden(x, std=0)` are RANDOM draws here (z0 = mu0 + eps0).  `noise` of a std = 0 call is that unscaled eps0 [B, z0_dim]
+    (default: a fresh Philox draw); other calls take unscaled draws (std None / 1: the only values the reference's loop uses)."""
+    _clipped = True
+
+    def __init__(self, *a, **k):
+        self._flag_extra = L.MODEL_CLIPPED
+        super().__init__(*a, **k)
+
+    def _std0(self, x, raw0, want_hidden):
+        B, lib = x.size(0), L.lib()
+        raw = _f32c(raw0).view(B, -1)[:, :self.z0_dim].contiguous() if raw0 is not None else rng.normal((B, self.z0_dim), x.device)
+        ws = self._ws(lib.ardae_model_workspace_floats(ctypes.byref(self._desc), B, 1, 0))
+        out = torch.empty(B, self.hidden_dim if want_hidden else self.z_dim, device=x.device)
+        L.check(lib.ardae_model_encode_hidden_raw(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(x), L.ptr(raw), B,
+                                                  L.ptr(ws), ws.numel(), None if want_hidden else L.ptr(out), L.ptr(out) if want_hidden else None,
+                                                  L.stream_ptr()), "ardae_model_encode_hidden_raw")
+        return out
+
+    def _sample(self, x, nz, std, noise):
+        if std is not None and float(std) == 0.0:
+            if nz != 1:
+                raise NotImplementedError("the clipped class at std = 0 is built for nz = 1 (what ivae_ardae.py:735-748,815-826 calls)")
+            if isinstance(noise, (tuple, list)):
+                noise = noise[0]
+            return self._std0(x, noise, False).view(x.size(0), 1, self.z_dim)
+        if std is not None and float(std) != 1.0:
+            raise NotImplementedError("MNISTResConvAuxIPVAEClipped: std must be None, 1 or 0 (the unscaled eps0 term needs the draw and std apart)")
+        return super()._sample(x, nz, None, noise)
+
+    def _hidden(self, input, raw0=None):
+        return self._std0(self._x(input), raw0, True)
+
+
 class ToyIPVAE(ImplicitPosteriorVAE):
     """models/ivae/toy.py::ImplicitPosteriorVAE with enc_type='concat' (`--model mlp-concat`)."""
     _kind = "toy"

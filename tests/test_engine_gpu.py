@@ -58,6 +58,10 @@ RESCONV_HEAD_CASES = {"resconv_mlp_b4_nz8": ("mlp", 1, True), "resconv_mlp2_noce
                       "resconv_resx2_b4_nz8": ("res-wn-mlp", 2, True)}
 for _nm, (_et, _nl, _ctr) in RESCONV_HEAD_CASES.items():
     CASES[_nm] = (O.ModelCfg("resconv", 784, 100, 512, 32, _nl, "elu", do_center=_ctr, enc_type=_et), O.CdaeCfg("res", 32, 32, 64, 2), 8, False)
+# --model auxresconv-clip / auxresconvct-clip (ivae_ardae.py:507-534): MNISTResConvAuxIPVAEClipped - unclipped log-variances, z0 keeps an unscaled eps0,
+# so the std = 0 calls of the loop are random draws whose eps0 the fixtures carry (noise/ctx_raw, z0_raw, vctx_raw, vz0_raw)
+CASES["auxresconv_clip_b4_nz8"] = (O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", clipped=True), O.CdaeCfg("res", 32, 450, 64, 2), 8, False)
+CASES["auxresconv_clip_nocenter_b4_nz8"] = (O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False, clipped=True), O.CdaeCfg("res", 32, 450, 64, 2), 8, False)
 RES_RECIPE = dict(std_scale=100., m_lr=1e-3, m_beta1=0.9, d_momentum=0.9)     # run_vae_dbmnist.sh, the two resconv lines
 
 
@@ -66,8 +70,8 @@ def build(mc, cc):
         model = net.ResConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers, noise_dim=mc.noise_dim,
                                  nonlinearity=mc.nonlin, do_center=mc.do_center, enc_type=mc.enc_type)
     elif mc.kind == "auxresconv":
-        model = net.MNISTResConvAuxIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim, nonlinearity=mc.nonlin,
-                                         do_center=mc.do_center)
+        model = (net.MNISTResConvAuxIPVAEClipped if mc.clipped else net.MNISTResConvAuxIPVAE)(
+            input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=mc.do_center)
     elif mc.kind == "auxconv":
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "auxmnist":
@@ -128,6 +132,9 @@ def noise_of(fx, t, dev):
     for k in ("sampler", "vae"):        # aux models: the second draw of a sampler call sits beside the first, rows [eps0 | eps]
         if f"s{t}/noise/{k}_z" in fx:
             n[k] = torch.cat([n[k], torch.tensor(fx[f"s{t}/noise/{k}_z"])], 1)
+    for k in ("ctx_raw", "z0_raw", "vctx_raw", "vz0_raw"):      # the clipped class: unscaled eps0 of the std = 0 calls
+        if f"s{t}/noise/{k}" in fx:
+            n[k] = torch.tensor(fx[f"s{t}/noise/{k}"])
     return {k: v.to(dev).contiguous() for k, v in n.items()}
 
 
@@ -603,6 +610,42 @@ def test_engine_two_cdae_updates_per_step(graph):
     assert not torch.equal(outs[0][1].cpu(), torch.cat([pc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)]))
 
 
+def test_engine_clipped_aux_resconv_own_draws_replay_and_refusals():
+    """--model auxresconv-clip / auxresconvct-clip with the engine's OWN noise: every phase opens with two std = 0 calls that are random
+    draws for this class (z0 = mu0 + eps0, ivae/auxresconv2.py:91) - four extra Philox draws per step (offsets 9 .. 12), made inside the
+    captured graphs.  Two engines from one seed end bit-identical after eager + captured + replayed steps, replay == eager, the draws move
+    from step to step; and what the class is not built for is refused by name."""
+    mc = O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", clipped=True)
+    cc = O.CdaeCfg("res", 32, 450, 64, 2)
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc)); pc = O.init_params(O.cdae_param_spec(cc), 1)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.bernoulli(torch.full((4, 784), 0.2), generator=g) for _ in range(3)]
+
+    def run(graph):
+        net.manual_seed(77)
+        model, cdae = build(mc, cc)
+        model.load_state_dict(pm); cdae.load_state_dict(pc)
+        model, cdae = model.to("cuda"), cdae.to("cuda")
+        eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=8, cdae_ctx_type="hidden1a", **RES_RECIPE), batch_size=4, graph=graph)
+        raws = []
+        for t in range(4):
+            eng.step(xs[t % 3].cuda(), xs[(t + 1) % 3].cuda())
+            raws.append(torch.cat([eng.raw_c.flatten(), eng.raw_v.flatten()]).clone())
+        torch.cuda.synchronize()
+        assert all(v == v for v in eng.stats().values())
+        return model.flat_params().clone(), cdae.flat_params().clone(), raws
+    a, b, e = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])                      # deterministic
+    assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1])                      # replay == eager
+    assert not torch.equal(a[2][2], a[2][3]) and float(a[2][3].abs().max()) > 0     # fresh draws in every replay
+    assert abs(float(a[2][3].mean())) < 0.2 and abs(float(a[2][3].std()) - 1) < 0.2
+    model, cdae = build(mc, O.CdaeCfg("res", 32, 32, 64, 2))
+    with pytest.raises(NotImplementedError, match="hidden1a"):
+        net.ArdaeEngine(model.to("cuda"), cdae.to("cuda"), net.TrainConfig(nz_cdae=8, cdae_ctx_type="lt0"), batch_size=4)
+    with pytest.raises(NotImplementedError, match="std must be"):
+        model.encode(xs[0].cuda(), std=0.5)
+
+
 def test_engine_beta_annealing_under_graph_mode():
     """--beta-annealing (utils/msc.py:53-55, ivae_ardae.py:800): beta is a kernel argument frozen in a captured graph, so the
     engine launches eagerly while beta moves and captures once it has settled - with the same parameters, bit for bit, as an
@@ -733,7 +776,7 @@ def test_iwae_logprob_golden_auxconv(golden_dir):
     assert abs(float(got) - ref) < 1e-4 * abs(ref)          # fixture is float64; the device path is fp32
 
 
-@pytest.mark.parametrize("name", ["resconv_b4_nz8", "auxresconv_b4_nz8"] + list(RESCONV_HEAD_CASES))
+@pytest.mark.parametrize("name", ["resconv_b4_nz8", "auxresconv_b4_nz8", "auxresconv_clip_b4_nz8"] + list(RESCONV_HEAD_CASES))
 def test_resconv_vae_phase_grads_vs_oracle(golden_dir, name):
     """The weight-normalised residual-conv families: EVERY gradient tensor of the VAE phase - direction, scale and bias
     of all 45 weight-normalised operators (conv trunk, ResLinear / ResMLP sampler head or the two Gaussian heads with 'spm4' clipping,
@@ -750,11 +793,20 @@ def test_resconv_vae_phase_grads_vs_oracle(golden_dir, name):
     eng = net.ArdaeEngine(model, cdae, tcfg, batch_size=B)
     noise = noise_of(fx, 0, "cuda")
     xv = torch.tensor(fx["s0/x_vae"])
-    if mc.kind == "auxresconv":
-        hid = model.encode.forward_hidden(xv.cuda(), std=0)
-        assert hid.shape == (B, 450) and rel_l2(hid, O.cdae_context(mc, tc, pm, xv)) < 1e-5
-    z0 = model.encode(xv.cuda(), std=0)
-    assert rel_l2(z0.reshape(B, -1), O.encode(mc, pm, xv, O.zero_noise(mc, B, xv), 1).reshape(B, -1)) < 1e-5
+    if mc.kind == "auxresconv" and mc.clipped:      # the std = 0 calls are random draws: inject the fixture's unscaled eps0
+        rc, rz = torch.tensor(fx["s0/noise/vctx_raw"]), torch.tensor(fx["s0/noise/vz0_raw"])
+        hid = model._hidden(xv.cuda(), raw0=rc.cuda())
+        assert hid.shape == (B, 450) and rel_l2(hid, O.cdae_context(mc, tc, pm, xv, rc)) < 1e-5
+        z0 = model.forward_hidden(xv.cuda(), std=0, nz=1, noise=rz.cuda())
+        assert rel_l2(z0.reshape(B, -1), O.encode(mc, pm, xv, O.zero_noise(mc, B, xv, rz), 1).reshape(B, -1)) < 1e-5
+        d1, d2 = model.encode(xv.cuda(), std=0), model.encode(xv.cuda(), std=0)      # fresh draws: two calls differ (z0 = mu0 + eps0)
+        assert not torch.equal(d1, d2) and torch.isfinite(d1).all()
+    else:
+        if mc.kind == "auxresconv":
+            hid = model.encode.forward_hidden(xv.cuda(), std=0)
+            assert hid.shape == (B, 450) and rel_l2(hid, O.cdae_context(mc, tc, pm, xv)) < 1e-5
+        z0 = model.encode(xv.cuda(), std=0)
+        assert rel_l2(z0.reshape(B, -1), O.encode(mc, pm, xv, O.zero_noise(mc, B, xv), 1).reshape(B, -1)) < 1e-5
     eng.vae_phase(xv.cuda(), noise=noise, apply_update=False)
     cpu_noise = {k[len("s0/noise/"):]: torch.tensor(v) for k, v in fx.items() if k.startswith("s0/noise/")}
     mloss, rec, pri, g, gm = O.vae_update_grads(mc, cc, tc, pm, pc, xv, cpu_noise)
@@ -776,11 +828,12 @@ def test_resconv_vae_phase_grads_vs_oracle(golden_dir, name):
     assert rel_l2(zs.reshape(B * 40, -1), O.encode(mc, pm, xv, nref, 40).reshape(B * 40, -1)) < 1e-5
 
 
-@pytest.mark.parametrize("name,kind,h", [("iwae_resconv", "resconv", 512), ("iwae_auxresconv", "auxresconv", 450), ("iwae_resconv_mlp", "resconv", 512)])
+@pytest.mark.parametrize("name,kind,h", [("iwae_resconv", "resconv", 512), ("iwae_auxresconv", "auxresconv", 450), ("iwae_resconv_mlp", "resconv", 512),
+                                         ("iwae_auxresconv_clip", "auxresconv", 450)])
 def test_iwae_logprob_golden_resconv(golden_dir, name, kind, h):
     """logprob (ivae/resconv.py:325-380, ivae/auxresconv.py:275-345) of the residual-conv models against the reference's value with injected draws."""
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-    mc = O.ModelCfg(kind, 784, 100, h, 32, 1, "elu", enc_type="mlp" if name.endswith("_mlp") else "res-wn-mlp")
+    mc = O.ModelCfg(kind, 784, 100, h, 32, 1, "elu", enc_type="mlp" if name.endswith("_mlp") else "res-wn-mlp", clipped=name.endswith("_clip"))
     pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc))
     model, _ = build(mc, O.CdaeCfg("res", 32, 450 if kind == "auxresconv" else 32, 32, 2))
     model.load_state_dict(pm)

@@ -108,6 +108,9 @@ def test_oracle_step_matches_reference_fixture(golden_dir, name):
     # --model resconv-res / auxresconv: the same families with do_center=False
     ("resconv_nocenter_b4_nz8", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 32, 64, 2), "lt0"),
     ("auxresconv_nocenter_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False), O.CdaeCfg("res", 32, 450, 64, 2), "hidden1a"),
+    # --model auxresconv-clip / auxresconvct-clip (MNISTResConvAuxIPVAEClipped): the fixture's noise holds the unscaled eps0 of the std = 0 calls
+    ("auxresconv_clip_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", clipped=True), O.CdaeCfg("res", 32, 450, 64, 2), "hidden1a"),
+    ("auxresconv_clip_nocenter_b4_nz8", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", do_center=False, clipped=True), O.CdaeCfg("res", 32, 450, 64, 2), "hidden1a"),
     # the other sampler heads of ResConvIPVAE (--model resconv / resconvct, -res2, -res3, -res4; one and two hidden layers)
 ] + [(nm, O.ModelCfg("resconv", 784, 100, 512, 32, nl, "elu", do_center=ctr, enc_type=et), O.CdaeCfg("res", 32, 32, 64, 2), "lt0") for nm, et, nl, ctr in (
     ("resconv_mlp_b4_nz8", "mlp", 1, True), ("resconv_mlp2_nocenter_b4_nz8", "mlp", 2, False), ("resconv_res2_b4_nz8", "res-mlp", 1, False),
@@ -194,7 +197,8 @@ def test_oracle_iwae_matches_reference_fixture_auxconv(golden_dir):
 
 @pytest.mark.parametrize("name,mc", [("iwae_resconv", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu")),
                                      ("iwae_resconv_mlp", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", enc_type="mlp")),
-                                     ("iwae_auxresconv", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu"))])
+                                     ("iwae_auxresconv", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu")),
+                                     ("iwae_auxresconv_clip", O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", clipped=True))])
 def test_oracle_iwae_matches_reference_fixture_resconv(golden_dir, name, mc):
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     pm = O.init_params(O.model_param_spec(mc), int(fx["meta_pseed"]), O.model_init_special(mc), torch.float64)
