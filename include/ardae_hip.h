@@ -226,7 +226,12 @@ int ardae_cdae_score(const ardae_cdae_desc* d, const float* params, const float*
  *   kind 6 (MNISTResConvAuxIPVAE, models/ivae/auxresconv.py, `--model auxresconvct`): the same trunk as encode.inp_encode.enc.*
  *                        (c_dim = h_dim, 450 in the recipe), encode.aux_encode.reparam.{mean_fn,logvar_fn}, encode.encode.fc.0,
  *                        encode.encode.reparam.{mean_fn,logvar_fn} (log-variances clipped 'spm4'), the same decoder; noise_dim = z0_dim,
- *                        noise layout of kind 3; its hidden1a context is h [B, h_dim] */
+ *                        noise layout of kind 3; its hidden1a context is h [B, h_dim]
+ *   kind 7 (ToyAuxIPVAE, models/ivae/auxtoy.py; `--model auxmlp`): kind 3's networks WITHOUT the 2x - 1 rescale, the Gaussian decoder of
+ *                        kind 1 (decode.main.*, decode.reparam.{mean_fn, logvar_fn}), and a SQUARE sampling scheme: a call with nz rows per
+ *                        image (nz = q^2, else refused) draws q z0's per image and q z's per z0 (auxtoy.py:215,230: `_nz = int(sqrt(nz))`);
+ *                        noise of such a call = [eps0: B q x noise_dim | eps: B q q x z_dim], two consecutive blocks; hidden1a context
+ *                        cat(h0, h) [B, 2 h_dim] */
 typedef struct ardae_model_desc {
   int kind;
   int input_dim, noise_dim, h_dim, z_dim;

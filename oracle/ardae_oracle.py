@@ -41,7 +41,7 @@ import torch
 import torch.nn.functional as F
 
 LOG2PI = math.log(2.0 * math.pi)
-AUX_KINDS = ("auxmnist", "auxconv", "auxresconv")     # hierarchical samplers: two draws per call
+AUX_KINDS = ("auxmnist", "auxconv", "auxresconv", "auxtoy")     # hierarchical samplers: two draws per call
 
 
 # --------------------------------------------------------------------------- #
@@ -140,6 +140,19 @@ def model_param_spec(c: ModelCfg):
         s += [("decode.deconv1.weight", (32, 32, 5, 5)), ("decode.deconv1.bias", (32,)),
               ("decode.deconv2.weight", (32, 16, 5, 5)), ("decode.deconv2.bias", (16,)),
               ("decode.reparam.logit_fn.weight", (16, 1, 5, 5)), ("decode.reparam.logit_fn.bias", (1,))]
+        return s
+    if c.kind == "auxtoy":
+        # models/ivae/auxtoy.py:44-130 (Encoder = AuxEncoder + SimpleEncoder of models/vae/auxtoy.py, the auxmnist networks without the 2x - 1
+        # rescale) + models/vae/toy.py Decoder (Gaussian: mean_fn / logvar_fn)
+        s = _mlp_spec("encode.aux_encode.main.", c.input_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += [("encode.aux_encode.reparam.mean_fn.weight", (c.noise_dim, c.h_dim)), ("encode.aux_encode.reparam.mean_fn.bias", (c.noise_dim,)),
+              ("encode.aux_encode.reparam.logvar_fn.weight", (c.noise_dim, c.h_dim)), ("encode.aux_encode.reparam.logvar_fn.bias", (c.noise_dim,))]
+        s += _mlp_spec("encode.encode.fc.", c.input_dim + c.noise_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += [("encode.encode.reparam.mean_fn.weight", (c.z_dim, c.h_dim)), ("encode.encode.reparam.mean_fn.bias", (c.z_dim,)),
+              ("encode.encode.reparam.logvar_fn.weight", (c.z_dim, c.h_dim)), ("encode.encode.reparam.logvar_fn.bias", (c.z_dim,))]
+        s += _mlp_spec("decode.main.", c.z_dim, c.h_dim, c.h_dim, c.n_layers - 1)
+        s += [("decode.reparam.mean_fn.weight", (c.input_dim, c.h_dim)), ("decode.reparam.mean_fn.bias", (c.input_dim,)),
+              ("decode.reparam.logvar_fn.weight", (c.input_dim, c.h_dim)), ("decode.reparam.logvar_fn.bias", (c.input_dim,))]
         return s
     if c.kind == "auxmnist":
         # models/ivae/auxmnist.py:47-132 (Encoder = AuxEncoder + SimpleEncoder of models/vae/auxmnist.py:31-190, enc_input = enc_noise
@@ -277,6 +290,8 @@ def model_init_special(c: ModelCfg):
         return sp
     if c.kind in ("resconv", "auxresconv"):   # no init override (the WN operators' and nn.Linear's own reset_parameters)
         return {}
+    if c.kind == "auxtoy":     # init='gaussian' reaches the toy Decoder only (ivae/auxtoy.py:165, models/vae/toy.py)
+        return {"decode.reparam.mean_fn.weight": ("normal",)}
     if c.kind == "auxmnist":   # do_xavier=True: self.apply(weight_init) on the whole model (ivae/auxmnist.py:172-174)
         return {name: (("xavier",) if name.endswith("weight") else ("zeros",)) for name, _ in spec}
     for name, _ in spec:
@@ -488,6 +503,10 @@ def encode(c: ModelCfg, p, x, noise, nz):
         z = ctxcat_mlp(p, "encode.fc.", expand_rows(inp, nz), noise, c.n_layers, c.nonlin)
     elif c.kind in ("auxmnist", "auxconv"):
         z = aux_encode(c, p, x, noise, nz)["z"]
+    elif c.kind == "auxtoy":      # the model-level entry points take nz = q^2 (ivae/auxtoy.py:215,230)
+        q = math.isqrt(nz)
+        assert q * q == nz, "ToyAuxIPVAE samples q z0's x q z's per image: nz must be a square"
+        z = aux_encode(c, p, x, noise, q)["z"]
     elif c.kind == "resconv":      # ivae/resconv.py:141-159
         inp = resconv_trunk(c, p, x)
         z = resconv_head(c, p, torch.cat([expand_rows(inp, nz), noise], 1))
@@ -523,6 +542,21 @@ def aux_encode(c: ModelCfg, p, x, noise, nz):
         h = f(F.linear(torch.cat([expand_rows(h3, nz), z0], 1), p["encode.encode.fc.weight"], p["encode.encode.fc.bias"]))
         mu, lv = heads("encode.encode.", h)
         z = mu + torch.exp(0.5 * lv) * eps
+        return {"z": z, "h0": h0, "h": h, "z0": z0, "mu0": mu0, "lv0": lv0, "mu": mu, "lv": lv}
+    if c.kind == "auxtoy":
+        # ToyAuxIPVAE (ivae/auxtoy.py:74-103): NO rescale of x, and a SQUARE sampling scheme - `nz` here is Encoder._forward's nz = q:
+        # q z0's per image (eps0 [B q, noise_dim]) and q z's per z0 (eps [B q q, z_dim]); the model-level calls pass q = int(sqrt(nz))
+        # (:215,230), logprob passes q = sample_size (:313).  Returns z [B q q, z]; h0 [B, h], h / mu / lv [B q, .]
+        q = nz
+        xs = x.reshape(B, c.input_dim)
+        h0 = mlp(p, "encode.aux_encode.main.", xs, c.n_layers - 1, c.nonlin, True)
+        mu0 = F.linear(h0, p["encode.aux_encode.reparam.mean_fn.weight"], p["encode.aux_encode.reparam.mean_fn.bias"])
+        lv0 = F.linear(h0, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"])
+        z0 = expand_rows(mu0, q) + torch.exp(0.5 * expand_rows(lv0, q)) * eps0
+        h = mlp(p, "encode.encode.fc.", torch.cat([expand_rows(xs, q), z0], 1), c.n_layers - 1, c.nonlin, True)
+        mu = F.linear(h, p["encode.encode.reparam.mean_fn.weight"], p["encode.encode.reparam.mean_fn.bias"])
+        lv = F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"])
+        z = expand_rows(mu, q) + torch.exp(0.5 * expand_rows(lv, q)) * eps
         return {"z": z, "h0": h0, "h": h, "z0": z0, "mu0": mu0, "lv0": lv0, "mu": mu, "lv": lv}
     xs = 2 * x.reshape(B, c.input_dim) - 1
     h0 = mlp(p, "encode.aux_encode.main.", xs, c.n_layers - 1, c.nonlin, True)
@@ -722,7 +756,8 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
     (they only advance the reference's RNG stream)."""
     N = B * tc.nz_cdae
     aux = mc.kind in AUX_KINDS       # a second draw per sampler call: eps of z = mu + exp(lv/2) eps (ivae/auxmnist.py:113-114)
-    n = {"sampler": torch.randn(N, mc.noise_dim, generator=gen)}          # forward_hidden
+    sq = (lambda rows_per_image: math.isqrt(rows_per_image)) if mc.kind == "auxtoy" else (lambda rows_per_image: rows_per_image)   # eps0 rows per image
+    n = {"sampler": torch.randn(B * sq(tc.nz_cdae), mc.noise_dim, generator=gen)}          # forward_hidden
     if aux:
         n["sampler_z"] = torch.randn(N, mc.z_dim, generator=gen)
     if aux and mc.clipped:       # the two std = 0 calls that open the cDAE update keep an unscaled eps0 each (ivae/auxresconv2.py:91)
@@ -730,7 +765,7 @@ def draw_step_noise(mc: ModelCfg, tc: TrainCfg, B, gen):
         n["z0_raw"] = torch.randn(B, mc.noise_dim, generator=gen)
     n["sigma"] = torch.randn(B, tc.nz_cdae * tc.nstd, 1, generator=gen)   # stdmat
     n["eps"] = torch.randn(N * tc.nstd, mc.z_dim, generator=gen)          # add_gaussian_noise
-    n["vae"] = torch.randn(B * tc.nz_model, mc.noise_dim, generator=gen)
+    n["vae"] = torch.randn(B * sq(tc.nz_model), mc.noise_dim, generator=gen)
     if aux:
         n["vae_z"] = torch.randn(B * tc.nz_model, mc.z_dim, generator=gen)
     if aux and mc.clipped:
@@ -817,14 +852,19 @@ def iwae_logprob(mc: ModelCfg, pm, x, sample_size, enc_noise, prop_noise):
     B = x.size(0)
     x = x.reshape(B, mc.input_dim)
     with torch.no_grad():
-        if mc.kind in AUX_KINDS:      # enc_noise = (eps0 [B,k,noise_dim], eps [B,k,z]); ivae/auxmnist.py:306-326
-            noise = (enc_noise[0].reshape(B * sample_size, mc.noise_dim), enc_noise[1].reshape(B * sample_size, mc.z_dim))
+        if mc.kind == "auxtoy":       # Encoder._forward(nz = sample_size) (ivae/auxtoy.py:313): k z0's x k z's = k^2 encoder samples per image fit
+            # the proposal; enc_noise = (eps0 [B, k, noise_dim], eps [B, k k, z])
+            noise = (enc_noise[0].reshape(B * sample_size, mc.noise_dim), enc_noise[1].reshape(B * sample_size * sample_size, mc.z_dim))
+            z = aux_encode(mc, pm, x, noise, sample_size)["z"].view(B, sample_size * sample_size, mc.z_dim)
         else:
-            noise = enc_noise.reshape(B * sample_size, mc.noise_dim)
-        z = encode(mc, pm, x, noise, sample_size)   # [B,k,z]
+            if mc.kind in AUX_KINDS:      # enc_noise = (eps0 [B,k,noise_dim], eps [B,k,z]); ivae/auxmnist.py:306-326
+                noise = (enc_noise[0].reshape(B * sample_size, mc.noise_dim), enc_noise[1].reshape(B * sample_size, mc.z_dim))
+            else:
+                noise = enc_noise.reshape(B * sample_size, mc.noise_dim)
+            z = encode(mc, pm, x, noise, sample_size)   # [B,k,z]
         mu = z.mean(1)
         zc = z - mu.unsqueeze(1)
-        cov = zc.transpose(1, 2) @ zc / (sample_size - 1)
+        cov = zc.transpose(1, 2) @ zc / (z.size(1) - 1)
         if mc.kind in AUX_KINDS:
             cov = cov + 1e-5 * torch.eye(mc.z_dim, dtype=cov.dtype)      # ivae/auxmnist.py:321, ivae/auxresconv.py:299
         Lc = torch.linalg.cholesky(cov)

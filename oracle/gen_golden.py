@@ -71,6 +71,9 @@ def build_reference(net, mc, cc, pm, pc, dtype):
     elif mc.kind == "auxresconv":   # ivae_ardae.py:493-505 (--model auxresconvct); :507-534 (--model auxresconv-clip / auxresconvct-clip)
         model = (net.MNISTResConvAuxIPVAEClipped if mc.clipped else net.MNISTResConvAuxIPVAE)(input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim,
                                          nonlinearity=mc.nonlin, do_center=mc.do_center)
+    elif mc.kind == "auxtoy":   # ivae_ardae.py:443-454 (--model auxmlp) with --model-clip-z0-logvar / --model-clip-z-logvar none
+        model = net.ToyAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
+                                nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
     elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
                                num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
@@ -156,6 +159,12 @@ def replay_noise(mc, tc, B_c, B_v, seed, dtype):
         # it runs then draw samples nobody uses (AuxEncoder.forward: randn_like [B, noise_dim], vae/auxmnist.py:66;
         # SimpleEncoder._forward_all: randn_like [R, z], :189)
         def fwd(B, nz):
+            if mc.kind == "auxtoy":     # the model-level calls pass q = int(sqrt(nz)) to Encoder._forward (ivae/auxtoy.py:215,230): q z0's x q z's
+                q = math.isqrt(nz)
+                e0 = torch.randn(B * q, mc.noise_dim)
+                e = torch.randn(B * q, q, mc.z_dim)
+                torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * q, mc.z_dim, dtype=dtype)
+                return e0, e.reshape(B * q * q, mc.z_dim)
             e0 = torch.randn(B * nz, mc.noise_dim)
             e = torch.randn(B * nz, 1, mc.z_dim)
             torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * nz, mc.z_dim, dtype=dtype)   # randn_like(std): the model's dtype
@@ -290,7 +299,7 @@ def run_case(net, rutils, name, mc, cc, tc, B, steps, dtype, store_full, pseed=0
 def run_iwae_case(net, name, mc, B, k, dtype, store_params=True):
     """models/ivae/mnist.py:378-437 with the per-image draws captured by replaying the seed."""
     pm = O.init_params(O.model_param_spec(mc), 7, O.model_init_special(mc), dtype)
-    cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=2 * mc.h_dim if mc.kind in ("auxmnist", "auxconv") else mc.z_dim, h_dim=32, n_layers=2)
+    cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=2 * mc.h_dim if mc.kind in ("auxmnist", "auxconv", "auxtoy") else mc.z_dim, h_dim=32, n_layers=2)
     if mc.kind == "auxresconv":
         cc = O.CdaeCfg(input_dim=mc.z_dim, context_dim=mc.h_dim, h_dim=32, n_layers=2)
     pc = O.init_params(O.cdae_param_spec(cc), 8, None, dtype)
@@ -301,7 +310,12 @@ def run_iwae_case(net, name, mc, B, k, dtype, store_params=True):
     with torch.no_grad():
         ref = model.logprob(x, sample_size=k)
     torch.manual_seed(99)
-    if mc.kind in O.AUX_KINDS:   # ONE Encoder._forward(nz=k) call for all images (ivae/auxmnist.py:314), then the per-image proposals
+    if mc.kind == "auxtoy":      # Encoder._forward(nz = k): k z0's x k z's per image (ivae/auxtoy.py:313)
+        e0 = torch.randn(B * k, mc.noise_dim)
+        e = torch.randn(B * k, k, mc.z_dim)
+        torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * k, mc.z_dim, dtype=dtype)
+        enc = (e0.to(dtype).reshape(B, k, -1), e.to(dtype).reshape(B, k * k, -1))
+    elif mc.kind in O.AUX_KINDS:   # ONE Encoder._forward(nz=k) call for all images (ivae/auxmnist.py:314), then the per-image proposals
         e0 = torch.randn(B * k, mc.noise_dim)
         e = torch.randn(B * k, 1, mc.z_dim)
         torch.randn(B, mc.noise_dim, dtype=dtype); torch.randn(B * k, mc.z_dim, dtype=dtype)     # the two unused reparam samples
@@ -496,6 +510,14 @@ def main():
     run_iwae_case(net, "iwae_resconv_mlp", O.ModelCfg("resconv", 784, 100, 512, 32, 1, "elu", enc_type="mlp"), B=2, k=64, dtype=f64, store_params=False)
     run_iwae_case(net, "iwae_resconv", res_m, B=2, k=64, dtype=f64, store_params=False)
     run_iwae_case(net, "iwae_auxresconv", ares_m, B=2, k=64, dtype=f64, store_params=False)
+    # --model auxmlp (ivae_ardae.py:443-454): ToyAuxIPVAE - the toy problem's hierarchical sampler, q z0's x q z's per image (nz_cdae = q^2),
+    # Gaussian decoder, tanh, --cdae-ctx-type hidden1a
+    atoy_m = O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh")
+    atoy_c = O.CdaeCfg("grad", input_dim=2, context_dim=64, h_dim=64, n_layers=3, nonlin="softplus")
+    atoy_t = O.TrainCfg(nz_cdae=16, ctx_type="hidden1a")
+    run_case(net, rutils, "tiny_auxtoy_grad_f64", atoy_m, atoy_c, atoy_t, B=4, steps=1, dtype=f64, store_full=True)
+    run_case(net, rutils, "tiny_auxtoy_grad", atoy_m, atoy_c, atoy_t, B=4, steps=3, dtype=f32, store_full=True)
+    run_iwae_case(net, "iwae_tiny_auxtoy", atoy_m, B=3, k=8, dtype=f64)
     # --model auxresconv-clip / auxresconvct-clip (ivae_ardae.py:507-534): MNISTResConvAuxIPVAEClipped - unclipped log-variances, z0 keeps an
     # unscaled eps0 (min_std = 1), so the std = 0 calls of the loop are random draws and their eps0 are part of the fixture's noise
     clip_m = O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", clipped=True)

@@ -12,7 +12,7 @@ int aux_model_pack(const ardae_model_desc& d, const float* params, float* packed
 int aux_model_encode(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,
                      float* workspace, size_t wsf, float* z_out, float* hidden_out, hipStream_t st);
 int aux_model_decode(const ardae_model_desc& d, const float* params, const float* packed, const float* z, int R, float* workspace, size_t wsf,
-                     float* out0, hipStream_t st);
+                     float* out0, hipStream_t st, float* out1 = nullptr);
 int aux_model_vae_forward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,
                           float beta, float* workspace, size_t wsf, float* z_out, float* losses, hipStream_t st);
 int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,

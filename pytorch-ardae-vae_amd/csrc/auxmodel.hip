@@ -9,6 +9,11 @@
 //   (the first encoder layer eats cat[xs, z0]: its image half is computed once per image and enters as a row bias - the
 //    reference expands xs to R rows, vae/auxmnist.py:138-141)
 // Noise layout of this kind: ONE [R, noise_dim + z_dim] tensor per sampler call, row = [eps0 | eps] (already scaled by std).
+//
+// kind 7, ToyAuxIPVAE (`--model auxmlp`, models/ivae/auxtoy.py:44-292 + models/vae/auxtoy.py + the Gaussian Decoder of models/vae/toy.py): the same
+// networks WITHOUT the 2x - 1 rescale, a decoder with mean_fn / logvar_fn heads, and a SQUARE sampling scheme: the model-level calls take nz = q^2
+// rows per image and run Encoder._forward with q = int(sqrt(nz)) (:215,230) - q z0's per image, the second stage on R = B q rows, q z's per
+// z0: z [B q q, z] = mu[R][.] + exp(lv[R][.] / 2) eps.  Noise layout of kind 7: [eps0: R x noise_dim | eps: R q x z_dim], two blocks.
 // Backward (closed form of the two reparameterisations):  dmu = dz, dlv = dz (z - mu) / 2;  dz0 = dt_1 Wz;
 //   dmu0[b] = sum_nz dz0, dlv0[b] = sum_nz dz0 (z0 - mu0[b]) / 2.
 #include <vector>
@@ -30,10 +35,19 @@ struct Lin {
 
 struct AuxLayout {
   int D, nd, h, zd, nl, act;
+  bool toy;                       // kind 7
   std::vector<Lin> am, ef, dec;   // aux_encode.main, encode.fc, decode.main: nl Linear each (nl - 1 hidden + fc, all followed by act)
-  Lin mean0, logvar0, mean, logvar, logit;
+  Lin mean0, logvar0, mean, logvar, logit, logvarx;   // logit: decode.reparam.logit_fn, or (toy) mean_fn followed by logvarx = logvar_fn
   size_t total = 0;
-  explicit AuxLayout(const ardae_model_desc& d) : D(d.input_dim), nd(d.noise_dim), h(d.h_dim), zd(d.z_dim), nl(d.n_layers), act(d.act) {
+  // stage rows per image of a call with nz rows per image: nz, or (toy) q = sqrt(nz)
+  int stage(int nz) const {
+    if (!toy) return nz;
+    int q = 1;
+    while ((q + 1) * (q + 1) <= nz) ++q;
+    return q;
+  }
+  explicit AuxLayout(const ardae_model_desc& d)
+      : D(d.input_dim), nd(d.noise_dim), h(d.h_dim), zd(d.z_dim), nl(d.n_layers), act(d.act), toy(d.kind == 7) {
     size_t off = 0;
     auto one = [&](int out, int in) {
       Lin l; l.out = out; l.in = in; l.w = off; off += (size_t)out * in; l.b = off; off += out;
@@ -45,13 +59,14 @@ struct AuxLayout {
     mean = one(zd, h); logvar = one(zd, h);
     for (int l = 0; l < nl; ++l) dec.push_back(one(h, l == 0 ? zd : h));
     logit = one(D, h);
+    if (toy) logvarx = one(D, h);
     total = off;
   }
 };
 
 struct AuxPacked {
   std::vector<size_t> am_f, am_b, ef_f, ef_b, dec_f, dec_b;   // ef_f[0] / ef_b[0]: the z0 half of the first encoder layer
-  size_t efx_f, mean0_f, mean0_b, logvar0_f, logvar0_b, mean_f, mean_b, logvar_f, logvar_b, logit_f, logit_b;
+  size_t efx_f, mean0_f, mean0_b, logvar0_f, logvar0_b, mean_f, mean_b, logvar_f, logvar_b, logit_f, logit_b, logvarx_f = 0, logvarx_b = 0;
   size_t total = 0;
   explicit AuxPacked(const AuxLayout& P) {
     size_t off = 0;
@@ -68,6 +83,7 @@ struct AuxPacked {
     logvar_f = take(packed_floats(P.zd, P.h)); logvar_b = take(packed_floats(P.h, P.zd));
     for (auto& l : P.dec) { dec_f.push_back(take(packed_floats(l.out, l.in))); dec_b.push_back(take(packed_floats(l.in, l.out))); }
     logit_f = take(packed_floats(P.D, P.h)); logit_b = take(packed_floats(P.h, P.D));
+    if (P.toy) { logvarx_f = take(packed_floats(P.D, P.h)); logvarx_b = take(packed_floats(P.h, P.D)); }
     total = off;
   }
 };
@@ -86,15 +102,17 @@ size_t al64(size_t n) { return (n + 63) & ~size_t(63); }
 struct AuxWs {
   float *xs, *mu0, *lv0, *rb, *z0, *mu, *lv, *z, *zero;
   std::vector<float*> e, t, dcd;        // e[l] [B,h] (l = 1..nl), t[i] [R,h], dcd[l] [R,h]
-  float *o, *rec_row, *pri_row;         // decoder logits and row losses
+  float *o, *o2, *rec_row, *pri_row;    // decoder logits (toy: mean, o2 = logvar) and row losses
   // backward
-  float *dox, *dzq, *dz, *dlv, *dz0, *dlv0r, *drb, *dmu0, *dlv0;
+  float *dox, *dox2, *dzq, *dz, *dlv, *dz0, *dlv0r, *drb, *dmu0, *dlv0;
+  float *dmu_s, *dlv_s;                 // toy: dz / dlv summed over the q z's of a stage row, [R, zd]
   std::vector<float*> ddec, dt, de;
 };
 
-int wgrad_nprob(const AuxLayout& P) { return 1 + P.nl + 2 + P.nl + 1 + 2 + P.nl; }
+int wgrad_nprob(const AuxLayout& P) { return 1 + (P.toy ? 1 : 0) + P.nl + 2 + P.nl + 1 + 2 + P.nl; }
 
-size_t wgrad_scratch(const AuxLayout& P, int B, int R, std::vector<int>* splits_out) {
+// R: stage rows (B nz, toy: B q); N: z / decoder rows (= R, toy: R q)
+size_t wgrad_scratch(const AuxLayout& P, int B, int R, int N, std::vector<int>* splits_out) {
   // problem order must match aux_model_vae_backward
   std::vector<int> sp;
   size_t tot = 0;
@@ -104,8 +122,9 @@ size_t wgrad_scratch(const AuxLayout& P, int B, int R, std::vector<int>* splits_
     sp.push_back(s);
     tot += al64((size_t)s * O * I) + al64((size_t)s * 2 * O);
   };
-  one(R, P.D, P.h);                                                  // logit head
-  for (int l = 0; l < P.nl; ++l) one(R, P.h, l == 0 ? P.zd : P.h);   // decoder
+  one(N, P.D, P.h);                                                  // logit head (toy: mean head)
+  if (P.toy) one(N, P.D, P.h);                                       // toy: logvar head
+  for (int l = 0; l < P.nl; ++l) one(N, P.h, l == 0 ? P.zd : P.h);   // decoder
   one(R, P.zd, P.h); one(R, P.zd, P.h);                              // mean, logvar
   for (int l = P.nl - 1; l >= 1; --l) one(R, P.h, P.h);              // encoder layers 2..n
   one(R, P.h, P.nd);                                                 // first encoder layer, z0 half (+ bias)
@@ -118,7 +137,7 @@ size_t wgrad_scratch(const AuxLayout& P, int B, int R, std::vector<int>* splits_
 
 // mode 0: sampler only; 1: + decoder, losses, backward, weight gradients
 void carve(const AuxLayout& P, Bump& ws, int B, int nz, int mode, AuxWs& W) {
-  const size_t R = (size_t)B * nz, h = P.h;
+  const size_t R = (size_t)B * P.stage(nz), N = (size_t)B * nz, h = P.h;
   W.xs = ws.take((size_t)B * P.D);
   W.e.assign(P.nl + 1, nullptr);
   for (int l = 1; l <= P.nl; ++l) W.e[l] = ws.take((size_t)B * h);
@@ -126,17 +145,19 @@ void carve(const AuxLayout& P, Bump& ws, int B, int nz, int mode, AuxWs& W) {
   W.z0 = ws.take(R * P.nd);
   W.t.assign(P.nl + 1, nullptr);
   for (int l = 1; l <= P.nl; ++l) W.t[l] = ws.take(R * h);
-  W.mu = ws.take(R * P.zd); W.lv = ws.take(R * P.zd); W.z = ws.take(R * P.zd);
-  W.zero = ws.take(R * (P.nd + P.zd));
+  W.mu = ws.take(R * P.zd); W.lv = ws.take(R * P.zd); W.z = ws.take(N * P.zd);
+  W.zero = ws.take(R * P.nd + N * P.zd);
   if (mode == 0) return;
   W.dcd.assign(P.nl + 1, nullptr);
-  for (int l = 1; l <= P.nl; ++l) W.dcd[l] = ws.take(R * h);
-  W.o = ws.take(R * P.D); W.rec_row = ws.take(R); W.pri_row = ws.take(R);
-  W.dox = ws.take(R * P.D); W.dzq = ws.take(R * P.zd); W.dz = ws.take(R * P.zd); W.dlv = ws.take(R * P.zd);
+  for (int l = 1; l <= P.nl; ++l) W.dcd[l] = ws.take(N * h);
+  W.o = ws.take(N * P.D); W.o2 = P.toy ? ws.take(N * P.D) : nullptr; W.rec_row = ws.take(N); W.pri_row = ws.take(N);
+  W.dox = ws.take(N * P.D); W.dox2 = P.toy ? ws.take(N * P.D) : nullptr;
+  W.dzq = ws.take(N * P.zd); W.dz = ws.take(N * P.zd); W.dlv = ws.take(N * P.zd);
+  W.dmu_s = P.toy ? ws.take(R * P.zd) : nullptr; W.dlv_s = P.toy ? ws.take(R * P.zd) : nullptr;
   W.dz0 = ws.take(R * P.nd); W.dlv0r = ws.take(R * P.nd);
   W.drb = ws.take((size_t)B * h); W.dmu0 = ws.take((size_t)B * P.nd); W.dlv0 = ws.take((size_t)B * P.nd);
   W.ddec.assign(P.nl + 1, nullptr); W.dt.assign(P.nl + 1, nullptr); W.de.assign(P.nl + 1, nullptr);
-  for (int l = 1; l <= P.nl; ++l) { W.ddec[l] = ws.take(R * h); W.dt[l] = ws.take(R * h); W.de[l] = ws.take((size_t)B * h); }
+  for (int l = 1; l <= P.nl; ++l) { W.ddec[l] = ws.take(N * h); W.dt[l] = ws.take(R * h); W.de[l] = ws.take((size_t)B * h); }
 }
 
 size_t workspace_floats(const AuxLayout& P, int B, int nz, int mode) {
@@ -145,7 +166,7 @@ size_t workspace_floats(const AuxLayout& P, int B, int nz, int mode) {
   AuxWs W;
   carve(P, ws, B, nz, mode == 0 ? 0 : 1, W);
   size_t t = ws.off;
-  if (mode != 0) t += wgrad_scratch(P, B, B * nz, nullptr);
+  if (mode != 0) t += wgrad_scratch(P, B, B * P.stage(nz), B * nz, nullptr);
   return t;
 }
 
@@ -201,10 +222,15 @@ int lin1(int epi, int act, int M, int Nout, const float* x, int ldx, int K, cons
 }
 
 // the sampler on R = B nz rows; noise [R, nd + zd] (never null here); fills every forward field of W
+// (toy: R = B q stage rows, z on B q q rows; noise = [eps0: R x nd | eps: R q x zd])
 int sampler_fwd(const AuxLayout& P, const AuxPacked& K, const float* params, const float* packed, const float* x, const float* noise, int B,
-                int nz, AuxWs& W, hipStream_t st) {
-  const int R = B * nz, h = P.h, act = P.act, nl = P.nl, ldn = P.nd + P.zd;
-  ARDAE_TRY(launch_affine(x, (int64_t)B * P.D, 2.f, -1.f, W.xs, st));
+                int nz_rows, AuxWs& W, hipStream_t st) {
+  const int nz = P.stage(nz_rows);               // samples per image at the stage level
+  const int R = B * nz, h = P.h, act = P.act, nl = P.nl;
+  const int ld0 = P.toy ? P.nd : P.nd + P.zd, lde = P.toy ? P.zd : P.nd + P.zd;
+  const float* eps = P.toy ? noise + (size_t)R * P.nd : noise + P.nd;
+  if (P.toy) ARDAE_TRY(launch_copy(x, (int64_t)B * P.D, W.xs, st));      // no rescale (models/vae/auxtoy.py: the `x = 2*x - 1` lines are gone)
+  else ARDAE_TRY(launch_affine(x, (int64_t)B * P.D, 2.f, -1.f, W.xs, st));
   for (int l = 1; l <= nl; ++l) {
     LinArgs A{}; A.bias = params + P.am[l - 1].b; A.Y = W.e[l]; A.ldY = h;
     ARDAE_TRY(lin1(EPI_ACT, act, B, h, l == 1 ? W.xs : W.e[l - 1], l == 1 ? P.D : h, P.am[l - 1].in, packed + K.am_f[l - 1], A, st));
@@ -217,7 +243,7 @@ int sampler_fwd(const AuxLayout& P, const AuxPacked& K, const float* params, con
     LinArgs A3{}; A3.bias = params + P.ef[0].b; A3.Y = W.rb; A3.ldY = h;   // image half of the first encoder layer (+ its bias)
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, h, W.xs, P.D, P.D, packed + K.efx_f, A3, st));
   }
-  ARDAE_TRY(launch_reparam_fwd(W.mu0, W.lv0, noise, ldn, R, P.nd, nz, W.z0, st));
+  ARDAE_TRY(launch_reparam_fwd(W.mu0, W.lv0, noise, ld0, R, P.nd, nz, W.z0, st));
   for (int l = 1; l <= nl; ++l) {
     LinArgs A{}; A.Y = W.t[l]; A.ldY = h;
     if (l == 1) { A.rowbias = W.rb; A.rowbias_ld = h; A.rows_per_group = nz; }
@@ -230,13 +256,15 @@ int sampler_fwd(const AuxLayout& P, const AuxPacked& K, const float* params, con
     LinArgs A2{}; A2.bias = params + P.logvar.b; A2.Y = W.lv; A2.ldY = P.zd;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.t[nl], h, h, packed + K.logvar_f, A2, st));
   }
-  return launch_reparam_fwd(W.mu, W.lv, noise + P.nd, ldn, R, P.zd, 1, W.z, st);
+  if (P.toy) return launch_reparam_fwd(W.mu, W.lv, eps, lde, (int64_t)R * nz, P.zd, nz, W.z, st);      // q z's per stage row
+  return launch_reparam_fwd(W.mu, W.lv, eps, lde, R, P.zd, 1, W.z, st);
 }
 
-const float* noise_or_zero(const AuxLayout& P, const float* noise, int R, AuxWs& W, hipStream_t st, int& rc) {
+// noise of a call with nz rows per image, or the zero block of a std = 0 pass
+const float* noise_or_zero(const AuxLayout& P, const float* noise, int B, int nz, AuxWs& W, hipStream_t st, int& rc) {
   rc = 0;
   if (noise) return noise;
-  if (rc == 0) rc = launch_fill(W.zero, (size_t)R * (P.nd + P.zd), 0.f, st);
+  if (rc == 0) rc = launch_fill(W.zero, (size_t)B * P.stage(nz) * P.nd + (size_t)B * nz * P.zd, 0.f, st);
   return W.zero;
 }
 
@@ -268,6 +296,7 @@ int aux_model_pack(const ardae_model_desc& d, const float* params, float* packed
   both(P.mean, K.mean_f, K.mean_b); both(P.logvar, K.logvar_f, K.logvar_b);
   for (int l = 0; l < P.nl; ++l) both(P.dec[l], K.dec_f[l], K.dec_b[l]);
   both(P.logit, K.logit_f, K.logit_b);
+  if (P.toy) both(P.logvarx, K.logvarx_f, K.logvarx_b);
   return launch_pack_batch(pack_items__.data(), (int)pack_items__.size(), st);
 }
 
@@ -280,7 +309,8 @@ int aux_model_encode(const ardae_model_desc& d, const float* params, const float
   carve(P, ws, B, nz, 0, W);
   ARDAE_CHECK_ARG(ws.ok, "aux_model_encode: workspace too small");
   int rc;
-  const float* nz_ptr = noise_or_zero(P, noise, B * nz, W, st, rc);
+  ARDAE_CHECK_ARG(!P.toy || P.stage(nz) * P.stage(nz) == nz, "aux_model_encode: ToyAuxIPVAE draws q z0's x q z's per image - nz (%d) must be a square", nz);
+  const float* nz_ptr = noise_or_zero(P, noise, B, nz, W, st, rc);
   ARDAE_TRY(rc);
   ARDAE_TRY(sampler_fwd(P, K, params, packed, x, nz_ptr, B, nz, W, st));
   if (z_out) ARDAE_TRY(launch_copy(W.z, (size_t)B * nz * P.zd, z_out, st));
@@ -293,7 +323,7 @@ int aux_model_encode(const ardae_model_desc& d, const float* params, const float
 }
 
 int aux_model_decode(const ardae_model_desc& d, const float* params, const float* packed, const float* z, int R, float* workspace, size_t wsf,
-                     float* out0, hipStream_t st) {
+                     float* out0, hipStream_t st, float* out1) {
   const AuxLayout P(d);
   const AuxPacked K(P);
   Bump ws(workspace, wsf);
@@ -306,7 +336,13 @@ int aux_model_decode(const ardae_model_desc& d, const float* params, const float
   }
   ARDAE_CHECK_ARG(ws.ok, "aux_model_decode: workspace too small");
   LinArgs A{}; A.bias = params + P.logit.b; A.Y = out0; A.ldY = P.D;
-  return lin1(EPI_ACT, ACT_NONE, R, P.D, cur, P.h, P.h, packed + K.logit_f, A, st);
+  ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.D, cur, P.h, P.h, packed + K.logit_f, A, st));
+  if (P.toy) {
+    ARDAE_CHECK_ARG(out1, "aux_model_decode: the Gaussian decoder returns mean (out0) and logvar (out1)");
+    LinArgs A2{}; A2.bias = params + P.logvarx.b; A2.Y = out1; A2.ldY = P.D;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.D, cur, P.h, P.h, packed + K.logvarx_f, A2, st));
+  }
+  return 0;
 }
 
 int aux_model_vae_forward(const ardae_model_desc& d, const float* params, const float* packed, const float* x, const float* noise, int B, int nz,
@@ -317,7 +353,8 @@ int aux_model_vae_forward(const ardae_model_desc& d, const float* params, const 
   AuxWs W;
   carve(P, ws, B, nz, 1, W);
   ARDAE_CHECK_ARG(ws.ok, "aux_model_vae_forward: workspace too small");
-  const int R = B * nz, h = P.h;
+  ARDAE_CHECK_ARG(!P.toy || P.stage(nz) * P.stage(nz) == nz, "aux_model_vae_forward: ToyAuxIPVAE needs a square nz (got %d)", nz);
+  const int R = B * nz, h = P.h;      // z / decoder rows
   ARDAE_TRY(sampler_fwd(P, K, params, packed, x, noise, B, nz, W, st));
   ARDAE_TRY(launch_copy(W.z, (size_t)R * P.zd, z_out, st));
   for (int l = 1; l <= P.nl; ++l) {
@@ -328,7 +365,11 @@ int aux_model_vae_forward(const ardae_model_desc& d, const float* params, const 
     LinArgs A{}; A.bias = params + P.logit.b; A.Y = W.o; A.ldY = P.D;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.D, W.dcd[P.nl], h, h, packed + K.logit_f, A, st));
   }
-  ARDAE_TRY(launch_vae_loss(0, W.o, nullptr, x, W.z, R, nz, P.D, P.zd, beta, 0, 0.f, nullptr, W.rec_row, W.pri_row, nullptr, nullptr, nullptr, st));
+  if (P.toy) {
+    LinArgs A{}; A.bias = params + P.logvarx.b; A.Y = W.o2; A.ldY = P.D;
+    ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.D, W.dcd[P.nl], h, h, packed + K.logvarx_f, A, st));
+  }
+  ARDAE_TRY(launch_vae_loss(P.toy ? 1 : 0, W.o, W.o2, x, W.z, R, nz, P.D, P.zd, beta, 0, 0.f, nullptr, W.rec_row, W.pri_row, nullptr, nullptr, nullptr, st));
   return launch_vae_loss_finalize(W.rec_row, W.pri_row, R, beta, losses, st);
 }
 
@@ -341,28 +382,43 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
   Bump ws(workspace, wsf);
   AuxWs W;
   carve(P, ws, B, nz, 1, W);
-  const int R = B * nz, h = P.h, act = P.act, nl = P.nl;
-  const float gscale = dloss / (float)R;
-  ARDAE_TRY(launch_vae_loss(0, W.o, nullptr, x, W.z, R, nz, P.D, P.zd, beta, 1, gscale, dz_extra, W.rec_row, W.pri_row, W.dox, nullptr, W.dzq, st));
+  const int N = B * nz;                                   // z / decoder rows
+  const int nzs = P.stage(nz);                            // samples per image at the stage level (toy: q)
+  const int R = B * nzs, h = P.h, act = P.act, nl = P.nl;
+  const float gscale = dloss / (float)N;
+  ARDAE_TRY(launch_vae_loss(P.toy ? 1 : 0, W.o, W.o2, x, W.z, N, nz, P.D, P.zd, beta, 1, gscale, dz_extra, W.rec_row, W.pri_row, W.dox, W.dox2, W.dzq, st));
   // decoder backward
-  {
+  if (P.toy) {      // two heads (mean_fn, logvar_fn) back into the last hidden layer
+    LinArgs A{}; A.M = N; A.Nout = h; A.nsrc = 2; A.act = act; A.S = W.dcd[nl]; A.ldS = h; A.Y = W.ddec[nl]; A.ldY = h;
+    A.src[0].x = W.dox; A.src[0].ld = P.D; A.src[0].K = P.D; A.src[0].wp = packed + K.logit_b;
+    A.src[1].x = W.dox2; A.src[1].ld = P.D; A.src[1].K = P.D; A.src[1].wp = packed + K.logvarx_b;
+    ARDAE_TRY(launch_linear(A, EPI_DACT, st));
+  } else {
     LinArgs A{}; A.S = W.dcd[nl]; A.ldS = h; A.Y = W.ddec[nl]; A.ldY = h;
-    ARDAE_TRY(lin1(EPI_DACT, act, R, h, W.dox, P.D, P.D, packed + K.logit_b, A, st));
+    ARDAE_TRY(lin1(EPI_DACT, act, N, h, W.dox, P.D, P.D, packed + K.logit_b, A, st));
   }
   for (int l = nl; l >= 2; --l) {
     LinArgs A{}; A.S = W.dcd[l - 1]; A.ldS = h; A.Y = W.ddec[l - 1]; A.ldY = h;
-    ARDAE_TRY(lin1(EPI_DACT, act, R, h, W.ddec[l], h, h, packed + K.dec_b[l - 1], A, st));
+    ARDAE_TRY(lin1(EPI_DACT, act, N, h, W.ddec[l], h, h, packed + K.dec_b[l - 1], A, st));
   }
   {  // dz = ddec_1 . D_1 + (prior + injected seed)
     LinArgs A{}; A.S = W.dzq; A.ldS = P.zd; A.Q = W.dzq; A.ldQ = P.zd; A.Y = W.dz; A.ldY = P.zd;
-    ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, R, P.zd, W.ddec[1], h, h, packed + K.dec_b[0], A, st));
+    ARDAE_TRY(lin1(EPI_DACT, ACT_NONE, N, P.zd, W.ddec[1], h, h, packed + K.dec_b[0], A, st));
   }
   // second reparameterisation: dmu = dz, dlv = dz (z - mu) / 2; both heads back into h = t_n
-  ARDAE_TRY(launch_reparam_bwd(W.dz, W.z, W.mu, R, P.zd, 1, W.dlv, st));
+  // (toy: q z's share a stage row's mu / lv: their dz and dlv are summed over the q rows first)
+  ARDAE_TRY(launch_reparam_bwd(W.dz, W.z, W.mu, N, P.zd, P.toy ? nzs : 1, W.dlv, st));
+  const float* dmu = W.dz;
+  const float* dlv = W.dlv;
+  if (P.toy) {
+    ARDAE_TRY(launch_segment_sum(W.dz, P.zd, R, nzs, P.zd, 1.0f, W.dmu_s, P.zd, st));
+    ARDAE_TRY(launch_segment_sum(W.dlv, P.zd, R, nzs, P.zd, 1.0f, W.dlv_s, P.zd, st));
+    dmu = W.dmu_s; dlv = W.dlv_s;
+  }
   {
     LinArgs A{}; A.M = R; A.Nout = h; A.nsrc = 2; A.act = act; A.S = W.t[nl]; A.ldS = h; A.Y = W.dt[nl]; A.ldY = h;
-    A.src[0].x = W.dz; A.src[0].ld = P.zd; A.src[0].K = P.zd; A.src[0].wp = packed + K.mean_b;
-    A.src[1].x = W.dlv; A.src[1].ld = P.zd; A.src[1].K = P.zd; A.src[1].wp = packed + K.logvar_b;
+    A.src[0].x = dmu; A.src[0].ld = P.zd; A.src[0].K = P.zd; A.src[0].wp = packed + K.mean_b;
+    A.src[1].x = dlv; A.src[1].ld = P.zd; A.src[1].K = P.zd; A.src[1].wp = packed + K.logvar_b;
     ARDAE_TRY(launch_linear(A, EPI_DACT, st));
   }
   for (int l = nl; l >= 2; --l) {
@@ -373,11 +429,11 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
     LinArgs A{}; A.Y = W.dz0; A.ldY = P.nd;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.nd, W.dt[1], h, h, packed + K.ef_b[0], A, st));
   }
-  ARDAE_TRY(launch_segment_sum(W.dt[1], h, B, nz, h, 1.0f, W.drb, h, st));
+  ARDAE_TRY(launch_segment_sum(W.dt[1], h, B, nzs, h, 1.0f, W.drb, h, st));
   // first reparameterisation, reduced over the nz samples of each image
-  ARDAE_TRY(launch_reparam_bwd(W.dz0, W.z0, W.mu0, R, P.nd, nz, W.dlv0r, st));
-  ARDAE_TRY(launch_segment_sum(W.dz0, P.nd, B, nz, P.nd, 1.0f, W.dmu0, P.nd, st));
-  ARDAE_TRY(launch_segment_sum(W.dlv0r, P.nd, B, nz, P.nd, 1.0f, W.dlv0, P.nd, st));
+  ARDAE_TRY(launch_reparam_bwd(W.dz0, W.z0, W.mu0, R, P.nd, nzs, W.dlv0r, st));
+  ARDAE_TRY(launch_segment_sum(W.dz0, P.nd, B, nzs, P.nd, 1.0f, W.dmu0, P.nd, st));
+  ARDAE_TRY(launch_segment_sum(W.dlv0r, P.nd, B, nzs, P.nd, 1.0f, W.dlv0, P.nd, st));
   {
     LinArgs A{}; A.M = B; A.Nout = h; A.nsrc = 2; A.act = act; A.S = W.e[nl]; A.ldS = h; A.Y = W.de[nl]; A.ldY = h;
     A.src[0].x = W.dmu0; A.src[0].ld = P.nd; A.src[0].K = P.nd; A.src[0].wp = packed + K.mean0_b;
@@ -390,7 +446,7 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
   }
   // weight gradients: one batched launch (order == wgrad_scratch)
   std::vector<int> splits;
-  wgrad_scratch(P, B, R, &splits);
+  wgrad_scratch(P, B, R, N, &splits);
   std::vector<WgradProblem> probs;
   auto push = [&](int M, int O, int I, const float* G, const float* X, int ldX, float* out, int ldout, float* out_bias) {
     WgradProblem p;
@@ -404,11 +460,12 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
     p.out = out; p.ldout = ldout; p.out_bias = out_bias; p.beta = grads_beta;
     probs.push_back(p);
   };
-  push(R, P.D, h, W.dox, W.dcd[nl], h, grads + P.logit.w, h, grads + P.logit.b);
+  push(N, P.D, h, W.dox, W.dcd[nl], h, grads + P.logit.w, h, grads + P.logit.b);
+  if (P.toy) push(N, P.D, h, W.dox2, W.dcd[nl], h, grads + P.logvarx.w, h, grads + P.logvarx.b);
   for (int l = 1; l <= nl; ++l)
-    push(R, h, P.dec[l - 1].in, W.ddec[l], l == 1 ? W.z : W.dcd[l - 1], l == 1 ? P.zd : h, grads + P.dec[l - 1].w, P.dec[l - 1].in, grads + P.dec[l - 1].b);
-  push(R, P.zd, h, W.dz, W.t[nl], h, grads + P.mean.w, h, grads + P.mean.b);
-  push(R, P.zd, h, W.dlv, W.t[nl], h, grads + P.logvar.w, h, grads + P.logvar.b);
+    push(N, h, P.dec[l - 1].in, W.ddec[l], l == 1 ? W.z : W.dcd[l - 1], l == 1 ? P.zd : h, grads + P.dec[l - 1].w, P.dec[l - 1].in, grads + P.dec[l - 1].b);
+  push(R, P.zd, h, dmu, W.t[nl], h, grads + P.mean.w, h, grads + P.mean.b);
+  push(R, P.zd, h, dlv, W.t[nl], h, grads + P.logvar.w, h, grads + P.logvar.b);
   for (int l = nl; l >= 2; --l) push(R, h, h, W.dt[l], W.t[l - 1], h, grads + P.ef[l - 1].w, h, grads + P.ef[l - 1].b);
   push(R, h, P.nd, W.dt[1], W.z0, P.nd, grads + P.ef[0].w + P.D, P.ef[0].in, grads + P.ef[0].b);
   push(B, h, P.D, W.drb, W.xs, P.D, grads + P.ef[0].w, P.ef[0].in, nullptr);

@@ -90,12 +90,12 @@ struct Bump {
 
 int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d != nullptr, "model: desc is NULL");
-  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 6,
+  ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 7,
                   "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE), 3 (MNISTAuxIPVAE), 4 (MNISTConvAuxIPVAE), 5 (ResConvIPVAE) or "
-                  "6 (MNISTResConvAuxIPVAE)");
-  ARDAE_CHECK_ARG((d->flags & ~(ARDAE_MODEL_NO_CENTER | ARDAE_MODEL_HEAD_MASK | ARDAE_MODEL_CLIPPED)) == 0 && (d->kind >= 5 || d->flags == 0),
+                  "6 (MNISTResConvAuxIPVAE) or 7 (ToyAuxIPVAE)");
+  ARDAE_CHECK_ARG((d->flags & ~(ARDAE_MODEL_NO_CENTER | ARDAE_MODEL_HEAD_MASK | ARDAE_MODEL_CLIPPED)) == 0 && ((d->kind == 5 || d->kind == 6) || d->flags == 0),
                   "model: unknown flags %d (ARDAE_MODEL_NO_CENTER / the sampler-head bits / ARDAE_MODEL_CLIPPED exist for the residual-conv kinds 5 / 6 only)", d->flags);
-  if (d->kind >= 5) {
+  if ((d->kind == 5 || d->kind == 6)) {
     ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1 && d->h_dim >= 1 && d->act == ACT_ELU && (d->kind == 6 || (d->n_layers >= 1 && d->n_layers <= 4)),
                     "model: the residual-conv models are 28x28x1, ELU, and (kind 5) 1 .. 4 hidden layers in the sampler head");
     return 0;
@@ -268,23 +268,23 @@ extern "C" {
 
 size_t ardae_model_param_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
-  if (d->kind >= 5) return res_model_param_floats(*d);
+  if ((d->kind == 5 || d->kind == 6)) return res_model_param_floats(*d);
   if (d->kind == 4) return auxconv_model_param_floats(*d);
-  if (d->kind == 3) return aux_model_param_floats(*d);
+  if ((d->kind == 3 || d->kind == 7)) return aux_model_param_floats(*d);
   return d->kind == 2 ? conv_model_param_floats(*d) : ModelLayout(*d).total;
 }
 size_t ardae_model_packed_floats(const ardae_model_desc* d) {
   if (desc_ok(d)) return 0;
-  if (d->kind >= 5) return res_model_packed_floats(*d);
+  if ((d->kind == 5 || d->kind == 6)) return res_model_packed_floats(*d);
   if (d->kind == 4) return auxconv_model_packed_floats(*d);
-  if (d->kind == 3) return aux_model_packed_floats(*d);
+  if ((d->kind == 3 || d->kind == 7)) return aux_model_packed_floats(*d);
   return d->kind == 2 ? conv_model_packed_floats(*d) : ModelPacked(ModelLayout(*d)).total;
 }
 size_t ardae_model_workspace_floats(const ardae_model_desc* d, int B, int nz, int mode) {
   if (desc_ok(d) || B <= 0 || nz <= 0) return 0;
-  if (d->kind >= 5) return res_model_workspace_floats(*d, B, nz, mode);
+  if ((d->kind == 5 || d->kind == 6)) return res_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 4) return auxconv_model_workspace_floats(*d, B, nz, mode);
-  if (d->kind == 3) return aux_model_workspace_floats(*d, B, nz, mode);
+  if ((d->kind == 3 || d->kind == 7)) return aux_model_workspace_floats(*d, B, nz, mode);
   if (d->kind == 2) return conv_model_workspace_floats(*d, B, nz, mode == 3 ? 0 : mode);
   const ModelLayout P(*d);
   if (mode == 2) return P.dec.size() * al64((size_t)B * nz * P.h);
@@ -296,9 +296,9 @@ int ardae_model_pack(const ardae_model_desc* d, const float* params, float* pack
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed, "model_pack: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (d->kind >= 5) return res_model_pack(*d, params, packed, st);
+  if ((d->kind == 5 || d->kind == 6)) return res_model_pack(*d, params, packed, st);
   if (d->kind == 4) return auxconv_model_pack(*d, params, packed, st);
-  if (d->kind == 3) return aux_model_pack(*d, params, packed, st);
+  if ((d->kind == 3 || d->kind == 7)) return aux_model_pack(*d, params, packed, st);
   if (d->kind == 2) return conv_model_pack(*d, params, packed, st);
   std::vector<PackItem> pack_items__;
   const ModelLayout P(*d);
@@ -340,8 +340,8 @@ int ardae_model_encode(const ardae_model_desc* d, const float* params, const flo
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 0));
   ARDAE_CHECK_ARG(z_out, "model_encode: z_out is NULL");
   hipStream_t st = (hipStream_t)stream;
-  if (d->kind >= 5) return res_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st);
-  if (d->kind == 3) {
+  if ((d->kind == 5 || d->kind == 6)) return res_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st);
+  if ((d->kind == 3 || d->kind == 7)) {
     ARDAE_TRY(aux_model_encode(*d, params, packed, x, noise, B, nz, workspace, workspace_floats_, z_out, nullptr, st));
     return 0;
   }
@@ -405,7 +405,7 @@ int ardae_model_encode_hidden_raw(const ardae_model_desc* d, const float* params
 int ardae_model_encode_hidden(const ardae_model_desc* d, const float* params, const float* packed, const float* x, int B, float* workspace,
                               size_t workspace_floats_, float* z0_out, float* hidden_out, void* stream) {
   ARDAE_TRY(model_common(d, params, packed, x, B, 1, workspace, workspace_floats_, 0));
-  ARDAE_CHECK_ARG(d->kind == 3 || d->kind == 4 || d->kind == 6, "model_encode_hidden: the hidden1a context exists for the aux models only (kinds 3, 4, 6)");
+  ARDAE_CHECK_ARG((d->kind == 3 || d->kind == 7) || d->kind == 4 || d->kind == 6, "model_encode_hidden: the hidden1a context exists for the aux models only (kinds 3, 4, 6, 7)");
   ARDAE_CHECK_ARG(hidden_out, "model_encode_hidden: hidden_out is NULL");
   hipStream_t st = (hipStream_t)stream;
   if (d->kind == 6) return res_model_encode(*d, params, packed, x, nullptr, B, 1, workspace, workspace_floats_, z0_out, hidden_out, st);   // z0_out may be NULL
@@ -418,7 +418,7 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
                        size_t workspace_floats_, float* out0, float* out1, void* stream) {
   ARDAE_TRY(desc_ok(d));
   ARDAE_CHECK_ARG(params && packed && z && workspace && out0 && R > 0, "model_decode: bad arguments");
-  if (d->kind >= 5) {
+  if ((d->kind == 5 || d->kind == 6)) {
     ARDAE_CHECK_ARG(workspace_floats_ >= res_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
     return res_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
   }
@@ -430,9 +430,9 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
     ARDAE_CHECK_ARG(workspace_floats_ >= auxconv_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
     return auxconv_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream);
   }
-  if (d->kind == 3) {
+  if ((d->kind == 3 || d->kind == 7)) {
     ARDAE_CHECK_ARG(workspace_floats_ >= aux_model_workspace_floats(*d, R, 1, 2), "model_decode: workspace too small");
-    ARDAE_TRY(aux_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream));
+    ARDAE_TRY(aux_model_decode(*d, params, packed, z, R, workspace, workspace_floats_, out0, (hipStream_t)stream, out1));
     return 0;
   }
   const ModelLayout P(*d);
@@ -459,7 +459,7 @@ int ardae_model_decode(const ardae_model_desc* d, const float* params, const flo
 int ardae_model_loss_rows(const ardae_model_desc* d, const float* out0, const float* out1, const float* x, const float* z, int rows,
                           int nz, float* recon_row, float* prior_row, void* stream) {
   ARDAE_TRY(desc_ok(d));
-  return launch_vae_loss(d->kind == 1 ? 1 : 0, out0, out1, x, z, rows, nz, d->input_dim, d->z_dim, 1.f, 0, 0.f, nullptr, recon_row, prior_row, nullptr,
+  return launch_vae_loss(d->kind == 1 || d->kind == 7 ? 1 : 0, out0, out1, x, z, rows, nz, d->input_dim, d->z_dim, 1.f, 0, 0.f, nullptr, recon_row, prior_row, nullptr,
                          nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -469,8 +469,8 @@ int ardae_model_vae_forward(const ardae_model_desc* d, const float* params, cons
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && z_out && losses, "model_vae_forward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
-  if (d->kind >= 5) return res_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
-  if (d->kind == 3) {
+  if ((d->kind == 5 || d->kind == 6)) return res_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st);
+  if ((d->kind == 3 || d->kind == 7)) {
     ARDAE_TRY(aux_model_vae_forward(*d, params, packed, x, noise, B, nz, beta, workspace, workspace_floats_, z_out, losses, st));
     return 0;
   }
@@ -588,7 +588,7 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   ARDAE_TRY(model_common(d, params, packed, x, B, nz, workspace, workspace_floats_, 1));
   ARDAE_CHECK_ARG(noise && grads, "model_vae_backward: null pointer argument");
   hipStream_t st = (hipStream_t)stream;
-  if (d->kind >= 5) {
+  if ((d->kind == 5 || d->kind == 6)) {
     return res_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
   if (d->kind == 2) {
@@ -597,7 +597,7 @@ int ardae_model_vae_backward(const ardae_model_desc* d, const float* params, con
   if (d->kind == 4) {
     return auxconv_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
-  if (d->kind == 3) {
+  if ((d->kind == 3 || d->kind == 7)) {
     return aux_model_vae_backward(*d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, workspace, workspace_floats_, grads, grads_beta, st);
   }
   return vae_backward_impl(d, params, packed, x, noise, B, nz, beta, dloss, dz_extra, 1.f, workspace, workspace_floats_, grads, grads_beta, 3, st);

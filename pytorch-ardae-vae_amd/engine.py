@@ -162,9 +162,9 @@ class ArdaeEngine:
                               lib.ardae_model_workspace_floats(ctypes.byref(md), B, 1, 0)))
         self.ws_small_v = f(lib.ardae_model_workspace_floats(ctypes.byref(md), B, 1, 0))   # VAE-side encode(std=0): may run beside the cDAE phase
         self.z0, self.latent = f(B, z), f(N, z)
-        self.noise_s, self.xi, self.eps = f(N, nd), f(B * S), f(B * S, z)
+        self.noise_s, self.xi, self.eps = f(model._noise_numel(B, nzc)), f(B * S), f(B * S, z)
         self.xbar, self.sigma, self.std_b = f(B * S, z), f(B * S), f(B)
-        self.noise_v, self.zv, self.z0v, self.u, self.g = f(B * nzm, nd), f(B * nzm, z), f(B, z), f(B * nzm, z), f(B * nzm, z)
+        self.noise_v, self.zv, self.z0v, self.u, self.g = f(model._noise_numel(B, nzm)), f(B * nzm, z), f(B, z), f(B * nzm, z), f(B * nzm, z)
         self.sigma0 = torch.zeros(B * nzm, device=self.dev)
         if self.clipped:        # [context draw | latent-mean draw] of a phase's two std = 0 calls, [2, B, z0_dim]
             self.raw_c, self.raw_v = f(2, B, model.noise_dim), f(2, B, model.noise_dim)

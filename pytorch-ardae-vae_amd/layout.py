@@ -64,6 +64,16 @@ def model_spec(kind, input_dim, noise_dim, h_dim, z_dim, n_layers, enc_type="res
         s += _mlp("decode.main.", z_dim, h_dim, h_dim, n_layers - 1)
         s += [("decode.reparam.mean_fn.weight", (input_dim, h_dim)), ("decode.reparam.mean_fn.bias", (input_dim,)),
               ("decode.reparam.logvar_fn.weight", (input_dim, h_dim)), ("decode.reparam.logvar_fn.bias", (input_dim,))]
+    elif kind == "auxtoy":     # models/ivae/auxtoy.py:44-130 (AuxEncoder + SimpleEncoder of models/vae/auxtoy.py) + models/vae/toy.py Decoder (Gaussian)
+        s = _mlp("encode.aux_encode.main.", input_dim, h_dim, h_dim, n_layers - 1)
+        s += [("encode.aux_encode.reparam.mean_fn.weight", (noise_dim, h_dim)), ("encode.aux_encode.reparam.mean_fn.bias", (noise_dim,)),
+              ("encode.aux_encode.reparam.logvar_fn.weight", (noise_dim, h_dim)), ("encode.aux_encode.reparam.logvar_fn.bias", (noise_dim,))]
+        s += _mlp("encode.encode.fc.", input_dim + noise_dim, h_dim, h_dim, n_layers - 1)
+        s += [("encode.encode.reparam.mean_fn.weight", (z_dim, h_dim)), ("encode.encode.reparam.mean_fn.bias", (z_dim,)),
+              ("encode.encode.reparam.logvar_fn.weight", (z_dim, h_dim)), ("encode.encode.reparam.logvar_fn.bias", (z_dim,))]
+        s += _mlp("decode.main.", z_dim, h_dim, h_dim, n_layers - 1)
+        s += [("decode.reparam.mean_fn.weight", (input_dim, h_dim)), ("decode.reparam.mean_fn.bias", (input_dim,)),
+              ("decode.reparam.logvar_fn.weight", (input_dim, h_dim)), ("decode.reparam.logvar_fn.bias", (input_dim,))]
     elif kind == "auxmnist":   # models/ivae/auxmnist.py:47-132 (AuxEncoder + SimpleEncoder of models/vae/auxmnist.py) + models/vae/mnist.py Decoder
         s = _mlp("encode.aux_encode.main.", input_dim, h_dim, h_dim, n_layers - 1)
         s += [("encode.aux_encode.reparam.mean_fn.weight", (noise_dim, h_dim)), ("encode.aux_encode.reparam.mean_fn.bias", (noise_dim,)),

@@ -123,8 +123,9 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-KIND_IDS = {"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4, "resconv": 5, "auxresconv": 6}     # ardae_model_desc.kind
-AUX_KINDS = ("auxmnist", "auxconv", "auxresconv")                                                           # hierarchical samplers
+KIND_IDS = {"mnist": 0, "toy": 1, "conv": 2, "auxmnist": 3, "auxconv": 4, "resconv": 5, "auxresconv": 6, "auxtoy": 7}     # ardae_model_desc.kind
+AUX_KINDS = ("auxmnist", "auxconv", "auxresconv", "auxtoy")                                                 # hierarchical samplers
+GAUSSIAN_DECODERS = ("toy", "auxtoy")                                                                        # decode.reparam.{mean_fn, logvar_fn}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -301,7 +302,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
         # floats per row of a sampler draw: the aux models take two draws per call, laid out side by side [eps0 | eps]
         self._noise_width = noise_dim + z_dim if self._kind in AUX_KINDS else noise_dim
         # columns of the `hidden1a` cDAE context (ivae_ardae.py:572-580): cat(h0, h) for the MLP / conv aux models, h alone for auxresconv
-        self.hidden_dim = {"auxmnist": 2 * h_dim, "auxconv": 2 * h_dim, "auxresconv": h_dim}.get(self._kind, 0)
+        self.hidden_dim = {"auxmnist": 2 * h_dim, "auxconv": 2 * h_dim, "auxresconv": h_dim, "auxtoy": 2 * h_dim}.get(self._kind, 0)
         self._build_params(layout.model_spec(self._kind, input_dim, noise_dim, h_dim, z_dim, num_hidden_layers, **getattr(self, "_spec_extra", {})),
                            {"encode": _EncodeBox})
         object.__setattr__(self.encode, "_owner_ref", weakref.ref(self))   # `model.encode(x, std=0)` (ivae_ardae.py:735)
@@ -333,6 +334,10 @@ class ImplicitPosteriorVAE(FlatParamModule):
                         if "deconv" in name or "logit_fn" in name:
                             continue
                         nn.init.xavier_uniform_(t) if t.dim() >= 2 else t.zero_()
+                return
+            if self._kind == "auxtoy":                    # init='gaussian' reaches the toy Decoder only (ivae/auxtoy.py:165, vae/toy.py)
+                if self.init == "gaussian":
+                    p["decode.reparam.mean_fn.weight"].normal_()
                 return
             if self._kind == "mnist":                     # decode.apply(weight_init): xavier-uniform W, zero b (ivae/mnist.py:20-25,235)
                 for name, t in p.items():
@@ -366,7 +371,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
             nptr = None                                   # encode(x, std=0): the draw is multiplied by zero
         else:
             if noise is None:
-                noise = rng.normal((B * nz, self._noise_width), x.device)
+                noise = rng.normal((self._noise_numel(B, nz),), x.device)
                 if std is not None:
                     noise = noise * float(std)
             noise = self._noise_rows(noise, B * nz)
@@ -377,6 +382,10 @@ class ImplicitPosteriorVAE(FlatParamModule):
         L.check(lib.ardae_model_encode(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(x), nptr, B, nz,
                                        L.ptr(ws), ws.numel(), L.ptr(z), L.stream_ptr()), "ardae_model_encode")
         return z.view(B, nz, self.z_dim)
+
+    def _noise_numel(self, B, nz):
+        """Floats of one sampler call's draws for B images x nz rows."""
+        return B * nz * self._noise_width
 
     def _noise_rows(self, noise, rows):
         """[rows, noise width] fp32 contiguous; the aux models also take the pair (eps0 [rows, noise_dim], eps [rows, z_dim])."""
@@ -407,7 +416,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
         out = self.decode_params(z_rows)
         R, lib = out[0].size(0), L.lib()
         sample = torch.empty_like(out[0])
-        if self._kind == "toy":
+        if self._kind in GAUSSIAN_DECODERS:
             e = _f32c(dec_noise).view(R, self.input_dim) if dec_noise is not None else rng.normal((R, self.input_dim), out[0].device)
             L.check(lib.ardae_gaussian_sample(L.ptr(out[0]), L.ptr(out[1]), L.ptr(e), out[0].numel(), L.ptr(sample), L.stream_ptr()),
                     "ardae_gaussian_sample")
@@ -427,7 +436,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
         x = self._x(input)
         B = x.size(0)
         if noise is None:
-            noise = rng.normal((B * nz, self._noise_width), x.device)
+            noise = rng.normal((self._noise_numel(B, nz),), x.device)
             if std is not None:
                 noise = noise * float(std)
         noise = self._noise_rows(noise, B * nz)
@@ -447,7 +456,7 @@ class ImplicitPosteriorVAE(FlatParamModule):
         R, lib = z.size(0), L.lib()
         ws = self._ws(lib.ardae_model_workspace_floats(ctypes.byref(self._desc), R, 1, 2))
         o0 = torch.empty(R, self.input_dim, device=z.device)
-        o1 = torch.empty(R, self.input_dim, device=z.device) if self._kind == "toy" else None
+        o1 = torch.empty(R, self.input_dim, device=z.device) if self._kind in GAUSSIAN_DECODERS else None
         L.check(lib.ardae_model_decode(ctypes.byref(self._desc), L.ptr(self._flat), L.ptr(self._packed_weights()), L.ptr(z), R, L.ptr(ws),
                                        ws.numel(), L.ptr(o0), L.ptr(o1), L.stream_ptr()), "ardae_model_decode")
         return (o0,) if o1 is None else (o0, o1)
@@ -468,14 +477,18 @@ class ImplicitPosteriorVAE(FlatParamModule):
         B, k, zd = x.size(0), sample_size, self.z_dim
         assert sample_size >= 2 * self.z_dim                 # ivae/mnist.py:382
         with torch.no_grad():
-            if isinstance(enc_noise, (tuple, list)):
+            ke = k * k if self._kind == "auxtoy" else k       # ToyAuxIPVAE fits the proposal to Encoder._forward(nz=k): k z0's x k z's (ivae/auxtoy.py:313)
+            if self._kind == "auxtoy":
+                if enc_noise is not None and not isinstance(enc_noise, (tuple, list)):
+                    raise ValueError("ToyAuxIPVAE.logprob: enc_noise is the pair (eps0 [B, k, noise_dim], eps [B, k k, z_dim])")
+            elif isinstance(enc_noise, (tuple, list)):
                 enc_noise = tuple(n.reshape(B * k, -1) for n in enc_noise)
             elif enc_noise is not None:
                 enc_noise = enc_noise.reshape(B * k, self._noise_width)
-            zs = self._sample(x, k, std, enc_noise)           # [B,k,z]
+            zs = self._sample(x, ke, std, enc_noise)          # [B,k,z]
             mu = zs.mean(1)
             zc = zs - mu.unsqueeze(1)
-            cov = zc.transpose(1, 2) @ zc / (k - 1)           # utils/stat.py:127-158
+            cov = zc.transpose(1, 2) @ zc / (ke - 1)          # utils/stat.py:127-158
             if self._kind in AUX_KINDS:
                 cov = cov + 1e-5 * torch.eye(zd, device=cov.device)      # ivae/auxmnist.py:321, ivae/auxconv.py, ivae/auxresconv.py:299
             cov = cov.contiguous()
@@ -537,6 +550,40 @@ class MNISTAuxIPVAE(ImplicitPosteriorVAE):
             raise NotImplementedError                     # ivae/auxmnist.py:72-73
         self.do_xavier, self.clip_z0_logvar, self.clip_z_logvar = do_xavier, None, None
         super().__init__(energy_func, input_dim, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, "none", enc_type)
+
+
+class ToyAuxIPVAE(ImplicitPosteriorVAE):
+    """models/ivae/auxtoy.py::ImplicitPosteriorVAE (`--model auxmlp`, ivae_ardae.py:443-454): MNISTAuxIPVAE's networks without the 2x - 1 rescale,
+    the toy problem's Gaussian decoder, and a SQUARE sampling scheme - a call with nz rows per image draws q = int(sqrt(nz)) z0's per image and
+    q z's per z0 (`forward_hidden` / `forward`, :215,230; nz must be a square), `logprob(sample_size=k)` fits its proposal to k x k encoder
+    samples (:313).  `noise=` of a sampler call: the pair (eps0 [B q, noise_dim], eps [B q q, z_dim]) or ONE flat tensor [eps0 block | eps block]."""
+    _kind = "auxtoy"
+    _enc_types = ("simple",)
+
+    def __init__(self, energy_func=normal_energy_func, input_dim=2, noise_dim=2, h_dim=64, z_dim=2, nonlinearity="tanh", num_hidden_layers=1,
+                 init="gaussian", enc_type="simple", clip_z0_logvar=None, clip_z_logvar=None):
+        for c in (clip_z0_logvar, clip_z_logvar):
+            if c not in (None, "none"):
+                raise NotImplementedError("log-variance clipping (the shipped recipes pass 'none')")
+        if enc_type != "simple":
+            raise NotImplementedError                     # ivae/auxtoy.py:70-71
+        self.clip_z0_logvar, self.clip_z_logvar = None, None
+        super().__init__(energy_func, input_dim, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, init, enc_type)
+
+    @staticmethod
+    def _q(nz):
+        q = math.isqrt(int(nz))
+        if q * q != nz:
+            raise ValueError(f"ToyAuxIPVAE draws q z0's x q z's per image: nz = {nz} is not a square (ivae/auxtoy.py:215)")
+        return q
+
+    def _noise_numel(self, B, nz):
+        return B * self._q(nz) * self.noise_dim + B * nz * self.z_dim
+
+    def _noise_rows(self, noise, rows):
+        if isinstance(noise, (tuple, list)):
+            noise = torch.cat([_f32c(n).reshape(-1) for n in noise])
+        return _f32c(noise).reshape(-1)
 
 
 class MNISTConvAuxIPVAE(ImplicitPosteriorVAE):

@@ -23,6 +23,8 @@ CASES = {
     "conv_b4_nz8": (O.ModelCfg("conv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 32, 64, 2), 8, False),   # cfg #4 model
     # the shipped "hierarchical mlp" recipe's model family: aux sampler + hidden1a context (run_vae_dbmnist.sh --model auxmnist)
     "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, True),
+    # --model auxmlp (ToyAuxIPVAE, ivae_ardae.py:443-454): q z0's x q z's per image (nz_cdae 16 = 4 x 4), Gaussian decoder, tanh
+    "tiny_auxtoy_grad": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, True),
     # the shipped "hierarchical conv" recipe's model family (run_vae_dbmnist.sh --model auxconv, hidden1a context of 1600 columns)
     "auxconv_b4_nz8": (O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 1600, 64, 2), 8, False),
     # the shipped "implicit resconv" / "hierarchical resconv" recipes' model families (--model resconvct-res / auxresconvct, ELU,
@@ -74,6 +76,9 @@ def build(mc, cc):
             input_height=28, input_channels=1, z_dim=mc.z_dim, c_dim=mc.h_dim, z0_dim=mc.noise_dim, nonlinearity=mc.nonlin, do_center=mc.do_center)
     elif mc.kind == "auxconv":
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
+    elif mc.kind == "auxtoy":
+        model = net.ToyAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
+                                nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
     elif mc.kind == "auxmnist":
         model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
                                   nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
@@ -127,11 +132,15 @@ def assert_update_close(after, before, ref_after, what, sgd=False):
     assert rel_l2(upd, ref) < 5e-2, what
 
 
-def noise_of(fx, t, dev):
+def noise_of(fx, t, dev, blocks=False):
     n = {k: torch.tensor(fx[f"s{t}/noise/{k}"]) for k in ("sampler", "sigma", "eps", "vae")}
     for k in ("sampler", "vae"):        # aux models: the second draw of a sampler call sits beside the first, rows [eps0 | eps]
         if f"s{t}/noise/{k}_z" in fx:
-            n[k] = torch.cat([n[k], torch.tensor(fx[f"s{t}/noise/{k}_z"])], 1)
+            ez = torch.tensor(fx[f"s{t}/noise/{k}_z"])
+            if blocks:                          # ToyAuxIPVAE: eps0 [B q, nd] and eps [B q q, z] - two blocks, one after the other
+                n[k] = torch.cat([n[k].reshape(-1), ez.reshape(-1)])
+            else:
+                n[k] = torch.cat([n[k], ez], 1)
     for k in ("ctx_raw", "z0_raw", "vctx_raw", "vz0_raw"):      # the clipped class: unscaled eps0 of the std = 0 calls
         if f"s{t}/noise/{k}" in fx:
             n[k] = torch.tensor(fx[f"s{t}/noise/{k}"])
@@ -171,7 +180,7 @@ def test_engine_trajectory_golden(golden_dir, name):
         pre = f"s{t}/"
         xc, xv = torch.tensor(fx[pre + "x_cdae"]).cuda(), torch.tensor(fx[pre + "x_vae"]).cuda()
         before_c, before_m = cdae.flat_params().clone(), model.flat_params().clone()
-        eng.step(xc, xv, noise=noise_of(fx, t, "cuda"))
+        eng.step(xc, xv, noise=noise_of(fx, t, "cuda", blocks=mc.kind == "auxtoy"))
         s = eng.stats()
         # sampler + latent statistics
         assert rel_l2(eng.z0, fx[pre + "z0"].reshape(B, -1)) < 1e-5
@@ -241,7 +250,7 @@ def test_engine_step_production_kernels_vs_oracle(kind):
     assert_update_close(model.flat_params().cpu(), before_m, ref_m, "model update")
 
 
-@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad", "tiny_toy_tanh", "tiny_mnist_elu",
+@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad", "tiny_auxtoy_grad", "tiny_toy_tanh", "tiny_mnist_elu",
                                   "tiny_mnist_leaky", "tiny_toy_relu_relu", "tiny_mnist_tanh_res"])
 def test_vae_phase_grads_golden(golden_dir, name):
     mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, name)
@@ -253,7 +262,7 @@ def test_vae_phase_grads_golden(golden_dir, name):
         cdae.flat_params().copy_(torch.cat([torch.tensor(fx["s0/cdae_params_after/" + n]).reshape(-1) for n, _ in O.cdae_param_spec(cc)]).cuda())
     B = int(fx["meta_B"])
     eng = net.ArdaeEngine(model, cdae, train_config(mc, nz), batch_size=B)
-    eng.vae_phase(torch.tensor(fx["s0/x_vae"]).cuda(), noise=noise_of(fx, 0, "cuda"), apply_update=False)
+    eng.vae_phase(torch.tensor(fx["s0/x_vae"]).cuda(), noise=noise_of(fx, 0, "cuda", blocks=mc.kind == "auxtoy"), apply_update=False)
     torch.cuda.synchronize()
     assert rel_l2(eng.zv, fx["s0/vae_latent"].reshape(B, -1)) < 1e-5
     # score at sigma=0 (glogprob); with the split backward the seed buffer holds g itself (the factor s*beta/(B nz) is applied
@@ -646,6 +655,33 @@ def test_engine_clipped_aux_resconv_own_draws_replay_and_refusals():
         model.encode(xs[0].cuda(), std=0.5)
 
 
+def test_engine_toy_aux_own_draws_replay():
+    """--model auxmlp with the engine's own noise under graph replay (nz_cdae 16 = 4 z0's x 4 z's per image; the sampler's draw is one flat
+    [eps0 block | eps block] buffer): two engines from one seed end bit-identical, replay == eager, a non-square nz_cdae is refused."""
+    mc = O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh")
+    cc = O.CdaeCfg("grad", 2, 64, 64, 3)
+    pm = O.init_params(O.model_param_spec(mc), 0, O.model_init_special(mc)); pc = O.init_params(O.cdae_param_spec(cc), 1)
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(8, 2, generator=g) for _ in range(3)]
+
+    def run(graph, nz=16):
+        net.manual_seed(5)
+        model, cdae = build(mc, cc)
+        model.load_state_dict(pm); cdae.load_state_dict(pc)
+        model, cdae = model.to("cuda"), cdae.to("cuda")
+        eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=nz, cdae_ctx_type="hidden1a"), batch_size=8, graph=graph)
+        for t in range(4):
+            eng.step(xs[t % 3].cuda(), xs[(t + 1) % 3].cuda())
+        torch.cuda.synchronize()
+        assert all(v == v for v in eng.stats().values())
+        return model.flat_params().clone(), cdae.flat_params().clone()
+    a, b, e = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], e[0]) and torch.equal(a[1], e[1])
+    assert not torch.equal(a[0].cpu(), torch.cat([pm[n].reshape(-1) for n, _ in O.model_param_spec(mc)]))
+    with pytest.raises(ValueError, match="square"):
+        run(False, nz=12)
+
+
 def test_engine_beta_annealing_under_graph_mode():
     """--beta-annealing (utils/msc.py:53-55, ivae_ardae.py:800): beta is a kernel argument frozen in a captured graph, so the
     engine launches eagerly while beta moves and captures once it has settled - with the same parameters, bit for bit, as an
@@ -709,6 +745,65 @@ def test_aux_model_module_surface(golden_dir):
         assert rel_l2(p.grad.cpu(), preq[n].grad) < 2e-4, n
     with pytest.raises(NotImplementedError):
         net.MNISTAuxIPVAE(clip_z_logvar="spm4")
+
+
+def test_toy_aux_model_module_surface_and_iwae(golden_dir):
+    """ToyAuxIPVAE (`--model auxmlp`) through the reference's call surface: the hidden1a context, the latent mean, the SQUARE sampler
+    (nz = 16 rows per image = 4 z0's x 4 z's; a non-square nz is refused), loss / gradients of model(...) + latent.backward(seed) against
+    the oracle (pinned to the reference's class at 1e-15 in float64), and logprob (k x k encoder samples fit the proposal, ivae/auxtoy.py:313)
+    against the reference's value with injected draws."""
+    mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, "tiny_auxtoy_grad")
+    model, _ = build(mc, cc)
+    model.load_state_dict(pm)
+    model = model.to("cuda")
+    x = torch.tensor(fx["s0/x_cdae"])
+    B = x.size(0)
+    hid = model.encode.forward_hidden(x.cuda(), std=0)
+    assert hid.shape == (B, 2 * mc.h_dim) and rel_l2(hid, O.cdae_context(mc, O.TrainCfg(ctx_type="hidden1a"), pm, x)) < 1e-5
+    z0 = model.encode(x.cuda(), std=0)
+    assert z0.shape == (B, 1, mc.z_dim) and rel_l2(z0.reshape(B, -1), fx["s0/z0"].reshape(B, -1)) < 1e-5
+    e0, e = torch.tensor(fx["s0/noise/sampler"]), torch.tensor(fx["s0/noise/sampler_z"])
+    assert e0.shape == (B * 4, mc.noise_dim) and e.shape == (B * 16, mc.z_dim)
+    z = model.forward_hidden(x.cuda(), nz=nz, noise=(e0.cuda(), e.cuda()))
+    assert z.shape == (B, nz, mc.z_dim) and rel_l2(z.reshape(B * nz, -1), fx["s0/latent"].reshape(B * nz, -1)) < 1e-5
+    with pytest.raises(ValueError, match="not a square"):
+        model.forward_hidden(x.cuda(), nz=12)
+    zz = model.forward_hidden(x.cuda(), nz=9)          # own draws
+    assert zz.shape == (B, 9, mc.z_dim) and torch.isfinite(zz).all()
+    xv = torch.tensor(fx["s0/x_vae"])
+    nv = (torch.tensor(fx["s0/noise/vae"]), torch.tensor(fx["s0/noise/vae_z"]))
+    seed = torch.tensor(fx["s0/score"]).reshape(B, 1, mc.z_dim) * 0.01
+    _, _, latent, loss, rec, pri = model(xv.cuda(), beta=1.0, eta=0., lmbd=0., nz=1, noise=(nv[0].cuda(), nv[1].cuda()))
+    loss.backward(retain_graph=True)
+    latent.backward(seed.cuda())
+    preq = {k: v.clone().requires_grad_(True) for k, v in pm.items()}
+    zr, lr_, recr, prir, _ = O.vae_forward(mc, preq, xv, nv, 1.0, 1)
+    (lr_ + (zr * seed).sum()).backward()
+    assert rel(loss.item(), lr_.item()) < 1e-4 and rel(rec.item(), recr.item()) < 2e-5 and rel(pri.item(), prir.item()) < 2e-5
+    for n, p in model.named_parameters():
+        assert rel_l2(p.grad.cpu(), preq[n].grad) < 2e-4, n
+    # nz = 4 rows per image through the VAE forward / backward (2 z0's x 2 z's: the sums over the q z's of a stage row)
+    g4 = torch.Generator().manual_seed(4)
+    n4 = (torch.randn(B * 2, mc.noise_dim, generator=g4), torch.randn(B * 4, mc.z_dim, generator=g4))
+    model.zero_grad()
+    _, _, lat4, loss4, _, _ = model(xv.cuda(), beta=0.7, eta=0., lmbd=0., nz=4, noise=(n4[0].cuda(), n4[1].cuda()))
+    loss4.backward()
+    preq = {k: v.clone().requires_grad_(True) for k, v in pm.items()}
+    _, l4, _, _, _ = O.vae_forward(mc, preq, xv, n4, 0.7, 4)
+    l4.backward()
+    assert rel(loss4.item(), l4.item()) < 1e-4
+    for n, p in model.named_parameters():
+        assert rel_l2(p.grad.cpu(), preq[n].grad) < 2e-4, n
+    # IWAE
+    fi = dict(np.load(os.path.join(golden_dir, "iwae_tiny_auxtoy.npz")))
+    model.load_state_dict({n: torch.tensor(fi["pm/" + n]).float() for n, _ in O.model_param_spec(mc)})
+    k = int(fi["meta_k"])
+    got = model.logprob(torch.tensor(fi["x"]).float().cuda(), sample_size=k,
+                        enc_noise=(torch.tensor(fi["enc_noise"]).float().cuda(), torch.tensor(fi["enc_noise_z"]).float().cuda()),
+                        prop_noise=torch.tensor(fi["prop_noise"]).float().cuda())
+    assert abs(float(got) - float(fi["logprob"])) < 1e-4 * abs(float(fi["logprob"]))
+    _, mean, zg = model.generate(5)
+    assert mean.shape == (5, 2) and zg.shape == (5, 2)
 
 
 def test_iwae_logprob_golden_aux(golden_dir):

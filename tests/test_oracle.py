@@ -16,6 +16,9 @@ CASES = {
     # family is pinned against the reference's MNISTAuxIPVAE here; its HIP path is the next row to build
     "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, torch.float32),
     "tiny_auxmnist_grad_f64": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, torch.float64),
+    # --model auxmlp: ToyAuxIPVAE (q z0's x q z's per image: nz_cdae 16 = 4 x 4), Gaussian decoder, tanh, hidden1a context
+    "tiny_auxtoy_grad": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, torch.float32),
+    "tiny_auxtoy_grad_f64": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, torch.float64),
     # the other activations of get_nonlinear_func (utils/models.py:14-32): tanh = the class default of the reference's models and cDAEs,
     # relu = the default of --cdae-nonlin (mlp-grad: second-order terms vanish), elu, leaky_relu
     "tiny_toy_tanh": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 2, 64, 3, "tanh"), 8, torch.float32),
@@ -68,7 +71,7 @@ def rel_l2(a, b):
 def test_oracle_step_matches_reference_fixture(golden_dir, name):
     mc, cc, nz, dt = CASES[name]
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-    tc = O.TrainCfg(nz_cdae=nz, ctx_type="hidden1a" if mc.kind == "auxmnist" else "lt0")
+    tc = O.TrainCfg(nz_cdae=nz, ctx_type="hidden1a" if mc.kind in ("auxmnist", "auxtoy") else "lt0")
     if name in CTX_DATA:
         tc = O.TrainCfg(nz_cdae=nz, ctx_type="data", ctx_center=CTX_DATA[name])
     if name == "tiny_mnist_nstd3":
@@ -180,6 +183,15 @@ def test_oracle_iwae_matches_reference_fixture(golden_dir):
 def test_oracle_iwae_matches_reference_fixture_aux(golden_dir):
     fx = dict(np.load(os.path.join(golden_dir, "iwae_tiny_auxmnist.npz")))
     mc = O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus")
+    pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
+    got = O.iwae_logprob(mc, pm, torch.tensor(fx["x"]), int(fx["meta_k"]), (torch.tensor(fx["enc_noise"]), torch.tensor(fx["enc_noise_z"])),
+                         torch.tensor(fx["prop_noise"]))
+    assert abs(float(got) - float(fx["logprob"])) / abs(float(fx["logprob"])) < 1e-9
+
+
+def test_oracle_iwae_matches_reference_fixture_auxtoy(golden_dir):
+    fx = dict(np.load(os.path.join(golden_dir, "iwae_tiny_auxtoy.npz")))
+    mc = O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh")
     pm = {n: torch.tensor(fx["pm/" + n]) for n, _ in O.model_param_spec(mc)}
     got = O.iwae_logprob(mc, pm, torch.tensor(fx["x"]), int(fx["meta_k"]), (torch.tensor(fx["enc_noise"]), torch.tensor(fx["enc_noise_z"])),
                          torch.tensor(fx["prop_noise"]))
