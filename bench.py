@@ -121,7 +121,8 @@ def roofline_of(rep, prof_steps):
             traffic_src = (f"null: profiles/pmc_summary.json was recorded from kernel sources {str(meta.get('kernel_source_sha256'))[:12]} "
                            f"(git {meta.get('git', '?')}), the loaded library is built from {here[:12]}")
         else:
-            per = [(doc[n]["hbm_bytes_per_launch"], e["calls"]) for e in rep for n in [e["name"]]
+            # (multi-layer launches log their layer count behind the instantiation, "... x5": the counter rows are keyed by the instantiation)
+            per = [(doc[n]["hbm_bytes_per_launch"], e["calls"]) for e in rep for n in [e["name"].split(" x")[0]]
                    if kernel_family(n) == top["name"] and n in doc and doc[n].get("hbm_bytes_per_launch")]
             if per:
                 traffic = sum(b * c for b, c in per) / sum(c for _, c in per)

@@ -88,6 +88,13 @@ int ardae_linear(const ardae_linear_args* args, int epilogue, void* stream);
  * ardae_linear_chain_eligible: 1 if the shapes qualify (K = Nout = 256, M % 64 == 0, few row tiles, one epilogue kind). */
 int ardae_linear_chain_eligible(const ardae_linear_args* layers, int nl, int epilogue);
 int ardae_linear_chain(const ardae_linear_args* layers, int nl, int epilogue, void* stream);
+/* The same run LAYER-major for MANY tiles per workgroup (the full-size shard): one launch of the weight-stationary N-row kernel walks all
+ * its row tiles for layer l (the wave's weight slab loaded once per layer, as in a launch of its own), then layer l + 1 on the rows it has
+ * written itself - no hand-over between workgroups, no dispatch ramp / drain between the layers.  Bit-identical to nl calls of ardae_linear.
+ * Eligible: K = Nout = 256, every layer reading its predecessor's Y, one epilogue kind / activation (relu, softplus) / set of operands
+ * (forward layers with a bias only; DACT all with Q or all without; CHAIN). */
+int ardae_linear_wide_layers_eligible(const ardae_linear_args* layers, int nl, int epilogue);
+int ardae_linear_wide_layers(const ardae_linear_args* layers, int nl, int epilogue, void* stream);
 
 
 /* ---- K6w: batched weight gradients  dW[o][i] = sum_pairs sum_m G[m][o] X[m][i]  -------------------------------

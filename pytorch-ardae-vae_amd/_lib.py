@@ -100,6 +100,8 @@ EXPORTS = {
     "ardae_linear": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_void_p]),
     "ardae_linear_chain_eligible": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_int]),
     "ardae_linear_chain": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "ardae_linear_wide_layers_eligible": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_int]),
+    "ardae_linear_wide_layers": (ctypes.c_int, [ctypes.POINTER(LinearArgs), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "ardae_wgrad_splits": (ctypes.c_int, [ctypes.c_int] * 4),
     "ardae_wgrad_batch": (ctypes.c_int, [ctypes.POINTER(WgradProblem), ctypes.c_int, ctypes.c_void_p]),
     "ardae_latent_perturb": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 4),

@@ -37,6 +37,13 @@ int ardae_linear(const ardae_linear_args* args, int epilogue, void* stream) {
   return launch_linear(*args, epilogue, (hipStream_t)stream);
 }
 
+int ardae_linear_wide_layers_eligible(const ardae_linear_args* layers, int nl, int epilogue) {
+  return layers && linear_wide_layers_eligible(layers, nl, epilogue) ? 1 : 0;
+}
+int ardae_linear_wide_layers(const ardae_linear_args* layers, int nl, int epilogue, void* stream) {
+  ARDAE_CHECK_ARG(layers != nullptr, "ardae_linear_wide_layers: layers is NULL");
+  return launch_linear_wide_layers(layers, nl, epilogue, (hipStream_t)stream);
+}
 int ardae_linear_chain_eligible(const ardae_linear_args* layers, int nl, int epilogue) {
   return (layers != nullptr && linear_chain_eligible(layers, nl, epilogue)) ? 1 : 0;
 }

@@ -202,6 +202,14 @@ struct LayerRun {
       if (n >= 2) {
         ARDAE_TRY(launch_linear_chain(v.data() + i, (int)n, epi, st));
         i += n;
+        continue;
+      }
+      // many tiles per workgroup: the same run layer-major in the weight-stationary kernel (one launch, the slab loaded once per layer)
+      size_t m = std::min<size_t>(v.size() - i, 6);
+      while (m >= 2 && !linear_wide_layers_eligible(v.data() + i, (int)m, epi)) --m;
+      if (m >= 2) {
+        ARDAE_TRY(launch_linear_wide_layers(v.data() + i, (int)m, epi, st));
+        i += m;
       } else {
         ARDAE_TRY(launch_linear(v[i], epi, st));
         i += 1;

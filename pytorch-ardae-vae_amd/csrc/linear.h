@@ -40,6 +40,9 @@ int launch_linear_small(const LinArgs& a, int epi, hipStream_t st);
 int launch_linear_pair(const LinArgs& a0, const LinArgs& a1, int epi, hipStream_t st);
 // a dependent CHAIN of per-image levels (one or two independent problems each, probs[i] on level level_of[i], levels ascending) in
 // ONE launch with a row-block counter hand-over between the levels (linear_small.hip); counters: 3 ceil(M / 32) floats of scratch
+// a run of row-local K = Nout = 256 layers as one layer-major launch of the weight-stationary kernel (linear_wide.hip)
+bool linear_wide_layers_eligible(const LinArgs* L, int nl, int epi);
+int launch_linear_wide_layers(const LinArgs* L, int nl, int epi, hipStream_t st);
 constexpr int LINEAR_SMALL_CHAIN_COUNTER_WORDS = 32;     // scratch words per 16-row block (one 128-byte line): counters = 32 x ceil(M / 16) words
 int launch_linear_small_chain(const LinArgs* probs, const int* epis, const int* level_of, int nprob, float* counters, hipStream_t st);
 // streaming kernel for N-row layers with Nout <= 32 and K = 256 (linear_narrow.hip): HBM-bound

@@ -1,5 +1,7 @@
 // Dispatcher of the software-pipelined wide linear kernel (template code: linear_wide_kernel.h; the kernels are
 // instantiated per epilogue / activation in linear_wide_inst_*.hip so that the build parallelises).
+#include <string.h>
+
 #include "linear_wide_kernel.h"
 
 namespace ardae {
@@ -94,6 +96,40 @@ bool linear_wide_eligible(const LinArgs& a, int epi) {
   const int64_t ldmax = std::max<int64_t>({a.ldY, a.ldY2, a.ldS, a.ldR, a.ldQ});
   if (ldmax * a.M * 4 >= (int64_t)1 << 32) return false;   // every epilogue tensor behind a 32-bit buffer offset
   return true;
+}
+
+// A run of consecutive row-local N-row layers as ONE layer-major launch (linear_wide_layers_kernel): K = Nout = 256, one epilogue kind,
+// one activation, the same optional operands in every layer (forward: bias only; DACT: all with Q or none; CHAIN), every layer reading
+// its predecessor's Y.  ARDAE_WIDE_LAYERS=0: off (A/B).
+bool linear_wide_layers_eligible(const LinArgs* L, int nl, int epi) {
+  static const bool on = !(debug_knob("ARDAE_WIDE_LAYERS") && atoi(debug_knob("ARDAE_WIDE_LAYERS")) == 0);
+  if (!on || nl < 2 || nl > WIDE_MAXL || !(epi == EPI_ACT || epi == EPI_DACT || epi == EPI_CHAIN)) return false;
+  const LinArgs& f = L[0];
+  if (f.act != ACT_SOFTPLUS && !(f.act == ACT_RELU && epi != EPI_CHAIN)) return false;
+  for (int l = 0; l < nl; ++l) {
+    const LinArgs& a = L[l];
+    if (!linear_wide_eligible(a, epi)) return false;
+    if (a.M != f.M || a.Nout != 256 || a.nsrc != 1 || a.src[0].K != 256 || a.act != f.act || !a.Y) return false;
+    if (l > 0 && (a.src[0].x != L[l - 1].Y || a.src[0].ld != L[l - 1].ldY)) return false;
+    if (epi == EPI_ACT && (a.rowbias || a.rowscale || a.Y2)) return false;             // plain forward layers
+    if (epi == EPI_DACT && ((a.Q != nullptr) != (f.Q != nullptr))) return false;
+    if (epi == EPI_CHAIN && (!a.Y2 || !a.R)) return false;
+    // a layer must not write what a LATER layer of the run still reads as an operand from another workgroup's rows: all operands are
+    // row-local (S, Q, R rows of the tile), so only the chaining above matters
+  }
+  return true;
+}
+
+int launch_linear_wide_layers(const LinArgs* L, int nl, int epi, hipStream_t st) {
+  ARDAE_CHECK_ARG(linear_wide_layers_eligible(L, nl, epi), "linear_wide_layers: run not eligible");
+  const int act = L[0].act;
+  if (epi == EPI_ACT) return act == ACT_SOFTPLUS ? launch_wide_layers<8, 4, 2, EPI_ACT, ACT_SOFTPLUS, false, false>(L, nl, st)
+                                                 : launch_wide_layers<8, 4, 2, EPI_ACT, ACT_RELU, false, false>(L, nl, st);
+  if (epi == EPI_CHAIN) return launch_wide_layers<8, 4, 2, EPI_CHAIN, ACT_SOFTPLUS, false, false>(L, nl, st);
+  if (L[0].Q) return act == ACT_SOFTPLUS ? launch_wide_layers<8, 4, 2, EPI_DACT, ACT_SOFTPLUS, true, false>(L, nl, st)
+                                         : launch_wide_layers<8, 4, 2, EPI_DACT, ACT_RELU, true, false>(L, nl, st);
+  return act == ACT_SOFTPLUS ? launch_wide_layers<8, 4, 2, EPI_DACT, ACT_SOFTPLUS, false, false>(L, nl, st)
+                             : launch_wide_layers<8, 4, 2, EPI_DACT, ACT_RELU, false, false>(L, nl, st);
 }
 
 int launch_linear_wide(const LinArgs& a, int epi, hipStream_t st) {

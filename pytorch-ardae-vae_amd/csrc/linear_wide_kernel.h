@@ -553,7 +553,7 @@ template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
 // tpg > 0 ("group tiles"): the per-image row-bias groups are no multiple of the 64-row tile (nz_cdae 625 of the shipped recipes).  Tiles are
 // then laid out per group - tpg = ceil(rows_per_group / 64) of them, the last one shifted back so that it ENDS with its group - so that no
 // tile meets two images; the rows two tiles of a group share are computed (identically) and written twice, +2.4 % work at 625 rows.
-__global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, int nrt, int ncp, int tpg) {
+__device__ __forceinline__ void wide_body(const LinArgs& a, int nrt, int ncp, int tpg) {
   using PG = PanelGeo<NCH>;
   using EPI_T = WideEpi<EPI, ACT, F1, F2, NJ>;
   using SC = Sched<NCH, NP, NJ, EPI_T::NLT, EPI_T::NST, true>;
@@ -680,6 +680,31 @@ __global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, in
 #endif
 }
 
+template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
+__global__ __launch_bounds__(256, 1) void linear_wide_kernel(const LinArgs a, int nrt, int ncp, int tpg) {
+  wide_body<NCH, NP, NJ, EPI, ACT, F1, F2>(a, nrt, ncp, tpg);
+}
+
+// A RUN of row-local layers of one kind (each reading its predecessor's output; same shape, epilogue, activation, flags) in ONE launch,
+// LAYER-major: the workgroup walks all its row tiles for layer l - exactly wide_body, the wave's weight slab loaded once per layer - and
+// then goes on to layer l + 1, whose rows it has written itself (a workgroup keeps its row tiles and its column panel: nothing is handed
+// over between workgroups, so there is no grid-wide dependency; its own stores are complete (vmcnt) and ordered by a workgroup barrier
+// before its own loads of them).  Against one launch per layer this removes the dispatch ramp / drain and the wait for the slowest
+// workgroup at every layer boundary; the arithmetic is the per-layer kernel's, bit for bit.  (linear_chain_kernel is the TILE-major form
+// for few tiles per workgroup: it keeps the tile in LDS but reloads the slab per tile and layer.)
+constexpr int WIDE_MAXL = 6;
+struct WideLayers {
+  int nl;
+  LinArgs L[WIDE_MAXL];
+};
+template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
+__global__ __launch_bounds__(256, 1) void linear_wide_layers_kernel(const WideLayers c, int nrt, int ncp, int tpg) {
+  for (int l = 0; l < c.nl; ++l) {
+    wide_body<NCH, NP, NJ, EPI, ACT, F1, F2>(c.L[l], nrt, ncp, tpg);      // ends with every wave's s_waitcnt vmcnt(0)
+    __syncthreads();
+  }
+}
+
 int wide_grid(int ntiles, int ncp);
 
 template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
@@ -706,6 +731,49 @@ int launch_wide(const LinArgs& a, hipStream_t st) {
   return 0;
 }
 
+
+template <int NCH, int NP, int NJ, int EPI, int ACT, bool F1, bool F2>
+int launch_wide_layers(const LinArgs* L, int nl, hipStream_t st) {
+  const LinArgs& a = L[0];
+  const int ncp = a.Nout / (128 * NJ);
+  const int nrt = a.M / WBM;
+  const int grid = wide_grid(nrt * ncp, ncp);
+  WideLayers c;
+  memset(&c, 0, sizeof(c));
+  c.nl = nl;
+  for (int l = 0; l < nl; ++l) c.L[l] = L[l];
+  if (g_prof_enabled) {
+    char name[112];
+    snprintf(name, sizeof(name), "linear_wide_layers_kernel<%d, %d, %d, %d, %d, %s, %s> x%d", NCH, NP, NJ, EPI, ACT, F1 ? "true" : "false", F2 ? "true" : "false", nl);
+    double fl = 0, by = 0;
+    for (int l = 0; l < nl; ++l) {
+      const double K = L[l].src[0].K;
+      const double tensors = 1.0 + (L[l].Y2 ? 1 : 0) + ((EPI == EPI_DACT || EPI == EPI_CHAIN) ? 1 : 0) + ((EPI == EPI_CHAIN) ? 1 : 0) + ((EPI == EPI_DACT && L[l].Q) ? 1 : 0);
+      fl += 2.0 * a.M * (double)a.Nout * K;
+      by += 4.0 * ((double)a.M * K + tensors * a.M * (double)a.Nout + K * a.Nout);
+    }
+    prof_begin(st, name, fl, by);
+  }
+  hipLaunchKernelGGL((linear_wide_layers_kernel<NCH, NP, NJ, EPI, ACT, F1, F2>), dim3(grid), dim3(256), 0, st, c, nrt, ncp, 0);
+  prof_end(st);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// the layer runs of the cDAE update at h = 256: A_2.., the score pass (DACT), the forward-mode pass (CHAIN), the backward pass (DACT + Q)
+#define ARDAE_WIDE_LAYERS_FOR(X)                          \
+  X(8, 4, 2, EPI_ACT, ACT_SOFTPLUS, false, false)         \
+  X(8, 4, 2, EPI_ACT, ACT_RELU, false, false)             \
+  X(8, 4, 2, EPI_DACT, ACT_SOFTPLUS, false, false)        \
+  X(8, 4, 2, EPI_DACT, ACT_SOFTPLUS, true, false)         \
+  X(8, 4, 2, EPI_DACT, ACT_RELU, false, false)            \
+  X(8, 4, 2, EPI_DACT, ACT_RELU, true, false)             \
+  X(8, 4, 2, EPI_CHAIN, ACT_SOFTPLUS, false, false)
+#define ARDAE_WIDE_LAYERS_EXTERN(NCH, NP, NJ, EPI, ACT, F1, F2) extern template int launch_wide_layers<NCH, NP, NJ, EPI, ACT, F1, F2>(const LinArgs*, int, hipStream_t);
+#define ARDAE_WIDE_LAYERS_INSTANTIATE(NCH, NP, NJ, EPI, ACT, F1, F2) template int launch_wide_layers<NCH, NP, NJ, EPI, ACT, F1, F2>(const LinArgs*, int, hipStream_t);
+#ifndef ARDAE_WIDE_INST_TU
+ARDAE_WIDE_LAYERS_FOR(ARDAE_WIDE_LAYERS_EXTERN)
+#endif
 
 // explicit instantiations live in linear_wide_inst_*.hip
 #define ARDAE_WIDE_FOR_GEOS(X, EPI, ACT, F1, F2) \

@@ -509,6 +509,83 @@ def test_linear_chain_kernel_equals_per_layer_launches(M, kind, nl):
         assert torch.equal(csa, csb)
 
 
+@pytest.mark.parametrize("M", [131072, 80000, 32768])
+@pytest.mark.parametrize("kind", ["act", "dact", "dact_q", "chain"])
+@pytest.mark.parametrize("nl", [2, 5])
+def test_linear_wide_layers_kernel_equals_per_layer_launches(M, kind, nl):
+    """linear_wide_layers_kernel (a row-local run of h x h layers LAYER-major in one launch of the weight-stationary kernel: a workgroup
+    walks all its row tiles for layer l, then reads back what it wrote for layer l + 1) against nl launches of ardae_linear: bit-identical,
+    every tensor of every layer.  131072 rows = config #2's shard (8 tiles per workgroup), 80000 = the shipped recipes' 128 x 625 (1250
+    tiles: workgroups with 4 and 5 tiles), 32768 = 2 tiles per workgroup; the backward run in place (Y = Q), the last CHAIN layer with per-tile
+    column sums.  Run twice: a second pass over the same buffers must not see stale rows."""
+    h, act = 256, 2
+    g = torch.Generator(device="cuda").manual_seed(M + nl)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    X = rn(M, h)
+    wps = [pack(rn(h, h) / h ** 0.5) for _ in range(nl)]
+    S = [torch.nn.functional.softplus(rn(M, h) * 3) for _ in range(nl)]
+    R = [rn(M, h) for _ in range(nl)]
+    Q0 = [rn(M, h) for _ in range(nl)]
+    bias = [rn(h) for _ in range(nl)]
+    epi = {"act": L.EPI_ACT, "dact": L.EPI_DACT, "dact_q": L.EPI_DACT, "chain": L.EPI_CHAIN}[kind]
+    ntile = M // 64
+
+    def build():
+        Y = [torch.full((M, h), float("nan"), device="cuda") for _ in range(nl)]
+        Y2 = [torch.full((M, h), float("nan"), device="cuda") for _ in range(nl)]
+        Q = [q.clone() for q in Q0]
+        cs = torch.full((ntile, h), float("nan"), device="cuda")
+        arr = (L.LinearArgs * nl)()
+        for l in range(nl):
+            x = X if l == 0 else Y[l - 1]
+            if kind == "act":
+                a = _make_args(M, h, x, wps[l], act=act, bias=bias[l], Y=Y[l])
+            elif kind == "dact":
+                a = _make_args(M, h, x, wps[l], act=act, S=S[l], Y=Y[l])
+            elif kind == "dact_q":
+                Y[l] = Q[l]
+                a = _make_args(M, h, x, wps[l], act=act, S=S[l], Q=Q[l], Y=Q[l])
+            else:
+                kw = dict(act=act, S=S[l], R=R[l], Y=Y[l], Y2=Y2[l])
+                if l == nl - 1:
+                    kw.update(colsum=cs)
+                a = _make_args(M, h, x, wps[l], **kw)
+            arr[l] = a
+        return arr, Y, Y2, cs
+
+    lib = L.lib()
+    arr, Ya, Y2a, csa = build()
+    for l in range(nl):
+        L.check(lib.ardae_linear(ctypes.byref(arr[l]), epi, L.stream_ptr()), "ardae_linear")
+    arr, Yb, Y2b, csb = build()
+    assert lib.ardae_linear_wide_layers_eligible(arr, nl, epi) == 1
+    L.check(lib.ardae_linear_wide_layers(arr, nl, epi, L.stream_ptr()), "ardae_linear_wide_layers")
+    torch.cuda.synchronize()
+    for l in range(nl):
+        assert not torch.isnan(Yb[l]).any(), f"layer {l}: rows never written"
+        assert torch.equal(Ya[l], Yb[l]), f"Y of layer {l}: max |diff| {float((Ya[l] - Yb[l]).abs().max())}"
+        if kind == "chain":
+            assert torch.equal(Y2a[l], Y2b[l]), f"Y2 of layer {l}"
+    if kind == "chain":
+        assert torch.equal(csa, csb)
+    if kind != "dact_q":        # (in place the second pass would start from the first one's results)
+        Ykeep = [y.clone() for y in Yb]
+        for y in Yb:
+            y.fill_(float("nan"))
+        L.check(lib.ardae_linear_wide_layers(arr, nl, epi, L.stream_ptr()), "ardae_linear_wide_layers")
+        torch.cuda.synchronize()
+        for l in range(nl):
+            assert torch.equal(Yb[l], Ykeep[l]), f"second pass, layer {l}"
+    # what it refuses: a layer that does not read its predecessor's output, mixed operands
+    if kind == "dact_q" and nl == 2:
+        arr2, _, _, _ = build()
+        arr2[1].Q = None
+        assert lib.ardae_linear_wide_layers_eligible(arr2, nl, epi) == 0
+        arr3, _, _, _ = build()
+        arr3[1].src[0].x = X.data_ptr()
+        assert lib.ardae_linear_wide_layers_eligible(arr3, nl, epi) == 0
+
+
 def test_linear_chain_refuses_what_it_cannot_run():
     h, M = 256, 16384
     X = torch.randn(M, h, device="cuda"); W = pack(torch.randn(h, h, device="cuda"))
