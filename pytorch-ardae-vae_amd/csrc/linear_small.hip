@@ -341,7 +341,9 @@ template <int EPI, int ACT, bool COH>
 __device__ __forceinline__ void small_block16(const LinArgs& a, int bx, int by, float (*red)[4][64]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
-  const int col = by * 16 + c16, row = bx * 16 + 4 * q + wave;      // this lane finishes (row, col): accumulator register `wave` of lane
+  const int col_raw = by * 16 + c16, row = bx * 16 + 4 * q + wave;   // this lane finishes (row, col): accumulator register `wave` of lane
+  const bool cok = col_raw < a.Nout;                                  // ragged column count (h = 300 of the shipped aux recipe, the 100 noise columns)
+  const int col = cok ? col_raw : a.Nout - 1;
   float o1 = 0.f, o2 = 0.f, bcol = 0.f, wsig = 0.f, wv = 0.f;
   if (EPI == EPI_ACT) {
     if (a.bias) bcol = a.bias[col];
@@ -354,33 +356,49 @@ __device__ __forceinline__ void small_block16(const LinArgs& a, int bx, int by, 
     else if (a.Q) o2 = ld_row<COH>(a.Q + (size_t)row * a.ldQ + col);
   }
 
-  const int K = a.src[0].K, T = K >> 3, G = K >> 4;                   // chunks of 8 k (the packed image's unit), steps of 16 k
-  const int gbeg = (G * wave) >> 2, gend = (G * (wave + 1)) >> 2;
-  const f32x4* ap = reinterpret_cast<const f32x4*>(a.src[0].x + (size_t)(bx * 16 + c16) * a.src[0].ld + 4 * q) + 4 * gbeg;          // + 4 per step
-  const f32x4* bp = reinterpret_cast<const f32x4*>(a.src[0].wp) + ((size_t)(by >> 1) * T + 2 * gbeg + (q >> 1)) * 64 + (by & 1) * 16 + c16 + 32 * (q & 1);   // + 128 per step
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  auto run = [&](auto nb) {
-    constexpr int NB = decltype(nb)::value;
-    f32x4 av[NB], bv[NB];
+  // one or two sources (concat inputs: [hidden | noise]); every source's steps of 16 k are split over the four waves.  K % 4 == 0: the
+  // source's last step may be partial - its lanes beyond K load nothing (neither the row, which ends there, nor weight chunks the packed
+  // image does not have) and multiply zeros
 #pragma unroll
-    for (int u = 0; u < NB; ++u) { av[u] = ld_row<COH>(ap + 4 * u); bv[u] = bp[128 * u]; }
-    ap += 4 * NB; bp += 128 * NB;
+  for (int s = 0; s < 2; ++s) {       // (static indices: the chain kernel's argument struct must stay in registers)
+    if (s >= a.nsrc) continue;
+    const int K = a.src[s].K, T = (K + 7) >> 3, Gf = K >> 4, tail = K & 15;     // packed chunks of 8 k; full steps of 16 k; k of a partial last step
+    const int G = Gf + (tail ? 1 : 0);
+    const int gbeg = (G * wave) >> 2, gend = (G * (wave + 1)) >> 2;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(a.src[s].x + (size_t)(bx * 16 + c16) * a.src[s].ld + 4 * q) + 4 * gbeg;          // + 4 per step
+    const f32x4* bp = reinterpret_cast<const f32x4*>(a.src[s].wp) + ((size_t)(by >> 1) * T + 2 * gbeg + (q >> 1)) * 64 + (by & 1) * 16 + c16 + 32 * (q & 1);   // + 128 per step
+    auto run = [&](auto nb) {
+      constexpr int NB = decltype(nb)::value;
+      f32x4 av[NB], bv[NB];
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+      for (int u = 0; u < NB; ++u) { av[u] = ld_row<COH>(ap + 4 * u); bv[u] = bp[128 * u]; }
+      ap += 4 * NB; bp += 128 * NB;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][j], bv[u][j], acc, 0, 0, 0);
-  };
-  int left = gend - gbeg;
-  for (; left >= 8; left -= 8) run(IntTag<8>{});
-  if (left & 4) run(IntTag<4>{});
-  if (left & 2) run(IntTag<2>{});
-  if (left & 1) run(IntTag<1>{});
+      for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][j], bv[u][j], acc, 0, 0, 0);
+    };
+    const bool has_tail = tail != 0 && gend == G && gend > gbeg;      // (uniform per wave) the wave that owns the source's last step
+    int left = gend - gbeg - (has_tail ? 1 : 0);
+    for (; left >= 8; left -= 8) run(IntTag<8>{});
+    if (left & 4) run(IntTag<4>{});
+    if (left & 2) run(IntTag<2>{});
+    if (left & 1) run(IntTag<1>{});
+    if (has_tail) {
+      f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+      if (4 * q < tail) { av = ld_row<COH>(ap); bv = bp[0]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+    }
+  }
 
   // partial sums of the four waves meet in LDS; wave w finishes accumulator register w of every lane: rows 4 q + w
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
   const float v = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+  if (!cok) return;
   if (EPI == EPI_ACT) {
     const float y = act_fwd<ACT>(v + bcol + o1 + o2 * wsig);
     a.Y[(size_t)row * a.ldY + col] = y;
@@ -407,8 +425,10 @@ inline bool small_regular(const LinArgs& a) {
 // what small_block16 assumes, and when it pays: the layer has few 32 x 32 blocks (ARDAE_SMALL16_MAX_BLOCKS, default 64)
 inline bool small_regular16(const LinArgs& a) {
   static const int max_blocks = debug_knob("ARDAE_SMALL16_MAX_BLOCKS") ? atoi(debug_knob("ARDAE_SMALL16_MAX_BLOCKS")) : 64;
-  return a.nsrc == 1 && a.src[0].K >= 16 && a.src[0].K % 16 == 0 && a.src[0].ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.src[0].x) & 15) == 0 &&
-         a.M % 16 == 0 && a.Nout % 16 == 0 && (int64_t)ceil_div(a.M, 32) * ceil_div(a.Nout, 32) <= max_blocks;
+  if (a.nsrc < 1 || a.nsrc > 2 || a.M % 16 || a.Nout < 1 || (int64_t)ceil_div(a.M, 32) * ceil_div(a.Nout, 32) > max_blocks) return false;
+  for (int s = 0; s < a.nsrc; ++s)      // float4 fragments: rows 16-byte aligned, K a multiple of 4 (a partial last step of 16 k is fine)
+    if (a.src[s].K < 4 || a.src[s].K % 4 || a.src[s].ld % 4 || (reinterpret_cast<uintptr_t>(a.src[s].x) & 15)) return false;
+  return true;
 }
 
 template <int EPI, int ACT>
@@ -619,7 +639,7 @@ int launch_small_pair(const LinArgs& a0, const LinArgs& a1, hipStream_t st) {
   }
   const dim3 grid(std::max(ceil_div(a0.M, 32), ceil_div(a1.M, 32)), std::max(ceil_div(a0.Nout, 32), ceil_div(a1.Nout, 32)), 2);
   if (small_fast_on() && small_regular16(a0) && small_regular16(a1))
-    hipLaunchKernelGGL((linear_small16_pair_kernel<EPI, ACT>), dim3(std::max(a0.M, a1.M) / 16, std::max(a0.Nout, a1.Nout) / 16, 2), dim3(256), 0, st, a0, a1);
+    hipLaunchKernelGGL((linear_small16_pair_kernel<EPI, ACT>), dim3(std::max(a0.M, a1.M) / 16, ceil_div(std::max(a0.Nout, a1.Nout), 16), 2), dim3(256), 0, st, a0, a1);
   else if (small_fast_on() && small_regular(a0) && small_regular(a1))
     hipLaunchKernelGGL((linear_small_fast_pair_kernel<EPI, ACT>), grid, dim3(256), 0, st, a0, a1);
   else
@@ -641,7 +661,7 @@ int launch_small(const LinArgs& a, hipStream_t st) {
     prof_begin(st, name, 2.0 * a.M * (double)a.Nout * ksum, 4.0 * ((double)a.M * ksum + tensors * a.M * (double)a.Nout + ksum * a.Nout));
   }
   if (small_fast_on() && small_regular16(a))
-    hipLaunchKernelGGL((linear_small16_kernel<EPI, ACT>), dim3(a.M / 16, a.Nout / 16), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((linear_small16_kernel<EPI, ACT>), dim3(a.M / 16, ceil_div(a.Nout, 16)), dim3(256), 0, st, a);
   else if (small_fast_on() && small_regular(a))
     hipLaunchKernelGGL((linear_small_fast_kernel<EPI, ACT>), dim3(a.M / 32, a.Nout / 32), dim3(256), 0, st, a);
   else

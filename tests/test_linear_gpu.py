@@ -101,6 +101,24 @@ def test_linear_transposed_pack_and_two_sources():
     assert relerr(Y, X1.double() @ Wt.double()) < 2e-5
 
 
+@pytest.mark.parametrize("M,K1,K2,Nout,act", [(64, 256, 100, 256, "softplus"), (128, 256, 100, 256, "relu"), (32, 784, 100, 300, "softplus"), (16, 256, 10, 48, "none"),
+                                              (512, 256, 100, 256, "softplus")])
+def test_linear_two_source_per_image_layers(M, K1, K2, Nout, act):
+    """Concat inputs [hidden | noise] of the per-image sampler layers (models/layers.py:501-515 on a few rows): two (activation, weight)
+    pairs summed into one output - on the 16 x 16 blocks where the layer is small (each source's steps split over the four waves, partial
+    last step for K = 100 / 10), on the generic block otherwise (512 rows); against float64."""
+    g = torch.Generator().manual_seed(M + K1 + K2 + Nout)
+    X1, X2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    W = torch.randn(Nout, K1 + K2, generator=g) / (K1 + K2) ** 0.5
+    b = torch.randn(Nout, generator=g)
+    pre = torch.cat([X1, X2], 1).double() @ W.double().T + b.double()
+    ref = {"none": pre, "relu": pre.clamp(min=0), "softplus": torch.nn.functional.softplus(pre)}[act]
+    Wd = W.cuda()
+    Y = torch.full((M, Nout), float("nan"), device="cuda")
+    run_linear(L.EPI_ACT, M, Nout, [(X1.cuda(), pack(Wd[:, :K1])), (X2.cuda(), pack(Wd[:, K1:]))], act=L.ACT[act], bias=b.cuda(), Y=Y)
+    assert relerr(Y, ref) < 2e-5
+
+
 @pytest.mark.parametrize("M,Nout", [(2048, 1024), (8192, 1024), (6144, 512), (20480, 128)])
 @pytest.mark.parametrize("epi", ["dact", "act_rowbias"])
 def test_linear_wide_kernel_k1024_rolling_slab(M, Nout, epi):
@@ -210,7 +228,8 @@ def test_linear_big_m_epilogues(M, K, Nout, epi, rpg=16):
 @pytest.mark.parametrize("M,K,Nout", [(64, 256, 256),      # 16 blocks of 32 x 32: the 16 x 16 blocks (few rows: small_block16)
                                       (16, 32, 48), (128, 784, 256), (48, 256, 784),     # K = 32: two waves idle; 784 = 49 blocks of 16 columns
                                       (512, 256, 256), (256, 784, 256),                 # 32 x 32 lean blocks (small_block_fast), 24.5 chunks per wave
-                                      (100, 256, 256), (64, 100, 256), (64, 256, 100)])  # ragged rows / K / columns: the generic block
+                                      (64, 100, 256), (64, 256, 100), (128, 300, 300), (32, 784, 300), (48, 20, 36),   # ragged K (a partial last step of 16 k) / ragged columns: still the 16 x 16 blocks
+                                      (100, 256, 256), (64, 102, 256), (512, 256, 100)])  # ragged rows / K % 4 / many ragged blocks: the generic block
 @pytest.mark.parametrize("epi", ["dact", "dact_q", "chain", "act_seed"])
 def test_linear_per_image_kernels(M, K, Nout, epi):
     """The latency kernels of the per-image (B-row) layers (linear_small.hip) - 16 x 16 blocks for layers of at most 64 blocks of 32 x 32,
