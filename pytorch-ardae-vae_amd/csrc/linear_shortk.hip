@@ -100,8 +100,13 @@ struct TailOut { const float* wp; const float* bias; float* Z; int ldz; };
 template <int ACT, int SK_MAXCH, int NOUT2>
 __global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void sampler_tail_kernel(const LinArgs a, const TailOut o0, const TailOut o1, int n2, int cs) {
   // cs (1, 2, 4): few rows - the hidden layer's column blocks of a 32-row block are split over cs waves (each a chain of 544 / cs MFMAs
-  // instead of 544), whose partial latent-space sums meet in LDS; the workgroup then holds 4 / cs row blocks
+  // instead of 544), whose partial latent-space sums meet in LDS; the workgroup then holds 4 / cs row blocks.
+  // The latent-space sum over the hidden columns has ONE order for every cs (round 4: a sample's z must not depend on how many rows the
+  // launch has, i.e. on the images per rank): the column blocks form FOUR groups, group g = blocks [g nblk / 4, (g + 1) nblk / 4), each
+  // summed block by block from zero, and z = ((p0 + p1) + p2) + p3 + bias - in one wave's registers (cs = 1), or with the groups of
+  // the other waves handed over through LDS (cs = 2: wave 1 hands p2 and p3 over separately; cs = 4: one group per wave).
   __shared__ float tile[4][32 * ST_LD];
+  __shared__ float part[4][NOUT2][2][32 * ST_LD];      // a wave's finished groups for the wave that adds them up (cs > 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
   const int cpart = wave & (cs - 1), rbi = wave / cs;
@@ -126,11 +131,14 @@ __global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void s
   const float* rbrow1 = (rb_two && split < 32) ? rbrow + a.rowbias_ld : rbrow;
   float* T = tile[wave];
 
-  f32x16 zacc[NOUT2];
+  f32x16 zacc[NOUT2];                    // the current group's sum (the sum of the wave's finished groups waits in LDS: part[wave][o][0])
 #pragma unroll
   for (int o = 0; o < NOUT2; ++o)
 #pragma unroll
     for (int r = 0; r < 16; ++r) zacc[o][r] = 0.f;
+  const bool adder = cs == 1 || cpart == 0;
+  const int gpw = 4 / cs;                // groups per wave
+  int grp = cpart * gpw;                 // the group the wave is summing; its last block is ((grp + 1) nblk) / 4 - 1
   f32x4 b0[SK_MAXCH], b1[SK_MAXCH];
   auto load_b = [&](f32x4 (&b)[SK_MAXCH], int nb) {
 #pragma unroll
@@ -177,9 +185,35 @@ __global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void s
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();     // the tile is rewritten by the next block
+    // group boundaries (wave-uniform): fold the finished group(s) - empty groups (nblk < 4) add an exact zero
+    while (grp < (cpart + 1) * gpw && nb + 1 == ((grp + 1) * nblk) / 4) {
+      const int gl = grp - cpart * gpw;            // index of the group inside the wave
+#pragma unroll
+      for (int o = 0; o < NOUT2; ++o) {
+        // the adding wave keeps (p0 + p1 ..) in its slot 0; the others hand every group over as it is
+        float* P = part[wave][o][adder ? 0 : gl];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int e = ((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31;
+          float v = zacc[o][r];
+          if (adder && gl > 0) v = P[e] + v;
+          P[e] = v;
+          zacc[o][r] = 0.f;
+        }
+      }
+      ++grp;
+    }
   };
   (void)nch2;
-  const int nb_lo = cpart * (nblk / cs), nb_hi = nb_lo + nblk / cs;
+  const int nb_lo = (cpart * gpw * nblk) / 4, nb_hi = ((cpart + 1) * gpw * nblk) / 4;
+  // groups that end before the wave's first block (empty leading groups when nblk < 4): nothing to add, move on
+  while (grp < (cpart + 1) * gpw && ((grp + 1) * nblk) / 4 <= nb_lo) {
+#pragma unroll
+    for (int o = 0; o < NOUT2; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave][o][adder ? 0 : grp - cpart * gpw][((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31] = 0.f;
+    ++grp;
+  }
   load_b(b0, nb_lo);
   for (int nb = nb_lo; nb < nb_hi; nb += 2) {
     if (nb + 1 < nb_hi) load_b(b1, nb + 1);
@@ -188,22 +222,18 @@ __global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void s
     if (nb + 2 < nb_hi) load_b(b0, nb + 2);
     block(b1, nb + 1);
   }
-  if (cs > 1) {      // partial sums over the column parts: wave (rbi, 0) adds those of (rbi, 1 .. cs - 1), in order
+  if (cs > 1) __syncthreads();
+  if (adder) {       // its own groups' sum, then (cs > 1) the groups of waves (rbi, 1 .. cs - 1) in group order
 #pragma unroll
     for (int o = 0; o < NOUT2; ++o) {
-      if (cpart != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31] = zacc[o][r];
-      }
-      __syncthreads();
-      if (cpart == 0) {
-        for (int c = 1; c < cs; ++c) {
-          const float* Tc = tile[wave + c];
+      for (int r = 0; r < 16; ++r) zacc[o][r] = part[wave][o][0][((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31];
+      for (int c = 1; c < cs; ++c)
+        for (int gl = 0; gl < gpw; ++gl) {
+          const float* P = part[wave + c][o][gl];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) zacc[o][r] += Tc[((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31];
+          for (int r = 0; r < 16; ++r) zacc[o][r] += P[((r & 3) + 8 * (r >> 2) + 4 * hh) * ST_LD + l31];
         }
-      }
-      if (NOUT2 > 1) __syncthreads();
     }
   }
   if (l31 < n2 && cpart == 0) {

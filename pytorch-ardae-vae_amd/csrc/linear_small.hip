@@ -79,46 +79,50 @@ __device__ __forceinline__ void small_block(const LinArgs& a, int bx, int by, fl
     for (int i = 0; i < 4; ++i) o2[i] = a.R[(size_t)rowv[i] * a.ldR + col];
   }
 
-  // ---- K loop over the flat chunk list of both sources; wave w owns a contiguous quarter
-  SmallSrc s0, s1;
-  s0.x = a.src[0].x; s0.wp = a.src[0].wp; s0.ld = a.src[0].ld; s0.K = a.src[0].K; s0.kchunks = (s0.K + 7) >> 3;
-  s0.vec = ((s0.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(s0.x) & 15) == 0);
-  s1 = s0;
-  int n1 = 0;
-  if (a.nsrc > 1) {
-    s1.x = a.src[1].x; s1.wp = a.src[1].wp; s1.ld = a.src[1].ld; s1.K = a.src[1].K; s1.kchunks = (s1.K + 7) >> 3;
-    s1.vec = ((s1.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(s1.x) & 15) == 0);
-    n1 = s1.kchunks;
-  }
-  const int n0 = s0.kchunks, T = n0 + n1;
-  const int cbeg = (T * wave) >> 2, cend = (T * (wave + 1)) >> 2;
-
-  auto load_chunk = [&](int c, f32x4& av, f32x4& bv) {
-    const bool live = c < cend;
-    const int cc = live ? c : cend - 1;       // clamped: a dead chunk re-reads a valid address and contributes A = 0
-    const bool second = cc >= n0;
-    const SmallSrc& s = second ? s1 : s0;
-    const int kc = second ? cc - n0 : cc;
-    const int k = kc * 8 + 4 * hh;
-    bv = *reinterpret_cast<const f32x4*>(s.wp + ((size_t)nb * s.kchunks + kc) * 256 + lane * 4);
-    const float* p = s.x + (size_t)arow * s.ld + k;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s.vec && k + 4 <= s.K) {
-      v = *reinterpret_cast<const f32x4*>(p);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (k + j < s.K) v[j] = p[j];
-    }
-    if (!live) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    av = v;
-  };
-
+  // ---- K loop: source by source (concat inputs: [hidden | noise]); every source's STEPS of 16 k (chunk pairs) are split over the four
+  //      waves and multiplied in the canonical order of SmallFrag::mac - the same sequence of products per accumulator element as in
+  //      small_block_fast and small_block16, so that a row's bits do not depend on which block shape its layer ran on
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32x4 a0[SB], b0[SB], a1[SB], b1[SB];
-  if (cbeg < cend) {
+#pragma unroll
+  for (int si = 0; si < 2; ++si) {
+    if (si >= a.nsrc) continue;
+    SmallSrc s;
+    s.x = a.src[si].x; s.wp = a.src[si].wp; s.ld = a.src[si].ld; s.K = a.src[si].K; s.kchunks = (s.K + 7) >> 3;
+    s.vec = ((s.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
+    const int G = (s.kchunks + 1) >> 1;
+    const int cbeg = 2 * ((G * wave) >> 2), cend = min(2 * ((G * (wave + 1)) >> 2), s.kchunks);
+    if (cbeg >= cend) continue;
+
+    auto load_chunk = [&](int c, f32x4& av, f32x4& bv) {
+      const bool live = c < cend;
+      const int kc = live ? c : cend - 1;       // clamped: a dead chunk re-reads a valid address and contributes A = 0
+      const int k = kc * 8 + 4 * hh;
+      bv = *reinterpret_cast<const f32x4*>(s.wp + ((size_t)nb * s.kchunks + kc) * 256 + lane * 4);
+      const float* p = s.x + (size_t)arow * s.ld + k;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (s.vec && k + 4 <= s.K) {
+        v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k + j < s.K) v[j] = p[j];
+      }
+      if (!live) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      av = v;
+    };
+    auto mac = [&](const f32x4 (&av)[SB], const f32x4 (&bv)[SB]) {
+#pragma unroll
+      for (int u = 0; u < SB; u += 2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], bv[u][q], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u + 1][q], bv[u + 1][q], acc, 0, 0, 0);
+        }
+    };
+
+    f32x4 a0[SB], b0[SB], a1[SB], b1[SB];
 #pragma unroll
     for (int u = 0; u < SB; ++u) load_chunk(cbeg + u, a0[u], b0[u]);
     for (int c = cbeg; c < cend; c += 2 * SB) {
@@ -127,19 +131,13 @@ __device__ __forceinline__ void small_block(const LinArgs& a, int bx, int by, fl
 #pragma unroll
         for (int u = 0; u < SB; ++u) load_chunk(c + SB + u, a1[u], b1[u]);
       }
-#pragma unroll
-      for (int u = 0; u < SB; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][q], b0[u][q], acc, 0, 0, 0);
+      mac(a0, b0);
       if (!more1) break;
       if (c + 2 * SB < cend) {
 #pragma unroll
         for (int u = 0; u < SB; ++u) load_chunk(c + 2 * SB + u, a0[u], b0[u]);
       }
-#pragma unroll
-      for (int u = 0; u < SB; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][q], b1[u][q], acc, 0, 0, 0);
+      mac(a1, b1);
     }
   }
 
@@ -206,11 +204,24 @@ struct SmallFrag {            // NB chunks (8 k each) of A and packed-B fragment
     for (int u = 0; u < NB; ++u) { a[u] = ld_row<COH>(ap + 2 * u); b[u] = bp[64 * u]; }
     ap += 2 * NB; bp += 64 * NB;
   }
+  // CANONICAL k ORDER (round 4; see the note above small_block16): a step of 16 k = the chunk pair (2 g, 2 g + 1), and inside it MFMA j of
+  // chunk 2 g, then MFMA j of chunk 2 g + 1, j = 0 .. 3 - the products enter the accumulator in the order k = 16 g + j + {0, 4, 8, 12},
+  // which is the order ONE v_mfma_f32_16x16x4_f32 of small_block16 adds them in.  A batch starts at an even chunk; a last odd chunk
+  // (K % 16 == 8) runs alone, where the 16 x 16 block multiplies zeros.
   __device__ __forceinline__ void mac(f32x16& acc) const {
+    static_assert(NB == 1 || NB % 2 == 0, "chunk pairs");
+    if (NB == 1) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][q], b[0][q], acc, 0, 0, 0);
+    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], b[u][q], acc, 0, 0, 0);
+      for (int u = 0; u + 1 < NB; u += 2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], b[u][q], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u + 1][q], b[u + 1][q], acc, 0, 0, 0);
+        }
+    }
   }
 };
 
@@ -257,8 +268,8 @@ __device__ __forceinline__ void small_block_fast(const LinArgs& a, int bx, int b
     }
   }
 
-  const int K = a.src[0].K, T = K >> 3;
-  const int cbeg = (T * wave) >> 2, cend = (T * (wave + 1)) >> 2;
+  const int K = a.src[0].K, T = K >> 3, G = (T + 1) >> 1;     // chunks of 8 k; steps of 16 k (the last one may hold one chunk)
+  const int cbeg = 2 * ((G * wave) >> 2), cend = min(2 * ((G * (wave + 1)) >> 2), T);      // the wave's quarter of the STEPS, as in small_block16
   const f32x4* ap = reinterpret_cast<const f32x4*>(a.src[0].x + (size_t)(bx * 32 + l31) * a.src[0].ld + 4 * hh) + 2 * cbeg;   // + 2 per chunk
   const f32x4* bp = reinterpret_cast<const f32x4*>(a.src[0].wp) + ((size_t)by * T + cbeg) * 64 + lane;                             // + 64 per chunk
   f32x16 acc;
@@ -335,8 +346,12 @@ __device__ __forceinline__ void small_block_fast(const LinArgs& a, int bx, int b
 // four times the workgroups, a quarter of the bytes and of the matrix time each (v_mfma_f32_16x16x4_f32, 16 per wave at K = 256).
 // Lane (c = lane % 16, q = lane / 16) of wave w, step g (16 k): ONE float4 of A (row c, k = 16 g + 4 q ..+3: the four q-lanes of a row read
 // 64 contiguous bytes) and ONE float4 of the packed weights (chunk 2 g + q / 2, half q % 2: the same four k), then four MFMAs - MFMA j
-// multiplies k = 16 g + 4 q + j over q = 0..3.  The sum over k therefore runs in a different order than in the 32 x 32 blocks: results
-// agree to rounding, not bit for bit.
+// multiplies k = 16 g + 4 q + j over q = 0..3.  An FP32 MFMA is a chain of fused multiply-adds over its k in ascending order, for both
+// shapes (scratch/mfma/order.hip on an MI355X: 204800 / 204800 and 51200 / 51200 elements equal to that model bit for bit, and one
+// 16 x 16 x 4 == two 32 x 32 x 2 on k pairs (0, 1), (2, 3)), so the 32 x 32 blocks can - and since round 4 do - add the SAME sequence of
+// products per output element: same split of a source's 16-k steps over the four waves, inside a step k = 16 g + j + {0, 4, 8, 12} for
+// j = 0 .. 3 (SmallFrag::mac), same (w0 + w1) + (w2 + w3) tree over the waves' partial sums.  A row's bits therefore do not depend on the
+// block shape, i.e. not on how many rows (images per rank) the layer has: tests/test_linear_gpu.py::test_linear_per_image_blocks_bit_identical.
 template <int EPI, int ACT, bool COH>
 __device__ __forceinline__ void small_block16(const LinArgs& a, int bx, int by, float (*red)[4][64]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -964,6 +964,32 @@ def test_nrow_sampler_fused_tail_vs_oracle(B, nz, nonlin):
     assert float((z.reshape(B * nz, -1).cpu() - ref.reshape(B * nz, -1).float()).abs().max()) < 5e-4
 
 
+@pytest.mark.parametrize("nonlin", ["softplus", "relu"])
+def test_sampler_bits_do_not_depend_on_images_per_launch(nonlin):
+    """"results independent of R".  A shard of the image batch must give each of its images the bits the whole batch gives
+    it: the per-image trunk (784 -> h ..., linear_small.hip: 16 x 16 blocks for few rows, 32 x 32 otherwise - one k order since round 4)
+    and the fused N-row sampler tail (its latent-space sum over the hidden columns is split over 1 / 2 / 4 waves depending on the row
+    count - four column groups in one order since round 4).  512 images x 256 samples against its shards of 256 / 128 / 64 / 32 images
+    (the 2 / 4 / 8 / 16-rank shards of config #2), for z = forward_hidden(x, nz) and z0 = encode(x, std=0)."""
+    mc = O.ModelCfg("mnist", 784, 100, 256, 32, 2, nonlin)
+    pm = O.init_params(O.model_param_spec(mc), 7, O.model_init_special(mc))
+    model, _ = build(mc, O.CdaeCfg("grad", 32, 32, 64, 2))
+    model.load_state_dict(pm)
+    model = model.to("cuda")
+    g = torch.Generator().manual_seed(11)
+    B, nz = 512, 256
+    x = (torch.rand(B, 784, generator=g) < 0.2).float().cuda()
+    noise = torch.randn(B * nz, mc.noise_dim, generator=g).cuda()
+    z = model.forward_hidden(x, nz=nz, noise=noise).clone()
+    z0 = model.encode(x, std=0).clone()
+    assert not torch.isnan(z).any()
+    for b, off in ((256, 256), (128, 128), (64, 448), (32, 96)):
+        zs = model.forward_hidden(x[off:off + b].contiguous(), nz=nz, noise=noise[off * nz:(off + b) * nz].contiguous())
+        assert torch.equal(zs, z[off:off + b]), (b, float((zs - z[off:off + b]).abs().max()))
+        z0s = model.encode(x[off:off + b].contiguous(), std=0)
+        assert torch.equal(z0s.reshape(b, -1), z0.reshape(B, -1)[off:off + b]), b
+
+
 @pytest.mark.parametrize("m_opt,d_opt", [("amsgrad", "adam"), ("rmsprop", "sgd"), ("sgd", "amsgrad")])
 def test_checkpoint_roundtrip_other_optimizers(tmp_path, m_opt, d_opt):
     """The four --m-optimizer / --d-optimizer choices keep torch.optim's state_dict() layouts (exp_avg / exp_avg_sq / max_exp_avg_sq,

@@ -237,6 +237,50 @@ def test_linear_per_image_kernels(M, K, Nout, epi):
     test_linear_big_m_epilogues(M, K, Nout, epi, rpg=4 if M % 4 == 0 else 1)
 
 
+@pytest.mark.parametrize("Ks,Nout", [((256,), 256), ((784,), 256), ((256,), 784), ((256,), 32), ((100,), 256), ((24,), 64), ((8,), 32),
+                                     ((256, 100), 256), ((256, 10), 256), ((784, 100), 300), ((40, 12), 48)])
+@pytest.mark.parametrize("epi", ["act", "dact_q", "chain"])
+def test_linear_per_image_blocks_bit_identical(Ks, Nout, epi):
+    """A per-image (B-row) layer gives a row the SAME BITS whatever block shape it runs on, i.e. however many rows (images per rank) the
+    launch has: 16 x 16 blocks (few rows), the lean 32 x 32 block (regular shapes) and the generic 32 x 32 block (ragged rows / K /
+    two sources) add one sequence of products per output element (linear_small.hip, `CANONICAL k ORDER`; an FP32 MFMA is a chain of
+    fused multiply-adds over its k ascending - scratch/mfma/order.hip).  This is what makes the data-parallel step independent of the
+    shard size up to the order of the sums over ROWS (the seed's B-row layers: ivae_ardae.py:826-834)."""
+    g = torch.Generator().manual_seed(sum(Ks) + Nout)
+    Mbig = 512
+    Xs = [torch.randn(Mbig + 32, K, generator=g).cuda() for K in Ks]
+    W = (torch.randn(Nout, sum(Ks), generator=g) / sum(Ks) ** 0.5).cuda()
+    wps, off = [], 0
+    for K in Ks:
+        wps.append(pack(W[:, off:off + K])); off += K
+    S = torch.nn.functional.softplus(torch.randn(Mbig + 32, Nout, generator=g) * 3).cuda()
+    Q = torch.randn(Mbig + 32, Nout, generator=g).cuda(); R = torch.randn(Mbig + 32, Nout, generator=g).cuda()
+    b = torch.randn(Nout, generator=g).cuda(); rb = torch.randn((Mbig + 32) // 4, Nout, generator=g).cuda()
+    sig = torch.randn(Mbig + 32, generator=g).cuda(); wsig = torch.randn(Nout, generator=g).cuda()
+
+    def run(M):
+        Y = torch.full((M, Nout), float("nan"), device="cuda"); Y2 = torch.full((M, Nout), float("nan"), device="cuda")
+        srcs = [(X[:M], wp) for X, wp in zip(Xs, wps)]
+        if epi == "act":
+            run_linear(L.EPI_ACT, M, Nout, srcs, act=2, bias=b, rowbias=rb, rows_per_group=4, rowscale=sig, rowscale_w=wsig, Y=Y)
+            return (Y,)
+        if epi == "dact_q":
+            run_linear(L.EPI_DACT, M, Nout, srcs, act=2, S=S, Q=Q, Y=Y)
+            return (Y,)
+        run_linear(L.EPI_CHAIN, M, Nout, srcs, act=2, S=S, R=R, Y=Y, Y2=Y2)
+        return (Y, Y2)
+
+    # 512 rows: 32 x 32 blocks (lean where the shape is regular, generic otherwise); 500 / 529: ragged rows, always the generic block;
+    # 16 .. 64 rows: 16 x 16 blocks (at most 64 blocks of 32 x 32 in the layer; Nout = 784 only up to 64 rows)
+    ref = run(Mbig)
+    for M in (16, 32, 64, 128, 500, 529):
+        got = run(M)
+        m = min(M, Mbig)
+        for r, o in zip(ref, got):
+            assert not torch.isnan(o).any()
+            assert torch.equal(r[:m], o[:m]), (M, float((r[:m] - o[:m]).abs().max()))
+
+
 @pytest.mark.parametrize("act", ["relu", "softplus"])
 def test_linear_dact_and_colsum(act):
     g = torch.Generator().manual_seed(11)
