@@ -160,27 +160,42 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=5, help="instrumented steps for the live roofline numbers")
     args = ap.parse_args()
 
+    # ---- process environment FIRST: HSA / RCCL read these when the runtime initialises, i.e. at the first call that touches the GPU
+    # (torch.cuda.set_device below) - a default set after that point never takes effect in this process
+    env_defaults = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}     # the host driver only supports dmabuf IPC (RCCL peer buffers over xGMI)
+    gpu_was_up = torch.cuda.is_initialized()
+    for k, v in env_defaults.items():
+        os.environ.setdefault(k, v)
+    env_report = {"set_before_device_init": not gpu_was_up, **{k: os.environ[k] for k in env_defaults},
+                  **{k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))}}
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Rehearsal knobs (tests/test_dp_gpu.py): BENCH_ONE_GPU=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo moves the
-    # gradient buffers through the host, because RCCL refuses two ranks on one device.  The driver's runs use neither.
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
-    dev_index = 0 if (world == 1 or os.environ.get("BENCH_ONE_GPU") == "1") else local_rank
+    knobs = os.environ.get("ARDAE_DEBUG_KNOBS") == "1"
+    # Rehearsal knobs (tests/test_dp_gpu.py; honoured only with ARDAE_DEBUG_KNOBS=1, like every experiment switch): BENCH_ONE_GPU=1 puts
+    # every rank on cuda:0 and BENCH_BACKEND=gloo moves the gradient buffers through the host, because RCCL refuses two ranks on one
+    # device; BENCH_FORCE_DP=1 runs the data-parallel plan (process group, RCCL communicator, captured all-reduces) with ONE rank;
+    # BENCH_GLOBAL_B: another global batch (the per-rank shards of the multi-GPU runs on one GPU).  The driver's runs use none of them.
+    knob = lambda name, default: os.environ.get(name, default) if knobs else default
+    backend = knob("BENCH_BACKEND", "nccl")
+    force_dp = knob("BENCH_FORCE_DP", "0") == "1"
+    dev_index = 0 if (world == 1 or knob("BENCH_ONE_GPU", "0") == "1") else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    distributed = world > 1 or (force_dp and "RANK" in os.environ)
+    if distributed:
         if backend == "nccl":
             torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             torch.distributed.init_process_group(backend=backend)
+        assert torch.distributed.get_world_size() == world and torch.distributed.get_rank() == rank
     dev = torch.device("cuda", dev_index)
 
     import ardae_amd as net
     from ardae_amd import _lib as L
     import ctypes
 
-    GLOBAL_B, NZ = int(os.environ.get("BENCH_GLOBAL_B", "512")), 256   # BENCH_GLOBAL_B: experiments only
+    GLOBAL_B, NZ = int(knob("BENCH_GLOBAL_B", "512")), 256
     assert GLOBAL_B % world == 0, "the global batch must divide over the ranks"
     B = GLOBAL_B // world
     torch.manual_seed(0)                                  # identical parameters on every rank
@@ -188,7 +203,7 @@ def main():
                            enc_type="concat", z_dim=32).to(dev)
     cdae = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=256, num_hidden_layers=3, nonlinearity="softplus",
                              noise_type="gaussian", enc_ctx=True, enc_input=True).to(dev)
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=B)
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=B, force_dp=force_dp and distributed)
     net.manual_seed(42)                                   # one noise stream: every rank draws its rows of the global draw (engine._normal)
     g = torch.Generator(device="cpu").manual_seed(1234)
     pimg = ((torch.rand(784, generator=g) < 0.2).float() * 0.6 + 0.03).to(dev)
@@ -204,7 +219,7 @@ def main():
         eng.step(xc, xv)
 
     def barrier():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -216,7 +231,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     rank_report = None
-    if world > 1:
+    if distributed:
         # per-rank wall times of the timed region (the headline takes their MAX) and the latency of the step's two collectives,
         # so that a multi-GPU line explains itself: compute per rank vs. time spent in the gradient all-reduces
         mine = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -226,20 +241,27 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
         from ardae_amd import dist as D
+        reduce_ = eng.comm.allreduce_mean_ if eng.comm is not None else D.allreduce_mean_      # the call the step itself makes
         lat = {}
         for name, buf in (("cdae_grads", eng.grads_c[:eng.n_c]), ("model_grads", eng.grads_m)):
             scratch = buf.clone()
             for _ in range(3):
-                D.allreduce_mean_(scratch)
+                reduce_(scratch)
             torch.cuda.synchronize(); torch.distributed.barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
-                D.allreduce_mean_(scratch)
+                reduce_(scratch)
             e1.record(); torch.cuda.synchronize()
             lat[name] = {"bytes": scratch.numel() * 4, "us_per_allreduce_mean": 1e3 * e0.elapsed_time(e1) / 20}
+        seen = eng.comm.query() if eng.comm is not None else None
         rank_report = {"ms_per_step_by_rank": [1e3 * float(x) / args.steps for x in every], "collectives": lat,
-                       "plan": eng.plan_summary()}
+                       "plan": eng.plan_summary(),
+                       # who took part: torch.distributed's view and, when the C ABI owns the communicator, RCCL's own
+                       "torch_distributed": {"backend": str(torch.distributed.get_backend()), "world_size": torch.distributed.get_world_size()},
+                       "rccl": None if seen is None else {"library": eng.comm.backend, "ranks": seen[0], "rank": seen[1], "device": seen[2],
+                                                          "allreduce": "ardae_dp_allreduce_mean, captured in the step graphs"},
+                       "env": env_report}
     stats = eng.stats()
 
     # ---- live per-kernel timing (HIP events on the launch stream), separate from the throughput region
@@ -265,11 +287,12 @@ def main():
         flop = algorithmic_flops_per_step(GLOBAL_B, NZ)
         executed = roofline["executed_tflop_per_step"] * 1e12 * world if roofline else None      # rank 0's kernels x ranks (equal shards)
         out = {
-            "metric": "AR-DAE-VAE train-steps/sec (batch 512, nz_cdae 256) on dbMNIST", "value": steps_per_s, "unit": "train-steps/sec",
+            "metric": f"AR-DAE-VAE train-steps/sec (batch {GLOBAL_B}, nz_cdae {NZ}) on dbMNIST", "value": steps_per_s, "unit": "train-steps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config #2: MNISTIPVAE mlp z=32 h=256 + cDAE mlp-grad h=256 L=3, global batch 512, "
-                                   "nz_cdae 256 (131072 rows), dynamic binarisation on device, 1 cDAE + 1 VAE update per step",
+            "config": {"workload": ("BASELINE config #2" if GLOBAL_B == 512 else f"EXPERIMENT (BENCH_GLOBAL_B={GLOBAL_B}): BASELINE config #2's networks") +
+                                   f": MNISTIPVAE mlp z=32 h=256 + cDAE mlp-grad h=256 L=3, global batch {GLOBAL_B}, "
+                                   f"nz_cdae {NZ} ({GLOBAL_B * NZ} rows), dynamic binarisation on device, 1 cDAE + 1 VAE update per step",
                        "global_batch": GLOBAL_B, "nz_cdae": NZ, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             # two whole-step figures: FLOPs the kernels EXECUTE (the honest utilisation), and SURVEY 8(d)'s formula, which also counts
             # work the reference performs on all N rows but the engine hoists to once per image (W_1c c and its weight gradient)
@@ -289,9 +312,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:      # every rank: a failure must end the job with a non-zero status, whichever rank it happens on
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        sys.stderr.write(f"[bench.py rank {os.environ.get('RANK', '0')}] failed:\n{traceback.format_exc()}")
+        sys.stderr.flush()
+        os._exit(1)                 # no interpreter teardown: a rank stuck in a collective's destructor would keep the job alive

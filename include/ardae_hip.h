@@ -342,6 +342,31 @@ int ardae_log_scalars(const float* cdae_loss, const float* model_losses, const f
 int ardae_gather_rows(const float* table, const int64_t* idx, int B, int D, float* out, void* stream);
 
 
+/* ---- data-parallel gradient exchange: RCCL over xGMI (SURVEY 8(b) `dp_allreduce_flat`, 8(e); kernel inventory K11) -----------
+ * The reference has no collectives (single process, single device: SURVEY 2.1).  Under data parallelism each rank holds
+ * a shard of the image batch and the reference's batch-mean losses (`cdae_loss.backward()` ivae_ardae.py:771,
+ * `model_loss.backward()` :804, the entropy seed :826-834) become a mean over ranks of the two flat gradient buffers.
+ * One communicator per rank, created once; one in-place all-reduce per buffer, issued on `stream` like any kernel
+ * of this library - it may be CAPTURED into the step's HIP graph.
+ * RCCL is bound at run time (dlopen; a copy already resident in the process - PyTorch's - is reused): without a usable
+ * librccl.so these entry points fail with a message and everything else works.  Status codes of this group:
+ * 0 ok, <0 invalid argument, 1..999 a hipError_t, 1000 + n an ncclResult_t n.                                         */
+#define ARDAE_DP_UNIQUE_ID_BYTES 128
+/* "RCCL <version> (<path of the bound library>)", "" when none could be bound */
+const char* ardae_dp_backend(void);
+/* rank 0: a fresh id (ncclGetUniqueId) into HOST memory; the caller ships the 128 bytes to every rank
+ * (torch.distributed broadcast, MPI, a file ...) */
+int ardae_dp_unique_id(void* host_id);
+/* every rank, with its GPU selected (hipSetDevice / torch.cuda.set_device): joins the communicator; blocks until all
+ * `nranks` processes have called it.  One rank per device (RCCL refuses two ranks on one GPU). */
+int ardae_dp_comm_create(const void* host_id, int nranks, int rank, void** comm_out);
+/* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank) + the device it was created on */
+int ardae_dp_comm_query(void* comm, int* nranks, int* rank, int* device);
+int ardae_dp_comm_destroy(void* comm);
+/* buf[0..n) <- mean over ranks of buf[0..n), in place, stream-ordered (ncclAllReduce, ncclAvg).  One rank: unchanged. */
+int ardae_dp_allreduce_mean(void* comm, float* buf, size_t n, void* stream);
+
+
 /* ---- live per-kernel timing (bench.py roofline): HIP events around every launch on the launch stream ---------- */
 typedef struct ardae_profile_entry {
   char name[96];   /* kernel name as rocprofv3 prints it (template arguments included)                         */

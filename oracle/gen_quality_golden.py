@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Oracle side of the IWAE-64 quality gate at BASELINE config #2 widths (test infrastructure).
 
-    python oracle/gen_quality_golden.py [--lr 1e-3] [--steps 1000] [--every 200] [--seeds 2024 1 2] [--out tests/golden/quality_cfg2.npz]
+    python oracle/gen_quality_golden.py [--lr 3e-4] [--steps 2400] [--every 100] [--ema 0.99] [--seeds 2024 1 2 3] [--out tests/golden/quality_cfg2.npz]
 
 Trains the CPU oracle (the pinned restatement of ivae_ardae.py:707-846) on the synthetic four-prototype problem of
 tests/test_training_quality_gpu.py at config #2's widths (784 pixels, noise 100, h 256, z 32; cDAE mlp-grad h 256 L 3) with 32 images x 256
 Monte-Carlo rows per batch - 8192 rows, the size from which the HIP engine runs its production N-row kernels - once per noise seed, and
-records the IWAE-64 bound on 256 held-out images every `--every` steps.  The GPU test trains the engine on the SAME batches (regenerated from
+records the IWAE-64 bound on 256 held-out images every `--every` steps - of the raw weights and of their exponential moving average
+(decay `--ema`, updated after every step, started at the initial weights: Polyak averaging, the evaluation mode the reference itself offers -
+`--weight-avg polyak`, ivae_ardae.py:560-565,646-647 - and what makes this gate resolve 0.2 nats: single raw checkpoints jump by several nats
+even on the plateau, the averaged weights' bound differs by 0.05-0.3 nats between noise seeds from step 1500 on; round 4).  The GPU test trains the engine on the SAME batches (regenerated from
 the same generator seeds) with its own Philox noise and compares the seed-averaged bounds: a CPU training of this size takes minutes per seed,
 which is why its numbers travel as a fixture and are not recomputed on the GPU box.  Stored: the settings, the per-seed / per-checkpoint
 bounds, the initial bound.  Nothing of the reference is stored.
@@ -47,10 +50,11 @@ def batches(steps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--lr", type=float, default=1e-3)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--every", type=int, default=200)
-    ap.add_argument("--seeds", type=int, nargs="+", default=[2024, 1, 2])
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--steps", type=int, default=2400)
+    ap.add_argument("--every", type=int, default=100)
+    ap.add_argument("--ema", type=float, default=0.99)
+    ap.add_argument("--seeds", type=int, nargs="+", default=[2024, 1, 2, 3])
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "quality_cfg2.npz"))
     a = ap.parse_args()
@@ -63,19 +67,25 @@ def main():
     ll0 = float(O.iwae_logprob(MC, pm0, x_eval, K, enc_noise, prop_noise))
     marks = list(range(a.every, a.steps + 1, a.every))
     table = np.zeros((len(a.seeds), len(marks)))
+    table_ema = np.zeros((len(a.seeds), len(marks)))
     for si, seed in enumerate(a.seeds):
         pm = {k: v.clone() for k, v in pm0.items()}
         pc = {k: v.clone() for k, v in pc0.items()}
         st_m, st_c = {}, {}
+        ema = {k: v.clone() for k, v in pm0.items()}
         gn = torch.Generator().manual_seed(seed)
         t0 = time.time()
         for t, (x1, x2) in enumerate(bs, 1):
             O.train_step(MC, CC, tc, pm, pc, st_m, st_c, x1, x2, O.draw_step_noise(MC, tc, B, gn))
+            for k in ema:
+                ema[k].lerp_(pm[k], 1.0 - a.ema)
             if t in marks:
                 table[si, marks.index(t)] = float(O.iwae_logprob(MC, pm, x_eval, K, enc_noise, prop_noise))
-                print(f"seed {seed} step {t}: IWAE-{K} {table[si, marks.index(t)]:.3f}  ({time.time() - t0:.0f} s)", flush=True)
-    print("init", ll0, "\n", table)
-    np.savez(a.out, lr=a.lr, steps=a.steps, marks=np.array(marks), seeds=np.array(a.seeds), iwae=table, iwae_init=ll0, B=B, NZ=NZ, K=K)
+                table_ema[si, marks.index(t)] = float(O.iwae_logprob(MC, ema, x_eval, K, enc_noise, prop_noise))
+                print(f"seed {seed} step {t}: IWAE-{K} {table[si, marks.index(t)]:.3f}  averaged weights {table_ema[si, marks.index(t)]:.3f}  ({time.time() - t0:.0f} s)", flush=True)
+        np.savez(a.out, lr=a.lr, steps=a.steps, marks=np.array(marks), seeds=np.array(a.seeds[:si + 1]), iwae=table[:si + 1], iwae_ema=table_ema[:si + 1],
+                 ema=a.ema, iwae_init=ll0, B=B, NZ=NZ, K=K)
+    print("init", ll0, "\n", table, "\n", table_ema)
 
 
 if __name__ == "__main__":

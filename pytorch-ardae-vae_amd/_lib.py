@@ -168,6 +168,12 @@ EXPORTS = {
     "ardae_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "ardae_debug_stamp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "ardae_profile_report": (ctypes.c_int, [ctypes.POINTER(ProfileEntry), ctypes.c_int]),
+    "ardae_dp_backend": (ctypes.c_char_p, []),
+    "ardae_dp_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "ardae_dp_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "ardae_dp_comm_query": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 3),
+    "ardae_dp_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "ardae_dp_allreduce_mean": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "ardae_cdae_score": (ctypes.c_int, [ctypes.POINTER(CdaeDesc)] + [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_size_t] + [ctypes.c_void_p] * 2),
 }

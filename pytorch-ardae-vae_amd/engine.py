@@ -120,7 +120,7 @@ class ArdaeEngine:
 
     RNG_STRIDE = 16   # Philox offsets reserved per step (draws use base + 0, 1, 2, ...)
 
-    def __init__(self, model, cdae, cfg: TrainConfig, batch_size, process_group=None, graph=True, force_dp=False):
+    def __init__(self, model, cdae, cfg: TrainConfig, batch_size, process_group=None, graph=True, force_dp=False, dp_comm="auto"):
         model._require_gpu()
         cdae._require_gpu()
         self.model, self.cdae, self.cfg = model, cdae, cfg
@@ -133,6 +133,21 @@ class ArdaeEngine:
         # force_dp: run the data-parallel plan (graphs cut at the gradient all-reduces, the collectives issued between them) even
         # with ONE rank - exercises the RCCL path on a single GPU (tests/test_dp_gpu.py)
         self.dp = self.world > 1 or bool(force_dp)
+        # The gradient exchange (SURVEY 8(b) `dp_allreduce_flat`): an RCCL communicator behind the C ABI (`dist.DpComm`) whose all-reduce
+        # is a stream-ordered call like any kernel launch and is CAPTURED into the step's graphs - the multi-rank step is then the same
+        # three linear graphs as the single-rank one.  dp_comm: a `dist.DpComm`, None (torch.distributed's collectives as eager items
+        # between the graphs: the gloo rehearsal, two ranks sharing a GPU), or "auto": a communicator when the process group is RCCL
+        # ("nccl" backend), none otherwise.
+        if isinstance(dp_comm, str):
+            if dp_comm != "auto":
+                raise ValueError(f"dp_comm must be a dist.DpComm, None or 'auto', got {dp_comm!r}")
+            dp_comm = None
+            if self.dp and torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                    "nccl" in str(torch.distributed.get_backend(process_group)):
+                dp_comm = dist.DpComm(process_group)
+        self.comm = dp_comm if self.dp else None
+        if self.comm is not None and (self.comm.world, self.comm.rank) != (self.world, self.rank):
+            raise ValueError(f"dp_comm is rank {self.comm.rank} of {self.comm.world}, the process group says {self.rank} of {self.world}")
         md, cd = model._desc, cdae._desc
         B, nzc, nzm = self.B, cfg.nz_cdae, cfg.nz_model
         N = B * nzc
@@ -274,13 +289,13 @@ class ArdaeEngine:
         for i, xc in enumerate(xs):
             segs.append(("run", f"cdae_grads{i}", "main", (), lambda xc=xc, i=i: self._cdae_grads(xc, nlist[i], 3 * i)))
             if self.dp:
-                segs.append(("allreduce", self.grads_c[:self.n_c]))
+                segs.append(self._allreduce_seg(f"allreduce_c{i}", self.grads_c[:self.n_c]))
             segs.append(("run", f"cdae_update{i}", "main", (), self._cdae_update))
         if not self.overlap:
             segs.append(vae_fwd)
         segs.append(("run", "vae_bwd", "main", ("vae_fwd",) if self.overlap else (), lambda: self._vae_backward_grads(x_vae, nv, beta)))
         if self.dp:
-            segs.append(("allreduce", self.grads_m))
+            segs.append(self._allreduce_seg("allreduce_m", self.grads_m))
 
         def model_update():
             self._model_update()
@@ -297,6 +312,20 @@ class ArdaeEngine:
                 return run
             segs = [s if s[0] != "run" else (s[0], s[1], s[2], s[3], wrap(s[1], s[4])) for s in segs]
         return segs
+
+    def _allreduce_seg(self, name, buf):
+        """The gradient mean over the ranks as a plan segment: a launch on the main stream when the C ABI owns the communicator (captured
+        with its neighbours), an eager item between the graphs otherwise (torch.distributed)."""
+        if self.comm is not None:
+            return ("run", name, "main", (), lambda: self.comm.allreduce_mean_(buf))
+        return ("allreduce", buf)
+
+    def _allreduce(self, buf):
+        """Outside the plan (phase calls made directly)."""
+        if self.comm is not None:
+            self.comm.allreduce_mean_(buf)
+        else:
+            dist.allreduce_mean_(buf, self.pg, force=True)
 
     @staticmethod
     def _units(segs):
@@ -389,7 +418,7 @@ class ArdaeEngine:
         """ivae_ardae.py:713-779 (one cDAE update).  noise: optional dict(sampler [N,nd], sigma [B,nz,1], eps [N,z])."""
         self._cdae_grads(x, noise)
         if self.dp:
-            dist.allreduce_mean_(self.grads_c[:self.n_c], self.pg, force=True)
+            self._allreduce(self.grads_c[:self.n_c])
         if apply_update:
             self._cdae_update()
 
@@ -500,7 +529,7 @@ class ArdaeEngine:
         """ivae_ardae.py:829-846: entropy gradient through the (updated) cDAE, backward, Adam."""
         self._vae_backward_grads(x, nv, beta)
         if self.dp:
-            dist.allreduce_mean_(self.grads_m, self.pg, force=True)
+            self._allreduce(self.grads_m)
         if apply_update:
             self._model_update()
 

@@ -79,14 +79,14 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def _steps(per_rank_batch, lo, hi, graph, nsteps=5, force_dp=False, **cfg):
+def _steps(per_rank_batch, lo, hi, graph, nsteps=5, force_dp=False, dp_comm="auto", **cfg):
     """nsteps full train steps (own Philox noise, fresh images per step) on images [lo, hi) of each global batch; returns the
     flat parameters and whether the engine ended up replaying captured graphs."""
     import ardae_amd as net
     dev = torch.device("cuda", 0)
     model, cdae = _build(dev)
     net.manual_seed(99)
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ, **cfg), batch_size=per_rank_batch, graph=graph, force_dp=force_dp)
+    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ, **cfg), batch_size=per_rank_batch, graph=graph, force_dp=force_dp, dp_comm=dp_comm)
     g = torch.Generator().manual_seed(21)
     for _ in range(nsteps):
         x1 = torch.bernoulli(torch.full((B, MC.input_dim), 0.3), generator=g)
@@ -223,7 +223,8 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     """bench.py under torch.distributed.run with two ranks on the one GPU: the launch contract (env rendezvous, barrier,
     max-over-ranks timing, one JSON line from rank 0) end to end."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_ONE_GPU="1", BENCH_GLOBAL_B="32")
+    env = dict(os.environ, ARDAE_DEBUG_KNOBS="1", BENCH_BACKEND="gloo", BENCH_ONE_GPU="1", BENCH_GLOBAL_B="32")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)          # bench.py must provide it itself - before anything touches the GPU
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240, cwd=root)
@@ -235,31 +236,90 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["value"] > 0 and d["roofline"]["kernel"]
     for k in ("cdae_loss", "model_loss"):
         assert d["losses"][k] == d["losses"][k]          # not NaN
+    # the HSA / RCCL environment defaults were in place BEFORE the first call that initialises the GPU runtime (bench.py records
+    # torch.cuda.is_initialized() at the moment it sets them), and the line says who took part
+    assert d["ranks"]["env"]["set_before_device_init"] is True and d["ranks"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert d["ranks"]["torch_distributed"] == {"backend": "gloo", "world_size": 2} and d["ranks"]["rccl"] is None
+    assert d["config"]["workload"].startswith("EXPERIMENT (BENCH_GLOBAL_B=32)") and "batch 32," in d["metric"]
+    # a rank that fails must end the job with a non-zero status (here: a global batch that does not divide over the ranks)
+    env_bad = dict(env, BENCH_GLOBAL_B="33")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env_bad, capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode != 0 and "[bench.py rank" in r.stderr
+
+
+def test_bench_one_rank_rccl_end_to_end(tmp_path):
+    """`bench.py` under torch.distributed.run on the `nccl` (= RCCL) backend, as far as one GPU allows: ONE rank with the data-parallel
+    plan forced (BENCH_FORCE_DP=1) - environment defaults, process group, the C ABI's RCCL communicator, both gradient all-reduces
+    captured in the step graphs, the collective-latency report - the code path the driver's N > 1 runs take, end to end."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ARDAE_DEBUG_KNOBS="1", BENCH_FORCE_DP="1", BENCH_GLOBAL_B="32")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["hip_graph"] is True and d["value"] > 0
+    rk = d["ranks"]
+    assert rk["env"]["set_before_device_init"] is True and rk["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert rk["torch_distributed"] == {"backend": "nccl", "world_size": 1}
+    assert rk["rccl"]["ranks"] == 1 and rk["rccl"]["rank"] == 0 and rk["rccl"]["library"].startswith("RCCL ")
+    assert rk["plan"] == ["graph:side", "graph:main", "graph:main"]          # the all-reduces are inside the graphs
+    assert set(rk["collectives"]) == {"cdae_grads", "model_grads"}
 
 
 def _worker_rccl_one_rank(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from ardae_amd import dist, _lib as L
+    # (a) the C ABI's own communicator (dist.DpComm): what `ArdaeEngine` builds by itself on an RCCL process group
     pm_e, pc_e, _ = _steps(B, 0, B, graph=False, force_dp=True)
     pm_g, pc_g, plan = _steps(B, 0, B, graph=True, force_dp=True)
+    # (b) torch.distributed's collectives as eager items between the graphs (dp_comm=None: the rehearsal path, here on RCCL)
+    pm_t, pc_t, plan_t = _steps(B, 0, B, graph=True, force_dp=True, dp_comm=None)
     pm_1, pc_1, plan1 = _steps(B, 0, B, graph=True)                 # the ordinary single-rank plan (no collectives)
-    torch.save({"pm_eager": pm_e, "pc_eager": pc_e, "pm_graph": pm_g, "pc_graph": pc_g, "pm_plain": pm_1, "pc_plain": pc_1, "plan": plan,
-                "plain_plan": plan1, "backend": torch.distributed.get_backend()}, out)
+    # (c) the entry points themselves: query, a stream-ordered call, a captured call
+    comm = dist.DpComm()
+    buf = torch.randn(543489, device="cuda")
+    want = buf.clone()
+    comm.allreduce_mean_(buf)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=side):
+        buf.mul_(2.0)
+        comm.allreduce_mean_(buf)
+        buf.add_(1.0)
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    q = comm.query()
+    comm.close()
+    bad = L.lib().ardae_dp_allreduce_mean(None, L.ptr(buf), buf.numel(), None)
+    torch.save({"pm_eager": pm_e, "pc_eager": pc_e, "pm_graph": pm_g, "pc_graph": pc_g, "pm_torch": pm_t, "pc_torch": pc_t, "pm_plain": pm_1,
+                "pc_plain": pc_1, "plan": plan, "plan_torch": plan_t, "plain_plan": plan1, "backend": torch.distributed.get_backend(),
+                "query": list(q), "rccl": comm.backend, "captured_ok": bool(torch.equal(buf, (want * 2 + 1) * 2 + 1)), "bad_rc": bad}, out)
     torch.distributed.destroy_process_group()
 
 
-def test_rccl_collectives_between_the_graphs_on_one_rank(tmp_path):
-    """RCCL as far as one GPU allows: a ONE-rank `nccl` (= RCCL) process group with `force_dp=True`, so that the step runs the
-    data-parallel plan - linear graphs cut at the two gradient all-reduces, the collectives issued by torch.distributed between
-    the replays, ordered on the current stream, none of them captured.  A one-rank all-reduce is the identity, so the result must
-    equal the eager run of the same plan AND the ordinary single-rank plan, bit for bit."""
+def test_rccl_allreduce_inside_the_c_abi_captured_in_the_step_graphs(tmp_path):
+    """SURVEY 8(b) `dp_allreduce_flat`, as far as one GPU allows: a ONE-rank RCCL communicator owned by the C ABI (`ardae_dp_comm_create`;
+    RCCL accepts nranks = 1).  With `force_dp=True` the step runs the data-parallel plan, whose two gradient all-reduces are calls of
+    `ardae_dp_allreduce_mean` on the launch stream - CAPTURED into the step's linear graphs, so the replayed multi-rank step submits the
+    same three graphs as the single-rank one and no collective cuts it.  A one-rank all-reduce is the identity: the result must equal
+    the eager run of the same plan, the plan with torch.distributed's collectives between the graphs, and the ordinary single-rank
+    plan, bit for bit."""
     out = str(tmp_path / "rccl1.pt")
     mp.spawn(_worker_rccl_one_rank, args=(1, _free_port(), out), nprocs=1, join=True)
     got = torch.load(out, weights_only=True)
-    assert got["backend"] == "nccl"
-    assert got["plan"] == ["graph:side", "graph:main", "allreduce", "graph:main", "graph:main", "allreduce", "graph:main"]
-    assert got["plain_plan"] == ["graph:side", "graph:main", "graph:main"]
-    for a, b in (("pm_graph", "pm_eager"), ("pc_graph", "pc_eager"), ("pm_graph", "pm_plain"), ("pc_graph", "pc_plain")):
+    assert got["backend"] == "nccl" and got["rccl"].startswith("RCCL ")
+    assert got["query"] == [1, 0, 0] and got["captured_ok"] and got["bad_rc"] < 0
+    assert got["plan"] == ["graph:side", "graph:main", "graph:main"] == got["plain_plan"]            # no "allreduce" cut
+    assert got["plan_torch"] == ["graph:side", "graph:main", "allreduce", "graph:main", "graph:main", "allreduce", "graph:main"]
+    for a, b in (("pm_graph", "pm_eager"), ("pc_graph", "pc_eager"), ("pm_graph", "pm_plain"), ("pc_graph", "pc_plain"),
+                 ("pm_graph", "pm_torch"), ("pc_graph", "pc_torch")):
         assert torch.equal(got[a], got[b]), (a, b)
     assert torch.isfinite(got["pm_graph"]).all()
