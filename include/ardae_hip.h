@@ -26,10 +26,11 @@ extern "C" {
 
 /* activations: reference utils/models.py:14-32 (F.relu, F.softplus beta=1 threshold=20) */
 /* get_nonlinear_func (reference utils/models.py:14-32): relu, softplus ('csoftplus' = log(exp(x) + 1) is the same function; it is evaluated in softplus' overflow- and cancellation-free form), elu (alpha 1), tanh, leaky_relu
- * (slope 0.2).  'swish' is not offered (derivatives are rebuilt from saved OUTPUTS; x sigmoid(x) is not invertible).  The
- * software-pipelined N-row kernels exist for NONE / RELU / SOFTPLUS (every shipped recipe); ELU / TANH / LEAKY layers run on the
- * generic kernels. */
-enum { ARDAE_ACT_NONE = 0, ARDAE_ACT_RELU = 1, ARDAE_ACT_SOFTPLUS = 2, ARDAE_ACT_ELU = 3, ARDAE_ACT_TANH = 4, ARDAE_ACT_LEAKY_RELU = 5 };
+ * (slope 0.2), swish (x sigmoid(x), utils/models.py:8-10).  Derivatives are rebuilt from saved OUTPUTS; swish is not monotonic, so its
+ * forward records the branch (x below / above the minimum at -1.27846) in the lowest mantissa bit of the stored output (<= 1 ulp) and
+ * the derivative epilogues invert it by bisection (csrc/common.h::swish_f).  The software-pipelined N-row kernels exist for
+ * NONE / RELU / SOFTPLUS (every shipped recipe); ELU / TANH / LEAKY / SWISH layers run on the generic kernels. */
+enum { ARDAE_ACT_NONE = 0, ARDAE_ACT_RELU = 1, ARDAE_ACT_SOFTPLUS = 2, ARDAE_ACT_ELU = 3, ARDAE_ACT_TANH = 4, ARDAE_ACT_LEAKY_RELU = 5, ARDAE_ACT_SWISH = 6 };
 
 /* epilogues of ardae_linear */
 enum {

@@ -435,7 +435,9 @@ def main():
     # relu the default of --model-nonlin / --cdae-nonlin (mlp-grad with a piecewise linear activation: second-order terms vanish)
     for nm, mk, mnl, ck, cnl in (("tiny_toy_tanh", "toy", "tanh", "grad", "tanh"), ("tiny_mnist_elu", "mnist", "elu", "grad", "elu"),
                                  ("tiny_mnist_leaky", "mnist", "leaky_relu", "res", "leaky_relu"), ("tiny_toy_relu_relu", "toy", "relu", "grad", "relu"),
-                                 ("tiny_mnist_tanh_res", "mnist", "tanh", "res", "tanh")):
+                                 ("tiny_mnist_tanh_res", "mnist", "tanh", "res", "tanh"),
+                                 # swish (utils/models.py:8-10): not monotonic - the HIP path keeps the branch in the stored output's lowest bit
+                                 ("tiny_mnist_swish", "mnist", "swish", "grad", "swish"), ("tiny_toy_swish_res", "toy", "swish", "res", "swish")):
         m_ = (O.ModelCfg("toy", input_dim=2, noise_dim=10, h_dim=64, z_dim=2, n_layers=2, nonlin=mnl) if mk == "toy"
               else O.ModelCfg("mnist", input_dim=24, noise_dim=10, h_dim=64, z_dim=8, n_layers=2, nonlin=mnl))
         c_ = O.CdaeCfg(ck, input_dim=m_.z_dim, context_dim=m_.z_dim, h_dim=64, n_layers=3, nonlin=cnl)

@@ -83,8 +83,8 @@ MODEL_HEAD_SHIFT = 1     # kind 5: sampler-head type in flags bits 1-3 (layout.R
 MODEL_CLIPPED = 16       # kind 6: MNISTResConvAuxIPVAEClipped (no 'spm4' clip, z0 keeps an unscaled eps0)
 
 
-# utils/models.py:14-32 (get_nonlinear_func); 'csoftplus' = log(exp(x) + 1) is softplus (evaluated in its accurate form); 'swish' is not offered
-ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2, "csoftplus": 2, "elu": 3, "tanh": 4, "leaky_relu": 5}
+# utils/models.py:14-32 (get_nonlinear_func): all seven names; 'csoftplus' = log(exp(x) + 1) is softplus (evaluated in its accurate form)
+ACT = {"none": 0, None: 0, "relu": 1, "softplus": 2, "csoftplus": 2, "elu": 3, "tanh": 4, "leaky_relu": 5, "swish": 6}
 LOG_RECORD_FLOATS = 16
 EPI_ACT, EPI_DACT, EPI_CHAIN, EPI_DAE_LOSS = 0, 1, 2, 3
 

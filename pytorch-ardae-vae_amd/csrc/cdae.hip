@@ -104,7 +104,7 @@ int desc_ok(const ardae_cdae_desc* d) {
   ARDAE_CHECK_ARG(d->kind == 0 || d->kind == 1, "cdae: kind must be 0 (mlp-grad) or 1 (mlp-res)");
   ARDAE_CHECK_ARG(d->input_dim >= 1 && d->context_dim >= 1 && d->h_dim >= 1 && d->n_layers >= 1, "cdae: bad dimensions");
   ARDAE_CHECK_ARG(d->n_layers <= 6, "cdae: n_layers <= 6 supported (3L+1 gradient problems per batch)");
-  // every activation of get_nonlinear_func except swish; with a piecewise linear one mlp-grad's second-order terms vanish, as
+  // every activation of get_nonlinear_func; with a piecewise linear one mlp-grad's second-order terms vanish, as
   // they do under autograd in the reference
   ARDAE_CHECK_ARG(d->act > ACT_NONE && d->act <= ACT_LAST, "cdae: unknown activation %d", d->act);
   return 0;

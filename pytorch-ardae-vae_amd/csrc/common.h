@@ -55,11 +55,11 @@ inline const char* debug_knob(const char* name) {
 // rebuilt from it:  softplus: s = sigmoid(pre) = 1 - exp(-a),  s' = s(1-s);  relu: s = [a>0], s' = 0.
 // ----------------------------------------------------------------------------------------------
 // get_nonlinear_func (utils/models.py:14-32): relu, softplus (csoftplus = log(exp(x) + 1) is the same function, evaluated in the accurate form), elu (alpha 1), tanh,
-// leaky_relu (slope 0.2).  swish is not offered: the kernels rebuild derivatives from the saved OUTPUT and x sigmoid(x) is not
-// invertible.  The software-pipelined N-row kernels are instantiated for NONE / RELU / SOFTPLUS (every shipped recipe); the other
-// three run on the generic kernels.
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2, ACT_ELU = 3, ACT_TANH = 4, ACT_LEAKY = 5 };
-constexpr int ACT_LAST = ACT_LEAKY;
+// leaky_relu (slope 0.2), swish (utils/models.py:8-10: x sigmoid(x); see swish_f below for how its derivatives are rebuilt from the
+// saved output).  The software-pipelined N-row kernels are instantiated for NONE / RELU / SOFTPLUS (every shipped recipe); the other
+// four run on the generic kernels.
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS = 2, ACT_ELU = 3, ACT_TANH = 4, ACT_LEAKY = 5, ACT_SWISH = 6 };
+constexpr int ACT_LAST = ACT_SWISH;
 constexpr float LEAKY_SLOPE = 0.2f;
 
 // Both helpers go straight to the hardware exp2 / log2 units (v_exp_f32 / v_log_f32, ~1 ulp; __expf/__logf expand to the
@@ -127,6 +127,51 @@ __device__ __forceinline__ f32x2 softplus_d1_from_out2(f32x2 a, f32x2& em) {
   r[1] = select_lt(a[1], 0.02f, series[1], direct[1]);
   return r;
 }
+// ---- swish (utils/models.py:8-10,29-30: x * sigmoid(x)) ---------------------------------------------------------------------------
+// Every kernel rebuilds act' / act'' from the SAVED OUTPUT (one tensor per layer serves as the next layer's input and as the
+// derivative's argument).  y = x sigmoid(x) is not monotonic: it falls from 0 to its minimum y_m = -0.27846 at x_m = -1.27846 and
+// rises from there, so an output in (y_m, 0) has two pre-images.  The forward therefore records the BRANCH (x < x_m or not) in the
+// lowest mantissa bit of the stored output - a perturbation of at most one ulp of y, below the rounding of the product that made it -
+// and the derivative helpers recover x by 32 bisection steps on that branch (both branches are monotonic; bracket [-104, x_m] or
+// [x_m, max(y, 0) + 0.2785], i.e. |x error| <= bracket / 2^32), then evaluate swish'(x) = s (1 + x (1 - s)) and
+// swish''(x) = s (1 - s) (2 + x (1 - 2 s)) with s = sigmoid(x).  ~250 vector-ALU instructions per element: swish layers run on
+// the generic kernels only (no shipped recipe uses it), where this is affordable.  Close to the minimum the inversion is
+// ill-conditioned (dy/dx -> 0): there |swish' error| <= swish''(x_m) |x error| ~ 1e-4 at worst, on the few elements within 1e-3 of x_m.
+constexpr float SWISH_XM = -1.2784645f;
+__device__ __forceinline__ float sigmoid_f(float x) {
+  const float t = fast_exp(-fabsf(x));             // in (0, 1]: no overflow
+  const float r = 1.f / (1.f + t);
+  return x >= 0.f ? r : t * r;
+}
+__device__ __forceinline__ float swish_raw(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float swish_f(float x) {
+  const unsigned b = (__float_as_uint(swish_raw(x)) & ~1u) | (x < SWISH_XM ? 1u : 0u);
+  return __uint_as_float(b);
+}
+__device__ __forceinline__ float swish_pre_from_out(float y) {
+  const bool left = (__float_as_uint(y) & 1u) != 0u && y <= 0.f;
+  float lo = left ? -104.f : SWISH_XM, hi = left ? SWISH_XM : fmaxf(y, 0.f) + 0.2785f;
+#pragma nounroll
+  for (int it = 0; it < 32; ++it) {
+    const float mid = 0.5f * (lo + hi);
+    const float fm = swish_raw(mid);
+    const bool up = left ? (fm > y) : (fm < y);      // the root lies above mid (left branch: swish falls)
+    lo = up ? mid : lo;
+    hi = up ? hi : mid;
+  }
+  return 0.5f * (lo + hi);
+}
+__device__ __forceinline__ float swish_d1_from_out(float y) {
+  const float x = swish_pre_from_out(y), s = sigmoid_f(x);
+  return s * __builtin_fmaf(x, 1.f - s, 1.f);
+}
+__device__ __forceinline__ float swish_ratio_from_out(float y) {      // swish'' / swish'; 0 where swish' vanishes (the factor it multiplies carries swish')
+  const float x = swish_pre_from_out(y), s = sigmoid_f(x);
+  const float d1 = s * __builtin_fmaf(x, 1.f - s, 1.f);
+  const float d2 = s * (1.f - s) * __builtin_fmaf(x, 1.f - 2.f * s, 2.f);
+  return fabsf(d1) > 1e-20f ? d2 / d1 : 0.f;
+}
+
 template <int ACT>
 __device__ __forceinline__ f32x2 act_fwd2(f32x2 x) {
   if (ACT == ACT_RELU) { f32x2 r; r[0] = fmaxf(x[0], 0.f); r[1] = fmaxf(x[1], 0.f); return r; }
@@ -148,6 +193,7 @@ __device__ __forceinline__ float act_fwd(float x) {
   if (ACT == ACT_ELU) return x > 0.f ? x : expm1f(x);
   if (ACT == ACT_TANH) return tanhf(x);
   if (ACT == ACT_LEAKY) return x > 0.f ? x : LEAKY_SLOPE * x;
+  if (ACT == ACT_SWISH) return swish_f(x);
   return x;
 }
 
@@ -160,6 +206,7 @@ __device__ __forceinline__ float act_d1(float a) {
   if (ACT == ACT_ELU) return a > 0.f ? 1.f : a + 1.f;
   if (ACT == ACT_TANH) return __builtin_fmaf(-a, a, 1.f);
   if (ACT == ACT_LEAKY) return a > 0.f ? 1.f : LEAKY_SLOPE;
+  if (ACT == ACT_SWISH) return swish_d1_from_out(a);
   return 1.f;
 }
 
@@ -171,6 +218,7 @@ __device__ __forceinline__ float act_ratio(float a) {
   if (ACT == ACT_SOFTPLUS) return fast_exp(-a);
   if (ACT == ACT_ELU) return a > 0.f ? 0.f : 1.f;
   if (ACT == ACT_TANH) return -2.f * a;
+  if (ACT == ACT_SWISH) return swish_ratio_from_out(a);
   return 0.f;
 }
 
@@ -183,6 +231,7 @@ __device__ __forceinline__ float act_fwd_rt(int act, float x) {
     case ACT_ELU: return act_fwd<ACT_ELU>(x);
     case ACT_TANH: return act_fwd<ACT_TANH>(x);
     case ACT_LEAKY: return act_fwd<ACT_LEAKY>(x);
+    case ACT_SWISH: return act_fwd<ACT_SWISH>(x);
     default: return x;
   }
 }
@@ -193,6 +242,7 @@ __device__ __forceinline__ float act_d1_rt(int act, float a) {
     case ACT_ELU: return act_d1<ACT_ELU>(a);
     case ACT_TANH: return act_d1<ACT_TANH>(a);
     case ACT_LEAKY: return act_d1<ACT_LEAKY>(a);
+    case ACT_SWISH: return act_d1<ACT_SWISH>(a);
     default: return 1.f;
   }
 }

@@ -528,6 +528,7 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_ELU) return launch_epi<EPI_ACT, ACT_ELU>(a, st);
       if (a.act == ACT_TANH) return launch_epi<EPI_ACT, ACT_TANH>(a, st);
       if (a.act == ACT_LEAKY) return launch_epi<EPI_ACT, ACT_LEAKY>(a, st);
+      if (a.act == ACT_SWISH) return launch_epi<EPI_ACT, ACT_SWISH>(a, st);
       break;
     case EPI_DACT:
       ARDAE_CHECK_ARG(a.S, "linear: EPI_DACT needs S");
@@ -537,6 +538,7 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_ELU) return launch_epi<EPI_DACT, ACT_ELU>(a, st);
       if (a.act == ACT_TANH) return launch_epi<EPI_DACT, ACT_TANH>(a, st);
       if (a.act == ACT_LEAKY) return launch_epi<EPI_DACT, ACT_LEAKY>(a, st);
+      if (a.act == ACT_SWISH) return launch_epi<EPI_DACT, ACT_SWISH>(a, st);
       break;
     case EPI_CHAIN:
       ARDAE_CHECK_ARG(a.S && a.R && a.Y2, "linear: EPI_CHAIN needs S, R and Y2");
@@ -545,6 +547,7 @@ int launch_linear(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_ELU) return launch_epi<EPI_CHAIN, ACT_ELU>(a, st);
       if (a.act == ACT_TANH) return launch_epi<EPI_CHAIN, ACT_TANH>(a, st);
       if (a.act == ACT_LEAKY) return launch_epi<EPI_CHAIN, ACT_LEAKY>(a, st);
+      if (a.act == ACT_SWISH) return launch_epi<EPI_CHAIN, ACT_SWISH>(a, st);
       break;
     case EPI_DAE_LOSS:
       ARDAE_CHECK_ARG(a.sigma && a.eps, "linear: EPI_DAE_LOSS needs sigma and eps");

@@ -497,8 +497,11 @@ __global__ __launch_bounds__(256) void linear_small_pair_kernel(const LinArgs a0
 // reads rows rb of level l only) - a counter per row block, released / acquired at agent scope, instead of a kernel boundary.
 // Row block rb's workgroups are placed on ONE XCD (block index i runs on XCD i % 8 - scratch/mfma/hwid.hip - so i = (rb / 8) * 8 nj +
 // j * 8 + rb % 8 puts all nj blocks of row block rb on XCD rb % 8): their hand-over stays inside that XCD's L2.
-// Deadlock freedom: the grid is at most a few hundred workgroups of 256 threads / 16 KiB LDS and waits only for workgroups of its own
-// launch; other kernels finish without it, so every workgroup is scheduled eventually.
+// Deadlock freedom: a workgroup waits only for workgroups of its OWN launch, so the launch must fit the device as a whole - every
+// workgroup resident at once, whatever order the dispatcher picks them in.  The host admits a chain launch only when its grid is at most
+// (workgroups of this kernel one CU holds, hipOccupancyMaxActiveBlocksPerMultiprocessor) x (CUs of the device), queried once
+// (sc_resident_cap); larger problems go out one launch per problem.  Other kernels on the device finish without this one, so their CUs
+// free up and every workgroup of the grid is dispatched eventually.
 constexpr int SC_CNT_STRIDE = LINEAR_SMALL_CHAIN_COUNTER_WORDS;     // counters of different row blocks never share a cache line
 constexpr int SC_MAXLEV = 16, SC_MAXPROB = 20;     // the argument block stays under the 4 KiB kernel-argument limit
 struct ScProblem {            // what small_block reads of ardae_linear_args, 104 bytes
@@ -561,10 +564,12 @@ __global__ __launch_bounds__(256) void linear_small_chain_kernel(const ScArgs c)
     if (threadIdx.x == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      // the mask bit is published BEFORE the arrival (release), and the mask is read AFTER the last arrival has been seen (acquire): a
+      // reader that counts nj arrivals sees all nj mask bits, so every workgroup of the row block takes the same decision (once per launch)
       __hip_atomic_fetch_or(c.cnt + SC_CNT_STRIDE * rb + 1, 1u << (xcc & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(c.cnt + SC_CNT_STRIDE * rb + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c.cnt + SC_CNT_STRIDE * rb + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       while (__hip_atomic_load(c.cnt + SC_CNT_STRIDE * rb + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nj) __builtin_amdgcn_s_sleep(1);
-      s_mask = __hip_atomic_load(c.cnt + SC_CNT_STRIDE * rb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_mask = __hip_atomic_load(c.cnt + SC_CNT_STRIDE * rb + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     fast = (c.fast & 1) && __builtin_popcount(s_mask) == 1;
@@ -700,6 +705,54 @@ bool linear_small_eligible(const LinArgs& a, int epi) {
 }
 
 namespace {
+// How many workgroups of linear_small_chain_kernel the device holds AT ONCE (see "Deadlock freedom" above).  ARDAE_SC_CAP (debug knob):
+// another value, for the test of the fallback.
+int sc_resident_cap() {
+  static const int cap = [] {
+    if (debug_knob("ARDAE_SC_CAP")) return atoi(debug_knob("ARDAE_SC_CAP"));
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, linear_small_chain_kernel, 256, 0) != hipSuccess)
+      return 0;      // unknown: never chain
+    return cus * per_cu;
+  }();
+  return cap;
+}
+
+// [p, p + bytes) of two buffers overlap
+inline bool sc_overlap(const float* a, size_t na, const float* b, size_t nb) {
+  if (!a || !b || na == 0 || nb == 0) return false;
+  const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
+  return a0 < b0 + nb * sizeof(float) && b0 < a0 + na * sizeof(float);
+}
+// The hand-over inside one XCD relies on every chained buffer being written exactly ONCE before any read of it in the launch (the
+// consumers' `nt` loads must find nothing stale): a problem's outputs may alias nothing an EARLIER or the same level reads or writes.
+bool sc_write_once(const LinArgs* probs, const int* level_of, int nprob) {
+  auto extent = [](const LinArgs& a, int ld, int cols) { return (size_t)(a.M - 1) * (size_t)ld + (size_t)cols; };
+  for (int i = 0; i < nprob; ++i) {
+    const LinArgs& w = probs[i];
+    const float* outs[2] = {w.Y, w.Y2};
+    const size_t outn[2] = {extent(w, w.ldY, w.Nout), w.Y2 ? extent(w, w.ldY2, w.Nout) : 0};
+    for (int j = 0; j < nprob; ++j) {
+      if (level_of[j] > level_of[i]) continue;             // later levels READ what this one writes: that is the chain
+      const LinArgs& r = probs[j];
+      for (int o = 0; o < 2; ++o) {
+        if (!outs[o]) continue;
+        if (j != i && (sc_overlap(outs[o], outn[o], r.Y, extent(r, r.ldY, r.Nout)) || (r.Y2 && sc_overlap(outs[o], outn[o], r.Y2, extent(r, r.ldY2, r.Nout)))))
+          return false;
+        for (int s = 0; s < r.nsrc; ++s)
+          if (sc_overlap(outs[o], outn[o], r.src[s].x, extent(r, r.src[s].ld, r.src[s].K))) return false;
+        if (sc_overlap(outs[o], outn[o], r.S, r.S ? extent(r, r.ldS, r.Nout) : 0)) return false;
+        if (sc_overlap(outs[o], outn[o], r.Q, r.Q ? extent(r, r.ldQ, r.Nout) : 0)) return false;
+        if (r.rowbias && sc_overlap(outs[o], outn[o], r.rowbias, (size_t)((r.M - 1) / std::max(r.rows_per_group, 1)) * r.rowbias_ld + r.Nout)) return false;
+        if (r.rowscale && sc_overlap(outs[o], outn[o], r.rowscale, (size_t)r.M)) return false;
+      }
+      if (j == i && w.Y2 && sc_overlap(w.Y, outn[0], w.Y2, outn[1])) return false;
+    }
+  }
+  return true;
+}
+
 bool sc_fill(const LinArgs& a, int epi, ScProblem& q) {
   if (!linear_small_eligible(a, epi) || a.nsrc < 1 || a.nsrc > 2 || !(epi == EPI_ACT || epi == EPI_DACT)) return false;
   if (a.act != ACT_NONE && a.act != ACT_RELU && a.act != ACT_SOFTPLUS) return false;
@@ -742,7 +795,8 @@ int launch_linear_small_chain(const LinArgs* probs, const int* epis, const int* 
     if (c.lv[l].nblk > c.nj) c.nj = c.lv[l].nblk;
   }
   const int nrb = ceil_div(M, blk);
-  ok = ok && nlev >= 2 && (int64_t)nrb * c.nj <= 2048;
+  // the whole grid resident at once (deadlock freedom), nothing written twice or over an input (XCD-local hand-over)
+  ok = ok && nlev >= 2 && (int64_t)ceil_div(nrb, 8) * 8 * c.nj <= sc_resident_cap() && sc_write_once(probs, level_of, nprob);
   if (!ok) {
     for (int i = 0; i < nprob; ++i) ARDAE_TRY(launch_linear(probs[i], epis[i], st));
     return 0;
@@ -793,6 +847,7 @@ int launch_linear_small(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_ELU) return launch_small<EPI_ACT, ACT_ELU>(a, st);
       if (a.act == ACT_TANH) return launch_small<EPI_ACT, ACT_TANH>(a, st);
       if (a.act == ACT_LEAKY) return launch_small<EPI_ACT, ACT_LEAKY>(a, st);
+      if (a.act == ACT_SWISH) return launch_small<EPI_ACT, ACT_SWISH>(a, st);
       break;
     case EPI_DACT:
       if (a.act == ACT_NONE) return launch_small<EPI_DACT, ACT_NONE>(a, st);
@@ -801,6 +856,7 @@ int launch_linear_small(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_ELU) return launch_small<EPI_DACT, ACT_ELU>(a, st);
       if (a.act == ACT_TANH) return launch_small<EPI_DACT, ACT_TANH>(a, st);
       if (a.act == ACT_LEAKY) return launch_small<EPI_DACT, ACT_LEAKY>(a, st);
+      if (a.act == ACT_SWISH) return launch_small<EPI_DACT, ACT_SWISH>(a, st);
       break;
     case EPI_CHAIN:
       if (a.act == ACT_SOFTPLUS) return launch_small<EPI_CHAIN, ACT_SOFTPLUS>(a, st);
@@ -808,6 +864,7 @@ int launch_linear_small(const LinArgs& a, int epi, hipStream_t st) {
       if (a.act == ACT_ELU) return launch_small<EPI_CHAIN, ACT_ELU>(a, st);
       if (a.act == ACT_TANH) return launch_small<EPI_CHAIN, ACT_TANH>(a, st);
       if (a.act == ACT_LEAKY) return launch_small<EPI_CHAIN, ACT_LEAKY>(a, st);
+      if (a.act == ACT_SWISH) return launch_small<EPI_CHAIN, ACT_SWISH>(a, st);
       break;
   }
   ARDAE_CHECK_ARG(false, "linear_small: unsupported epilogue/activation combination (epi=%d act=%d)", epi, a.act);

@@ -102,12 +102,12 @@ int desc_ok(const ardae_model_desc* d) {
   }
   if (d->kind == 2 || d->kind == 4) {
     ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1, "model: ConvIPVAE is hard-wired to 28x28x1 inputs (input_dim 784)");
-    ARDAE_CHECK_ARG(d->act > ACT_NONE && d->act <= ACT_LAST, "model: unknown activation %d (relu, softplus, elu, tanh, leaky_relu)", d->act);
+    ARDAE_CHECK_ARG(d->act > ACT_NONE && d->act <= ACT_LAST, "model: unknown activation %d (relu, softplus, elu, tanh, leaky_relu, swish)", d->act);
     return 0;
   }
   ARDAE_CHECK_ARG(d->input_dim >= 1 && d->noise_dim >= 1 && d->h_dim >= 1 && d->z_dim >= 1 && d->n_layers >= 1 && d->n_layers <= 4,
                   "model: bad dimensions");
-  ARDAE_CHECK_ARG(d->act > ACT_NONE && d->act <= ACT_LAST, "model: unknown activation %d (relu, softplus, elu, tanh, leaky_relu)", d->act);
+  ARDAE_CHECK_ARG(d->act > ACT_NONE && d->act <= ACT_LAST, "model: unknown activation %d (relu, softplus, elu, tanh, leaky_relu, swish)", d->act);
   return 0;
 }
 

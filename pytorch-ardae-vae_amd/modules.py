@@ -171,7 +171,7 @@ class ConditionalARDAE(FlatParamModule):
         if not (enc_input and enc_ctx):
             raise NotImplementedError("enc_input=enc_ctx=True is the only configuration ivae_ardae.py:583-606 constructs")
         if nonlinearity not in L.ACT or nonlinearity in ("none", None):
-            raise NotImplementedError(f"nonlinearity {nonlinearity!r}: the HIP engine implements relu, softplus / csoftplus, elu, tanh and leaky_relu")
+            raise NotImplementedError(f"nonlinearity {nonlinearity!r}: get_nonlinear_func (utils/models.py:14-32) knows relu, softplus / csoftplus, elu, tanh, leaky_relu and swish")
         self.input_dim, self.h_dim, self.context_dim, self.std = input_dim, h_dim, context_dim, std
         self.num_hidden_layers, self.nonlinearity, self.noise_type = num_hidden_layers, nonlinearity, noise_type
         self.enc_input, self.enc_ctx = enc_input, enc_ctx

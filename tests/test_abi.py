@@ -138,8 +138,8 @@ def test_argument_validation_of_the_step_entry_points():
     # the split backward exists for the MLP models only
     fails(lib.ardae_model_vae_backward_decoder(ctypes.byref(conv), one, one, one, one, 4, 1, 1.0, 1.0, one, big, None), "conv model")
     fails(lib.ardae_model_vae_backward_sampler(ctypes.byref(conv), one, one, one, one, 4, 1, one, 1.0, one, big, one, 0.0, None), "conv model")
-    # unknown network kinds / activations (0 = none and anything beyond leaky_relu)
-    for bad_act in (0, 6):
+    # unknown network kinds / activations (0 = none and anything beyond swish)
+    for bad_act in (0, 7):
         bad = L.CdaeDesc(0, 8, 8, 64, 3, bad_act)
         assert lib.ardae_cdae_workspace_floats(ctypes.byref(bad), 4, 8, 1) == 0
         fails(lib.ardae_cdae_pack(ctypes.byref(bad), one, one, None), "unknown activation")
@@ -197,19 +197,22 @@ def test_host_and_in_step_philox_offsets_are_disjoint():
 
 
 def test_activation_names_follow_get_nonlinear_func():
-    """utils/models.py:14-32: relu, elu, tanh, softplus, csoftplus (= softplus; evaluated in the accurate form), leaky_relu; swish is refused by the host classes."""
+    """utils/models.py:14-32: relu, elu, tanh, softplus, csoftplus (= softplus; evaluated in the accurate form), leaky_relu, swish - every
+    name get_nonlinear_func knows constructs; anything else is refused by the host classes."""
     import torch
     import ardae_amd as net
     assert L.ACT["csoftplus"] == L.ACT["softplus"] == 2 and L.ACT["relu"] == 1
-    assert {L.ACT[k] for k in ("elu", "tanh", "leaky_relu")} == {3, 4, 5}
+    assert {L.ACT[k] for k in ("elu", "tanh", "leaky_relu", "swish")} == {3, 4, 5, 6}
     x = torch.linspace(-30, 30, 2001, dtype=torch.float64)
     from oracle import ardae_oracle as O
     # log(exp(x) + 1) is softplus; its literal fp32 evaluation only loses the tail below ~1e-7 (1 + e^x rounds to 1)
     assert torch.allclose(O.act("csoftplus")(x.float()), O.act("softplus")(x.float()), rtol=1e-6, atol=2e-7)
+    net.MLPGradCARDAE(input_dim=2, context_dim=2, h_dim=16, num_hidden_layers=1, nonlinearity="swish")
+    net.ToyIPVAE(input_dim=2, noise_dim=2, h_dim=16, z_dim=2, nonlinearity="swish", enc_type="concat")
     with pytest.raises(NotImplementedError):
-        net.MLPGradCARDAE(input_dim=2, context_dim=2, h_dim=16, num_hidden_layers=1, nonlinearity="swish")
+        net.MLPGradCARDAE(input_dim=2, context_dim=2, h_dim=16, num_hidden_layers=1, nonlinearity="gelu")
     with pytest.raises(NotImplementedError):
-        net.ToyIPVAE(input_dim=2, noise_dim=2, h_dim=16, z_dim=2, nonlinearity="swish", enc_type="concat")
+        net.ToyIPVAE(input_dim=2, noise_dim=2, h_dim=16, z_dim=2, nonlinearity="gelu", enc_type="concat")
     # the reference's class defaults (tanh) construct
     net.MLPGradCARDAE(input_dim=2, context_dim=2, h_dim=16, num_hidden_layers=1)
     net.ToyIPVAE(input_dim=2, noise_dim=2, h_dim=16, z_dim=2, enc_type="concat")

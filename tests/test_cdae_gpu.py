@@ -109,6 +109,9 @@ CASES = {
     "tiny_mnist_leaky": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "leaky_relu"), O.CdaeCfg("res", 8, 8, 64, 3, "leaky_relu"), 8),
     "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8),
     "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8),
+    # swish (utils/models.py:8-10): the seventh and last name of get_nonlinear_func (round 4)
+    "tiny_mnist_swish": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "swish"), O.CdaeCfg("grad", 8, 8, 64, 3, "swish"), 8),
+    "tiny_toy_swish_res": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "swish"), O.CdaeCfg("res", 2, 2, 64, 3, "swish"), 8),
 }
 
 
@@ -300,6 +303,48 @@ def test_cdae_score_per_image_chain_launch(B, act):
         assert torch.equal(H.score(x, sigma, ctx, B, 1), first)
     ref = O.cdae_score(cc, {k: v.double() for k, v in pc.items()}, x.double().requires_grad_(True), ctx.double(), sigma.double()[:, None], create_graph=False)
     assert rel_l2(first, ref.detach()) < 2e-5
+
+
+_CHAIN_CAP_CHILD = """
+import sys, json, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from ardae_amd import _lib as L
+from oracle import ardae_oracle as O
+import test_cdae_gpu as T
+cc = O.CdaeCfg("grad", 32, 32, 256, 3, "softplus")
+pc = O.init_params(O.cdae_param_spec(cc), 3)
+H = T.CdaeHarness(cc, torch.cat([pc[n].reshape(-1) for n, _ in O.cdae_param_spec(cc)]))
+g = torch.Generator().manual_seed(64)
+x, ctx, sigma = torch.randn(64, 32, generator=g) * 30, torch.randn(64, 32, generator=g), torch.zeros(64)
+L.lib().ardae_profile_enable(1)
+out = H.score(x, sigma, ctx, 64, 1)
+names = [e["name"] for e in L.profile_report()]
+L.lib().ardae_profile_enable(0)
+torch.save(out, sys.argv[1])
+print(json.dumps(names))
+"""
+
+
+def test_cdae_score_chain_launch_respects_the_residency_cap(tmp_path):
+    """`linear_small_chain_kernel` spins on counters of its own launch: it is only launched when its WHOLE grid is resident at once -
+    at most hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs workgroups (linear_small.hip::sc_resident_cap) - and the problems go out
+    one launch each otherwise.  Default: the 64-row score pass (4 L + 1 = 13 levels) is one chain launch; with the cap forced down to 8 workgroups
+    (ARDAE_SC_CAP, a debug knob) the fallback is taken, and both give the same bits."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = _CHAIN_CAP_CHILD.format(root=root, tests=os.path.join(root, "tests"))
+    outs = []
+    for extra in ({}, {"ARDAE_DEBUG_KNOBS": "1", "ARDAE_SC_CAP": "8"}):
+        f = str(tmp_path / f"score{len(outs)}.pt")
+        env = {k: v for k, v in os.environ.items() if not k.startswith("ARDAE_")}
+        r = subprocess.run([sys.executable, "-c", src, f], env=dict(env, **extra), capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-3000:]
+        names = json.loads(r.stdout.strip().splitlines()[-1])
+        outs.append((names, torch.load(f, weights_only=True)))
+    assert any(n.startswith("linear_small_chain_kernel x") for n in outs[0][0]), outs[0][0]
+    assert not any(n.startswith("linear_small_chain_kernel") for n in outs[1][0]), outs[1][0]
+    assert sum(n.startswith("linear_small") for n in outs[1][0]) >= 2
+    assert torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("B,nz,z,h,act", [(64, 256, 32, 256, "softplus"), (5, 64, 16, 320, "relu"), (3, 1024, 8, 64, "softplus")])

@@ -40,6 +40,9 @@ CASES.update({
     "tiny_mnist_leaky": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "leaky_relu"), O.CdaeCfg("res", 8, 8, 64, 3, "leaky_relu"), 8, True),
     "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8, True),
     "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8, True),
+    # swish (utils/models.py:8-10): the seventh and last name of get_nonlinear_func (round 4)
+    "tiny_mnist_swish": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "swish"), O.CdaeCfg("grad", 8, 8, 64, 3, "swish"), 8, True),
+    "tiny_toy_swish_res": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "swish"), O.CdaeCfg("res", 2, 2, 64, 3, "swish"), 8, True),
 })
 # --cdae-ctx-type data (ivae_ardae.py:730-734,809-813): the image itself (centred for the MNIST family) is the cDAE's context
 CASES.update({
@@ -251,7 +254,7 @@ def test_engine_step_production_kernels_vs_oracle(kind):
 
 
 @pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad", "tiny_auxtoy_grad", "tiny_toy_tanh", "tiny_mnist_elu",
-                                  "tiny_mnist_leaky", "tiny_toy_relu_relu", "tiny_mnist_tanh_res"])
+                                  "tiny_mnist_leaky", "tiny_toy_relu_relu", "tiny_mnist_tanh_res", "tiny_mnist_swish", "tiny_toy_swish_res"])
 def test_vae_phase_grads_golden(golden_dir, name):
     mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, name)
     model, cdae = build(mc, cc)

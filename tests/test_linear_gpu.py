@@ -402,7 +402,8 @@ def test_linear_rejects_bad_args():
 # ---- kernels - forward, derivative from the saved output, and the second-over-first derivative ratio of EPI_CHAIN
 def _fwd64(act, pre):
     F = torch.nn.functional
-    return {"elu": F.elu(pre), "tanh": torch.tanh(pre), "leaky_relu": F.leaky_relu(pre, 0.2), "relu": pre.clamp(min=0), "softplus": F.softplus(pre)}[act]
+    return {"elu": F.elu(pre), "tanh": torch.tanh(pre), "leaky_relu": F.leaky_relu(pre, 0.2), "relu": pre.clamp(min=0), "softplus": F.softplus(pre),
+            "swish": pre * torch.sigmoid(pre)}[act]
 
 
 def _d1_ratio64(act, pre):
@@ -416,7 +417,7 @@ def _d1_ratio64(act, pre):
 
 
 @pytest.mark.parametrize("M,K,Nout", [(200, 100, 256), (64, 256, 256), (4096, 256, 256), (96, 256, 32), (8192, 32, 256)])
-@pytest.mark.parametrize("act", ["elu", "tanh", "leaky_relu"])
+@pytest.mark.parametrize("act", ["elu", "tanh", "leaky_relu", "swish"])
 def test_linear_act_more_activations(M, K, Nout, act):
     g = torch.Generator().manual_seed(M + K + Nout)
     X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5 * 2; b = torch.randn(Nout, generator=g)
@@ -426,7 +427,9 @@ def test_linear_act_more_activations(M, K, Nout, act):
     run_linear(L.EPI_ACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], bias=b.cuda(), R=w.cuda(), Y=Y, Y2=Y2)
     assert relerr(Y, _fwd64(act, pre)) < 2e-5
     s, _ = _d1_ratio64(act, pre)
-    assert relerr(Y2, -w.double() * s) < 5e-5          # score seed -w (.) act'(a), rebuilt from the saved output
+    # score seed -w (.) act'(a), rebuilt from the saved output (swish: inverted on the branch its lowest bit names; ill-conditioned within
+    # ~1e-3 of the minimum, where |swish' error| <= 1e-4)
+    assert relerr(Y2, -w.double() * s) < (2e-4 if act == "swish" else 5e-5)
 
 
 @pytest.mark.parametrize("M", [200, 4096])
@@ -446,6 +449,47 @@ def test_linear_dact_chain_more_activations(M, act):
     run_linear(L.EPI_CHAIN, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT[act], S=S.cuda(), R=R.cuda(), Y=Y, Y2=Y2)
     assert relerr(Y, v * s) < 5e-5
     assert relerr(Y2, v * R.double() * ratio) < 5e-5
+
+
+@pytest.mark.parametrize("M", [200, 4096])
+def test_linear_dact_chain_swish(M):
+    """swish (utils/models.py:8-10) through the derivative epilogues: the saved output carries the branch of x sigmoid(x) in its lowest
+    mantissa bit (csrc/common.h::swish_f), act' and act''/act' are rebuilt by inverting it.  S is written by the FORWARD epilogue here
+    (as in a step); R carries act' like the tensor the forward-mode pass multiplies (so that R act''/act' = t act'' is well conditioned
+    at the minimum, where act' vanishes).  Also: the stored output is swish(pre) to fp32 accuracy, over a dense sweep of both branches,
+    the minimum and the tails."""
+    g = torch.Generator().manual_seed(33 + M)
+    K, Nout = 256, 256
+    X = torch.randn(M, K, generator=g); W = torch.randn(Nout, K, generator=g) / 16
+    pre = (torch.randn(M, Nout, generator=g) * 2.5).float()
+    pre.view(-1)[:4001] = torch.linspace(-100.0, 30.0, 4001)                                        # tails on both sides
+    pre.view(-1)[4001:8002] = torch.linspace(-1.2784645 - 2e-3, -1.2784645 + 2e-3, 4001)           # around the minimum
+    eye = torch.eye(Nout)
+    S = torch.full((M, Nout), float("nan"), device="cuda")
+    run_linear(L.EPI_ACT, M, Nout, [(pre.cuda(), pack(eye.cuda()))], act=L.ACT["swish"], Y=S)        # S = swish(pre), branch bit included
+    ref_y = _fwd64("swish", pre.double())
+    # fp32 accuracy of x sigmoid(x) on the hardware exp unit (the argument's rounding costs |x| 6e-8 relative in exp(-|x|)), plus the one
+    # ulp the branch bit may move the stored value by; exp(-|x|) below the normal range is flushed (results under ~1e-36 come out as the bare branch bit)
+    tol = torch.maximum(ref_y.abs() * (5e-7 + 2e-7 * pre.double().abs()), torch.tensor(1e-35, dtype=torch.float64))
+    assert bool(((S.cpu().double() - ref_y).abs() <= tol).all())
+    s, _ = _d1_ratio64("swish", pre.double())
+    x = pre.double().clone().requires_grad_(True)
+    (s_x,) = torch.autograd.grad(_fwd64("swish", x).sum(), x, create_graph=True)
+    (s2,) = torch.autograd.grad(s_x.sum(), x)
+    Q = torch.randn(M, Nout, generator=g); t = torch.randn(M, Nout, generator=g)
+    v = X.double() @ W.double().T
+    Y = torch.empty(M, Nout, device="cuda"); Y2 = torch.empty(M, Nout, device="cuda")
+    # R = t act'(S) as the score pass leaves it: made by the derivative epilogue itself (the inverted x is the same in both launches,
+    # so act' cancels exactly in R act''/act' - also within 1e-3 of the minimum, where the inversion cannot resolve act')
+    Rd = torch.empty(M, Nout, device="cuda")
+    run_linear(L.EPI_DACT, M, Nout, [(t.cuda(), pack(eye.cuda()))], act=L.ACT["swish"], S=S, Y=Rd)
+    assert relerr(Rd, t.double() * s) < 1e-4
+    run_linear(L.EPI_DACT, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT["swish"], S=S, Q=Q.cuda(), Y=Y)
+    assert relerr(Y, v * s + Q.double()) < 1e-4
+    run_linear(L.EPI_CHAIN, M, Nout, [(X.cuda(), pack(W.cuda()))], act=L.ACT["swish"], S=S, R=Rd, Y=Y, Y2=Y2)
+    assert relerr(Y, v * s) < 1e-4
+    assert torch.isfinite(Y2).all()
+    assert relerr(Y2, v * t.double() * s2) < 5e-4
 
 
 @pytest.mark.parametrize("M,K,Nout,rpg", [(80000, 100, 256, 625),      # short-K kernel, groups of 625 rows (the shipped recipes' nz_cdae)

@@ -26,6 +26,9 @@ CASES = {
     "tiny_mnist_leaky": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "leaky_relu"), O.CdaeCfg("res", 8, 8, 64, 3, "leaky_relu"), 8, torch.float32),
     "tiny_toy_relu_relu": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("grad", 2, 2, 64, 3, "relu"), 8, torch.float32),
     "tiny_mnist_tanh_res": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "tanh"), O.CdaeCfg("res", 8, 8, 64, 3, "tanh"), 8, torch.float32),
+    # swish (utils/models.py:8-10): the seventh and last name of get_nonlinear_func (round 4)
+    "tiny_mnist_swish": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "swish"), O.CdaeCfg("grad", 8, 8, 64, 3, "swish"), 8, torch.float32),
+    "tiny_toy_swish_res": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "swish"), O.CdaeCfg("res", 2, 2, 64, 3, "swish"), 8, torch.float32),
     # --cdae-ctx-type data: the image itself as context (centred for the MNIST family)
     "tiny_mnist_ctxdata": (O.ModelCfg("mnist", 24, 10, 64, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 24, 64, 3), 8, torch.float32),
     "tiny_toy_ctxdata": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "relu"), O.CdaeCfg("res", 2, 2, 64, 3), 8, torch.float32),
