@@ -284,22 +284,25 @@ int cdae_impl(const ardae_cdae_desc* d, const float* params, const float* packed
     return launch_linear_small_chain(pr.data(), ep.data(), lv.data(), (int)pr.size(), chain_cnt, st);
   }
   ARDAE_CHECK_ARG(!a1_ready || a[1] == cdae_a1_slot(P, B, workspace), "cdae: a_1 slot moved (workspace layout and cdae_a1_slot disagree)");
-  if (!a1_ready && linear_small_eligible(inp_layer(1), EPI_ACT)) {
+  const bool few_rows = !a1_ready && linear_small_eligible(inp_layer(1), EPI_ACT);
+  auto ctx_bias = [&]() {  // per-image bias of the first energy layer: cb = W1c c_L + d_1
+    LinArgs A{}; A.bias = params + P.neg[0].b; A.Y = cb; A.ldY = h;
+    return lin(EPI_ACT, ACT_NONE, B, h, cL[L], h, h, packed + K.w1c_f, A, st);
+  };
+  LayerRun run(EPI_ACT, st);      // the forward N-row layers: A_1 (2) .. A_L, then W_1 .. W_L
+  if (few_rows) {
     // few rows: the two encoders are independent chains of per-image launches - level l of both in ONE launch
     for (int l = 1; l <= L; ++l) ARDAE_TRY(launch_linear_pair(ctx_layer(l), inp_layer(l), EPI_ACT, st));
+    ARDAE_TRY(ctx_bias());
   } else {
+    // the whole per-image branch FIRST (context encoder, then the bias it contributes to the first energy layer): the N-row forward
+    // layers of both networks then form ONE run (round 4: one multi-layer launch instead of two with a per-image launch between them)
     for (int l = 1; l <= L; ++l) ARDAE_TRY(launch_linear(ctx_layer(l), EPI_ACT, st));
-    LayerRun run(EPI_ACT, st);
+    ARDAE_TRY(ctx_bias());
     for (int l = a1_ready ? 2 : 1; l <= L; ++l) run.v.push_back(inp_layer(l));   // a1_ready: the perturbation kernel has written a_1
-    ARDAE_TRY(run.flush());
-  }
-  {  // per-image bias of the first energy layer: cb = W1c c_L + d_1
-    LinArgs A{}; A.bias = params + P.neg[0].b; A.Y = cb; A.ldY = h;
-    ARDAE_TRY(lin(EPI_ACT, ACT_NONE, B, h, cL[L], h, h, packed + K.w1c_f, A, st));
   }
   const float* wfc = params + P.neg[L].w;   // grad kind: w [1,h]
   {
-    LayerRun run(EPI_ACT, st);
     for (int l = 1; l <= L; ++l) {
       LinArgs A{}; A.Y = hh[l]; A.ldY = h;
       if (l == 1) {

@@ -35,13 +35,16 @@ __device__ __forceinline__ float u01_open(uint32_t x) { return ((x >> 8) + 1u) *
 __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t offset, uint64_t idx, float v[4]) {
   uint32_t r[4];
   philox4(seed, offset, idx, r);
+  // Box-Muller on the hardware transcendental units (round 4): v_log_f32 is log2, v_sin_f32 / v_cos_f32 take their argument in
+  // REVOLUTIONS, so sin(2 pi u) is one instruction with no range reduction.  ~12 vector-ALU instructions per pair instead of the ~150
+  // of logf + sincosf (the draws fused into latent_perturb_reg_kernel made that kernel issue-bound: SQ_WAIT_INST_ANY = a third of its
+  // wave cycles).  Absolute accuracy ~1e-6 - these are noise samples; what matters is that EVERY draw uses this one definition.
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const float rad = sqrtf(-2.0f * logf(u01_open(r[2 * h])));
-    float sn, cs;
-    sincosf(6.28318530717958647692f * u01_open(r[2 * h + 1]), &sn, &cs);
-    v[2 * h] = rad * cs;
-    v[2 * h + 1] = rad * sn;
+    const float rad = __builtin_amdgcn_sqrtf(-1.38629436111989062f * __builtin_amdgcn_logf(u01_open(r[2 * h])));      // sqrt(-2 ln u)
+    const float rev = u01_open(r[2 * h + 1]);
+    v[2 * h] = rad * __builtin_amdgcn_cosf(rev);
+    v[2 * h + 1] = rad * __builtin_amdgcn_sinf(rev);
   }
 }
 
@@ -568,8 +571,9 @@ int launch_latent_perturb_draw_fwd(const float* latent, const float* z0, int B, 
   const PerturbDraw dr{seed, off_xi, off_eps, (const StepState*)state, first_row, eps_out, wp1, bias1, a1_out, h};
   // few images: S workgroups per image, rows split among them (a slice is a whole number of 32-row blocks), until the grid fills the chip
   const int rg = 256 / zd, passes = (int)(per_image >> 8);
+  static const int target_wgs = debug_knob("ARDAE_LP_WGS") ? atoi(debug_knob("ARDAE_LP_WGS")) : 256;
   int S = 1;
-  while (B * S < 256 && passes % (2 * S) == 0 && (passes / (2 * S)) * rg % 32 == 0) S *= 2;
+  while (B * S < target_wgs && passes % (2 * S) == 0 && (passes / (2 * S)) * rg % 32 == 0) S *= 2;
   const size_t rows_sl = (size_t)(passes / S) * rg;
   const size_t lds = (rows_sl * (zd + LP_XPAD) + rows_sl) * sizeof(float);
 #define ARDAE_LP_FWD(NV_, ACT_)                                                                                                            \

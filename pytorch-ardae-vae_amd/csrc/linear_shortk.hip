@@ -7,6 +7,8 @@
 // fragments of the next block in flight from L2 behind the MFMAs of the current one.  No LDS, no barriers.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "linear.h"
 #include "profile.h"
 
@@ -250,6 +252,158 @@ __global__ __launch_bounds__(256, ((SK_MAXCH > 13 || NOUT2 > 1) ? 1 : 2)) void s
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same fused sampler tail, WEIGHT-STATIONARY, for the shape every MLP configuration of the reference has (h = 256, i.e. 8 hidden column
+// blocks; K <= 104; one head): round 4.  The general kernel above re-reads the packed W1 / W2 fragments for every 32-row block (13 + 4
+// float4 per lane per column block, double buffered: 104 registers of staging) and runs ONE accumulator chain of 52 + 16 dependent MFMAs
+// per column block - 123 us at config #2 against ~66 us of matrix time (0.46 of the FP32 MFMA peak; rocprofv3, round 3).  Here
+//   * a workgroup is persistent over 32-row blocks (row block i, i + grid, ...); wave w owns hidden column blocks 2 w and 2 w + 1 for
+//     EVERY row block, and its slices of the packed weights - W1: 2 x 13 fragments, W2: 2 x 4 - are loaded once, into registers;
+//   * the two column blocks' first-layer products are two INDEPENDENT accumulator chains, interleaved MFMA by MFMA (a dependent
+//     32 x 32 x 2 MFMA issues ~92 cycles after its predecessor, an independent one after 64: scratch/mfma/dep.hip);
+//   * the next row block's noise rows are requested before this block's products start (one whole row block of loads in flight);
+//   * the four waves' partial latent-space sums meet in LDS (double buffered over row blocks: one barrier per row block) and wave w
+//     finishes accumulator registers 4 w .. 4 w + 3.
+// Same order of every sum as sampler_tail_kernel (wave w's two column blocks ARE its column group w; z = ((p0 + p1) + p2) + p3 + bias):
+// bit-identical results - tests/test_engine_gpu.py::test_sampler_bits_do_not_depend_on_images_per_launch covers both kernels' row counts.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TW_CH = 13;      // chunks of 8 k of the first layer (K <= 104)
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void sampler_tail_ws_kernel(const LinArgs a, const TailOut o0, int n2, int nrb) {
+  __shared__ float tile[4][2][32 * ST_LD];      // wave-private: the wave's two hidden blocks of the current row block (accumulator -> A layout)
+  __shared__ float part[2][4][16][64];          // [row-block parity][wave][accumulator register][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int K = a.src[0].K, nch = (K + 7) >> 3;
+
+  // ---- stationary operands
+  f32x4 bw[2][TW_CH], w2[2][4];
+  float bcol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nb = 2 * wave + j;
+    const float* bp = a.src[0].wp + (size_t)nb * nch * 256 + lane * 4;
+#pragma unroll
+    for (int c = 0; c < TW_CH; ++c) {
+      bw[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nch) bw[j][c] = *reinterpret_cast<const f32x4*>(bp + (size_t)c * 256);
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) w2[j][c2] = *reinterpret_cast<const f32x4*>(o0.wp + (size_t)(4 * nb + c2) * 256 + lane * 4);
+    bcol[j] = a.bias ? a.bias[nb * 32 + l31] : 0.f;
+  }
+  const float bz = (o0.bias && l31 < n2) ? o0.bias[l31] : 0.f;
+  const bool rb_two = a.rowbias != nullptr;       // (host: rows_per_group >= 32 whenever there is a row bias)
+
+  auto load_rows = [&](int rb, f32x4 (&av)[TW_CH]) {
+    const float* xr = a.src[0].x + (size_t)(rb * 32 + l31) * a.src[0].ld + 4 * hh;
+#pragma unroll
+    for (int c = 0; c < TW_CH; ++c) {
+      av[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nch && 8 * c + 4 * hh + 4 <= K) av[c] = *reinterpret_cast<const f32x4*>(xr + 8 * c);
+    }
+  };
+
+  f32x4 avA[TW_CH], avB[TW_CH];
+  int rb = blockIdx.x, par = 0;
+  if (rb < nrb) load_rows(rb, avA);
+  // one row block: `av` holds its rows, `avn` receives the next one's (the two register sets swap roles from trip to trip: no copies)
+  auto row_block = [&](const f32x4 (&av)[TW_CH], f32x4 (&avn)[TW_CH]) {
+    const int row0 = rb * 32, rbn = rb + (int)gridDim.x;
+    if (rbn < nrb) load_rows(rbn, avn);            // the next row block's rows: in flight behind this block's products
+    // per-image row bias: the 32 rows belong to at most two images (see linear_shortk_kernel)
+    const int g0 = rb_two ? row0 / a.rows_per_group : 0;
+    const int split = rb_two ? (g0 + 1) * a.rows_per_group - row0 : 32;
+    float pre[2], pre1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (2 * wave + j) * 32 + l31;
+      const float* rbrow = rb_two ? a.rowbias + (size_t)g0 * a.rowbias_ld : nullptr;
+      const float* rbrow1 = (rb_two && split < 32) ? rbrow + a.rowbias_ld : rbrow;
+      pre[j] = bcol[j] + (rb_two ? rbrow[col] : 0.f);
+      pre1[j] = bcol[j] + (rb_two ? rbrow1[col] : 0.f);
+    }
+    // ---- first layer: two independent chains
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < TW_CH; ++c)
+      if (c < nch) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][q], bw[0][c][q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][q], bw[1][c][q], acc1, 0, 0, 0);
+        }
+      }
+    // ---- hidden blocks: accumulator layout (lane = column, registers = rows) -> tile[row][column]
+    float* T0 = tile[wave][0];
+    float* T1 = tile[wave][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      T0[rl * ST_LD + l31] = act_fwd<ACT>(acc0[r] + (rl < split ? pre[0] : pre1[0]));
+      T1[rl * ST_LD + l31] = act_fwd<ACT>(acc1[r] + (rl < split ? pre[1] : pre1[1]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- latent-space layer: this wave's column group (block 2 w, then block 2 w + 1), one chain from zero
+    f32x16 zacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zacc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float* T = j ? T1 : T0;
+#pragma unroll
+      for (int c2 = 0; c2 < 4; ++c2) {
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(T + l31 * ST_LD + 8 * c2 + 4 * hh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[q], w2[j][c2][q], zacc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[par][wave][r][lane] = zacc[r];
+    __syncthreads();        // (the tiles are wave-private; part is double buffered over row blocks: one barrier per row block)
+    // wave w finishes accumulator registers 4 w .. 4 w + 3: rows 8 w + 4 hh + {0 .. 3}, column l31
+    if (l31 < n2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i;
+        const float v = ((part[par][0][r][lane] + part[par][1][r][lane]) + part[par][2][r][lane]) + part[par][3][r][lane];
+        o0.Z[(size_t)(row0 + 8 * wave + 4 * hh + i) * o0.ldz + l31] = v + bz;
+      }
+    }
+    rb = rbn;
+    par ^= 1;
+  };
+  while (rb < nrb) {
+    row_block(avA, avB);
+    if (rb >= nrb) break;
+    row_block(avB, avA);
+  }
+}
+
+inline bool tail_ws_eligible(const LinArgs& a, const TailOut& o1) {
+  static const bool on = !(debug_knob("ARDAE_TAIL_WS") && atoi(debug_knob("ARDAE_TAIL_WS")) == 0);
+  return on && !o1.wp && a.Nout == 256 && ((a.src[0].K + 7) >> 3) <= TW_CH && (!a.rowbias || a.rows_per_group >= 32);
+}
+
+template <int ACT>
+int launch_tail_ws(const LinArgs& a, const TailOut& o0, int n2, hipStream_t st) {
+  if (g_prof_enabled) {
+    char name[64];
+    snprintf(name, sizeof(name), "sampler_tail_ws_kernel<%d>", ACT);
+    const double K = a.src[0].K, nc = (double)n2;
+    prof_begin(st, name, 2.0 * a.M * ((double)a.Nout * K + (double)a.Nout * nc), 4.0 * ((double)a.M * K + (double)a.M * nc + K * a.Nout + (double)a.Nout * nc));
+  }
+  const int nrb = a.M / 32;
+  hipLaunchKernelGGL((sampler_tail_ws_kernel<ACT>), dim3(std::min(nrb, 256)), dim3(256), 0, st, a, o0, n2, nrb);
+  prof_end(st);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int ACT, int MAXCH, int NOUT2>
 int launch_tail_ch(const LinArgs& a, const TailOut& o0, const TailOut& o1, int n2, hipStream_t st) {
   if (g_prof_enabled) {
@@ -271,6 +425,7 @@ int launch_tail_ch(const LinArgs& a, const TailOut& o0, const TailOut& o1, int n
 template <int ACT>
 int launch_tail(const LinArgs& a, const TailOut& o0, const TailOut& o1, int n2, hipStream_t st) {
   const int nch = (a.src[0].K + 7) >> 3;
+  if (tail_ws_eligible(a, o1)) return launch_tail_ws<ACT>(a, o0, n2, st);
   if (o1.wp) {
     if (nch <= 13) return launch_tail_ch<ACT, 13, 2>(a, o0, o1, n2, st);
     return launch_tail_ch<ACT, 16, 2>(a, o0, o1, n2, st);

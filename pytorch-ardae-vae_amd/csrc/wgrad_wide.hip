@@ -16,6 +16,7 @@
 
 #include "profile.h"
 #include "wgrad.h"
+#include "wgrad_wide_tiles.h"
 
 namespace ardae {
 namespace {
@@ -23,7 +24,6 @@ namespace {
 constexpr int WT = 256;                      // tile edge along o (and along i in the square geometry)
 constexpr int WRC = 32;                      // rows per chunk
 constexpr int WCHUNK_BYTES = WRC * WT * 4;   // the G chunk in LDS (32 KiB); the X chunk follows it
-constexpr int WW_MAX_TILES = 32;
 
 // NA x NB MFMA blocks per wave, WOW waves along o
 template <int NA, int NB, int WOW>
@@ -44,21 +44,7 @@ using GeoNarrow = WGeo<2, 1, 4>;   // 256 x 32
 
 typedef __attribute__((address_space(3))) float lds_f32;
 
-struct WwTile {
-  const float* G[2];
-  const float* X[2];
-  const float* rowscale;   // sigma per row (pair `bias_pair` only) or null
-  float* partial;          // [splits][O][I]
-  float* partial_vec;      // [splits][2][O] or null
-  int ldG[2], ldX[2];
-  int M, npairs, O, I, o0, i0, bias_pair, want_vec;
-};
 
-struct WwBatchDev {
-  int ntiles, splits;
-  WwTile t[WW_MAX_TILES];
-};
-static_assert(sizeof(WwBatchDev) <= 4000, "kernel argument block too large");
 
 // s_nop 4: see linear_wide_kernel.h (VALU-written scalar base -> VMEM needs 5 wait states, invisible to the compiler here)
 template <int OFF>
@@ -403,8 +389,16 @@ int launch_wgrad_wide_geo(WgradProblem* probs, const int* idx, int n, hipStream_
     fl += 2.0 * p.npairs * (double)p.M * p.O * p.I;
     by += 4.0 * (p.npairs * (double)p.M * (p.O + p.I) + (double)splits * p.O * p.I);
   }
-  if (g_prof_enabled) prof_begin(st, name, fl, by);
-  hipLaunchKernelGGL(wgrad_wide_kernel<GEO>, dim3(ntiles * splits), dim3(256), 0, st, b);
+  // 256 x 256 tiles: the products are formed on the BF16 matrix cores (wgrad_x9.hip); the FP32-MFMA kernel keeps the 256 x 32 geometry
+  // (a pure stream of G through HBM) and the square problems x9 cannot take
+  bool x9 = GEO::TI == 256;
+  for (int k = 0; x9 && k < n; ++k) x9 = wgrad_x9_eligible(probs[idx[k]]);
+  if (g_prof_enabled) prof_begin(st, x9 ? "wgrad_x9_kernel<256x256>" : name, fl, by);
+  if (x9) {
+    ARDAE_TRY(launch_wgrad_x9(b, st));
+  } else {
+    hipLaunchKernelGGL(wgrad_wide_kernel<GEO>, dim3(ntiles * splits), dim3(256), 0, st, b);
+  }
   prof_end(st);
   ARDAE_LAUNCH_CHECK();
   return n;

@@ -1,0 +1,356 @@
+// Weight gradients of the big N-row problems with the FP32 products formed on the BF16 matrix cores (gfx950, round 4):
+//     dW[o][i] = sum_pairs sum_m G[m][o] X[m][i],   O % 256 == 0, I % 256 == 0, M % 16 == 0.
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs on the vector ALU's FP32 lanes: 64 cycles for 2 k, no co-issue with v_* instructions
+// (scratch/mfma/samewave.hip) - wgrad_wide_kernel sits at 0.86 of that peak and cannot go further.  The BF16 matrix cores do
+// 16 k in 32 cycles (v_mfma_f32_32x32x16_bf16: 2027 TFLOP/s sustained, and up to four v_* instructions per MFMA ride along for free:
+// scratch/mfma/bf16x6.hip), i.e. 16 x the k per cycle.  An fp32 number is the EXACT sum of three bf16 numbers
+//     x = x_h + x_m + x_l        (x_h = the top 16 bits of x, x_m = the top 16 bits of x - x_h, x_l = x - x_h - x_m: 8 + 8 + 8 significand
+//                                 bits, every subtraction exact - the 24-bit significand is CUT into three pieces, no rounding anywhere)
+// so g * x = sum over the NINE piece products g_p x_q, each of which is exact in fp32 (8 x 8 bits), accumulated in fp32 inside the
+// MFMA - the product itself is formed without any rounding, which an fp32 FMA also guarantees and nothing weaker would.  Nine MFMAs
+// of 16 k in 32 cycles each against eight of 2 k in 64: 9 / 16 of the matrix time, measured at least as accurate as the FP32 MFMA
+// chain (32 x 32 x 256 products against float64: max 4.4e-7 / rms 7.2e-8 of the result scale, FP32 MFMA 6.1e-7 / 8.7e-8;
+// tests/test_wgrad_gpu.py::test_wgrad_x9_* hold the kernel to the fp32 kernels' tolerance).
+//
+// How.  One workgroup per CU owns a 256 (o) x 256 (i) tile over a contiguous slice of the concatenated (pair, row) range, four
+// waves = one per SIMD, each a 128 x 128 block = 4 x 4 accumulators (256 accumulator registers) - the geometry of
+// wgrad_wide_kernel, so both operands still cross HBM exactly once per tile.  What differs is the operand path:
+//   * staging: thread t owns COLUMN t of the G and of the X chunk (16 rows): sixteen coalesced global_load_dword per operand (a
+//     wave reads 256 contiguous bytes of one row per instruction), two chunks ahead of their use;
+//   * split: the thread's 8 consecutive rows of a column are exactly one lane's slice of an MFMA operand (8 consecutive k).  It cuts
+//     them into the three bf16 planes (v_and + v_sub twice per element, one v_perm per pair and plane: ~5.5 vector-ALU instructions per
+//     element, riding between the MFMAs) and writes three 16-byte fragments per 8 rows into LDS at [operand][plane][k group][column]: consecutive lanes,
+//     consecutive 16 bytes - conflict-free for the writes and for the fragment reads (one ds_read_b128 per operand block and plane);
+//   * a k-step = the whole chunk: 24 fragment reads feed 16 block pairs x 9 piece products = 144 MFMAs, issued piece-pair by
+//     piece-pair (smallest first) over the 16 independent accumulators, one s_barrier per chunk, two LDS buffers of 48 KiB;
+//   * bias / sigma-column sums come from the staged fp32 values of the thread's column (no LDS reduction needed any more).
+// Partial tiles, the fixed-order split reduction and everything around the launch are shared with wgrad_wide.hip.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "profile.h"
+#include "wgrad.h"
+#include "wgrad_wide_tiles.h"
+
+namespace ardae {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XT = 256;                       // tile edge
+constexpr int XRC = 16;                       // rows per chunk = k of one MFMA
+constexpr int X_PLANE_BYTES = 2 * XT * 16;    // [k group (2)][column (256)] x 16 bytes
+constexpr int X_OP_BYTES = 3 * X_PLANE_BYTES;
+constexpr int X_BUF_BYTES = 2 * X_OP_BYTES;   // G, X: 48 KiB
+
+// s_nop 4: a scalar base the compiler restored with v_readlane needs 5 wait states before a VMEM instruction reads it (linear_wide_kernel.h)
+#ifndef X9_EXP
+#define X9_EXP 0
+#endif
+__device__ __forceinline__ void xload1(float& dst, unsigned voff, const float* sbase) {
+#if X9_EXP & 8
+  dst = 1.f;
+#elif X9_EXP & 1
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+#else
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+#endif
+}
+
+__device__ __forceinline__ void xload4(f32x4& dst, unsigned voff, const float* sbase) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
+// One value cut into its three bf16 pieces, as fp32 bit patterns whose low halves are zero: h = the top 16 bits of x (sign, exponent, 7
+// mantissa bits), m = the top 16 bits of x - h, l = x - h - m (at most 8 significant bits are left: its low half is zero by itself).
+// Both subtractions are exact, so h + m + l == x bit for bit; the pieces share x's sign.
+struct Cut3 { unsigned h, m, l; };
+__device__ __forceinline__ Cut3 cut3(float x) {
+  Cut3 c;
+  c.h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(c.h);
+  c.m = __float_as_uint(r1) & 0xffff0000u;
+  c.l = __float_as_uint(r1 - __uint_as_float(c.m));
+  return c;
+}
+// two pieces (rows 2 q and 2 q + 1 of an operand slice) -> one dword of a bf16 plane: the high halves of `even` and `odd`
+__device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// f(integral_constant<0>) ... f(integral_constant<N - 1>): every index a compile-time constant (register arrays must never be indexed
+// by a loop variable the optimiser has yet to unroll: they would be demoted to scratch memory)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+constexpr int X9_PA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}, X9_PB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};      // (plane of G, plane of X), smallest product first
+
+struct X9Chunk {                 // where a chunk's rows live (wave-uniform)
+  const float* g; const float* x; const float* rs;
+  int ldg, ldx;
+  float fb, fr;                  // 1.0 when the chunk contributes to the bias / sigma-weighted column sums
+};
+
+__global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 2 x X_BUF_BYTES
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wo = wave >> 1, wi = wave & 1;
+  const int ti = (int)blockIdx.x / batch.splits, split = (int)blockIdx.x - ti * batch.splits;
+  // (a copy in registers: read through the reference, every field would be fetched from the kernel-argument segment again after each
+  // asm statement with a memory clobber - a chain of scalar-load latencies at the top of every trip)
+  const WwTile T = batch.t[ti];
+
+  // this workgroup's slice of the concatenated (pair, row) range, in chunks of 16 rows
+  const int cpp = T.M / XRC;
+  const int ctot = cpp * T.npairs;
+  const int cps = (ctot + batch.splits - 1) / batch.splits;
+  const int c_begin = split * cps;
+  const int c_end = c_begin + cps < ctot ? c_begin + cps : ctot;
+
+  auto chunk_at = [&](int ch) {
+    X9Chunk c;
+    const int cc = ch < c_end ? ch : c_end - 1;       // past the end: re-touch the last chunk (never used)
+    const int pr = cc >= cpp ? 1 : 0;
+    const int m0 = (cc - pr * cpp) * XRC;
+    c.ldg = pr ? T.ldG[1] : T.ldG[0];
+    c.ldx = pr ? T.ldX[1] : T.ldX[0];
+    c.g = (pr ? T.G[1] : T.G[0]) + (size_t)m0 * c.ldg + T.o0;
+    c.x = (pr ? T.X[1] : T.X[0]) + (size_t)m0 * c.ldx + T.i0;
+    const bool vec = T.want_vec && pr == T.bias_pair && ch < c_end;
+    c.fb = vec ? 1.f : 0.f;
+    c.fr = (vec && T.rowscale) ? 1.f : 0.f;
+    c.rs = T.rowscale ? T.rowscale + m0 : c.g;        // (no sigma: any readable address, weighted by fr = 0)
+    return c;
+  };
+  // thread t stages column t: rows 0 .. 15 of the chunk (a wave's load = 256 contiguous bytes of one row)
+  auto issue_loads = [&](const X9Chunk& c, float (&g)[XRC], float (&x)[XRC], f32x4 (&rs)[4]) {
+    // sigma of the chunk's 16 rows (every lane reads the same 64 bytes; travels with the rows, two chunks ahead of its use: a scalar load
+    // issued in the trip that needs it would expose its latency once per chunk)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xload4(rs[q], 0u, c.rs + 4 * q);
+    const float* pg = c.g;
+    const float* px = c.x;
+#pragma unroll
+    for (int j = 0; j < XRC; ++j) { xload1(g[j], (unsigned)tid * 4u, pg); pg += c.ldg; }      // (one 64-bit scalar add per row)
+#pragma unroll
+    for (int j = 0; j < XRC; ++j) { xload1(x[j], (unsigned)tid * 4u, px); px += c.ldx; }
+  };
+  float bsum = 0.f, rsum = 0.f;
+  // the three fragments of one operand's k group (rows 8 kg .. 8 kg + 7 of this thread's column)
+  auto write_group = [&](const u32x4& h, const u32x4& m, const u32x4& l, int op, int kg, unsigned char* buf) {
+    unsigned char* p = buf + op * X_OP_BYTES + (kg * XT + tid) * 16;
+    *reinterpret_cast<u32x4*>(p) = h;
+    *reinterpret_cast<u32x4*>(p + X_PLANE_BYTES) = m;
+    *reinterpret_cast<u32x4*>(p + 2 * X_PLANE_BYTES) = l;
+  };
+  auto stage_group = [&](const float (&v)[XRC], int op, int kg, unsigned char* buf) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const Cut3 e = cut3(v[8 * kg + 2 * q]), o = cut3(v[8 * kg + 2 * q + 1]);
+      h[q] = pack_hi(e.h, o.h); m[q] = pack_hi(e.m, o.m); l[q] = pack_hi(e.l, o.l);
+    }
+    write_group(h, m, l, op, kg, buf);
+  };
+  auto column_sums = [&](const X9Chunk& c, const float (&g)[XRC]) {      // bias / sigma gradients: this thread's column of G (branch-free)
+    float s = 0.f, r = 0.f;
+#pragma unroll
+    for (int j = 0; j < XRC; ++j) {
+      s += g[j];
+      r += g[j] * c.rs[j];
+    }
+    bsum += s * c.fb; rsum += r * c.fr;
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (c_begin < c_end) {
+    float gc[XRC], xc[XRC], gn[XRC], xn[XRC];
+    f32x4 rsc[4], rsn[4];
+    // ---- prologue: chunk c_begin -> buffer 0; chunk c_begin + 1 staged in registers; nothing else in flight
+    {
+      const X9Chunk c0 = chunk_at(c_begin);
+      issue_loads(c0, gc, xc, rsc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < XRC; ++j) asm volatile("" : "+v"(gc[j]), "+v"(xc[j]));
+      column_sums(c0, gc);
+      stage_group(gc, 0, 0, lds); stage_group(gc, 0, 1, lds); stage_group(xc, 1, 0, lds); stage_group(xc, 1, 1, lds);
+      issue_loads(chunk_at(c_begin + 1), gc, xc, rsc);
+      __syncthreads();
+      // landed BEFORE the loop is entered: values defined by asm loads must not be in flight at a control-flow join (the compiler may
+      // reconcile the loop header's definitions with register moves it believes are safe - linear_wide_kernel.h)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < XRC; ++j) asm volatile("" : "+v"(gc[j]), "+v"(xc[j]));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rsc[q]));
+    }
+    int buf = 0;
+    // Fragments: lane (row / column l31 of the block, k group hh), one ds_read_b128 per operand block and plane, read ONCE per chunk and
+    // kept in registers (96): re-reading two planes per product would need 64 bytes per clock of LDS bandwidth per CU.
+    bf16x8 Af[3][4], Bf[3][4];
+    auto read_plane = [&](auto pp, const unsigned char* from) {
+      constexpr int p = decltype(pp)::value;
+      static_for<4>([&](auto aa) {
+        constexpr int a = decltype(aa)::value;
+        Af[p][a] = *reinterpret_cast<const bf16x8*>(from + p * X_PLANE_BYTES + (hh * XT + wo * 128 + a * 32 + l31) * 16);
+      });
+      static_for<4>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        Bf[p][b] = *reinterpret_cast<const bf16x8*>(from + X_OP_BYTES + p * X_PLANE_BYTES + (hh * XT + wi * 128 + b * 32 + l31) * 16);
+      });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    read_plane(I2{}, lds);      // the first chunk's l and m planes (every later chunk's are read in the tail of the trip before it)
+    read_plane(I1{}, lds);
+    // One chunk per trip: gc / xc / rsc hold chunk ch + 1 (landed), gn / xn / rsn receive chunk ch + 2.  The trip's 144 MFMAs - the nine
+    // piece products (plane of G, plane of X), smallest first: (l,l) (m,l) (l,m) (h,l) (l,h) (m,m) (h,m) (m,h) (h,h) - run as ONE stream;
+    // everything else sits BETWEEN two MFMAs in program order (sched_barrier pins it), because only there the vector ALU, the LDS and
+    // the memory pipes work beside the matrix cores (about four v_* per 32-cycle MFMA are free: scratch/mfma/bf16x6.hip):
+    //   MFMA 0           the chunk's h-plane fragments are requested (first needed by product 3; l and m planes are in registers)
+    //   MFMA 1, 3 .. 71  the 36 loads of chunk ch + 2, one at a time (issued back to back they cost ~2000 idle cycles per trip)
+    //   MFMA 0, 3 .. 93  chunk ch + 1 is cut into its bf16 planes, one element (~6 v_*) per slot; a k group's three fragment writes
+    //                    follow its eighth element one per MFMA (all four waves writing three fragments at once stalls the stream)
+    //   MFMA 111         s_barrier: chunk ch + 1 is complete in the other LDS buffer (and nobody reads this one any more)
+    //   MFMA 112 ..      its l-plane fragments replace this chunk's (dead since product 4), from MFMA 128 its m-plane (dead since
+    //                    product 7): the next trip starts on operands that are already in registers
+    //   MFMA 112 .. 127  bias / sigma column sums of the staged rows;  MFMA 128 ..: chunk ch + 2 has landed and becomes the staged one
+    // (in-kernel cycle stamps, round 4: 8200 cycles per trip with everything at the top of the trip, 4608 are MFMA issue slots).
+#pragma unroll 1
+    for (int ch = c_begin; ch < c_end; ++ch) {
+      unsigned char* cur = lds + buf * X_BUF_BYTES;
+      unsigned char* oth = lds + (buf ^ 1) * X_BUF_BYTES;
+      const X9Chunk c1 = chunk_at(ch + 1);
+      const X9Chunk c2 = chunk_at(ch + 2);
+      const float* pgn = c2.g;
+      const float* pxn = c2.x;
+      u32x4 sh, sm, sl;
+      Cut3 ce{0u, 0u, 0u};
+      float cs = 0.f, cr = 0.f;
+      static_for<144>([&](auto nn) {
+        constexpr int n = decltype(nn)::value, s = n >> 4, idx = n & 15, a = idx >> 2, b = idx & 3;
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[X9_PA[s]][a], Bf[X9_PB[s]][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n == 0) {
+          read_plane(I0{}, cur);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr ((n & 1) == 1 && n < 72) {           // load q of chunk ch + 2: 16 rows of G, 16 rows of X, sigma of the 16 rows
+          constexpr int q = n >> 1;
+          if constexpr (q < 16) { xload1(gn[q], (unsigned)tid * 4u, pgn); pgn += c2.ldg; }
+          else if constexpr (q < 32) { xload1(xn[q - 16], (unsigned)tid * 4u, pxn); pxn += c2.ldx; }
+          else xload4(rsn[q - 32], 0u, c2.rs + 4 * (q - 32));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (n < 96 && n % 3 == 0) {             // element e of the staged chunk is cut behind MFMA 3 e
+          constexpr int e = n / 3, op = e >> 4, j = e & 15, pos = j & 7;
+#if X9_EXP & 4
+          const Cut3 c{__float_as_uint(op ? xc[j] : gc[j]), 0u, 0u};
+#else
+          const Cut3 c = cut3(op ? xc[j] : gc[j]);
+#endif
+          if constexpr ((pos & 1) == 0) {
+            ce = c;
+          } else {
+            sh[pos >> 1] = pack_hi(ce.h, c.h); sm[pos >> 1] = pack_hi(ce.m, c.m); sl[pos >> 1] = pack_hi(ce.l, c.l);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (n < 96 && n >= 21 && (n - 21) % 24 < 3) {      // group (op, kg) is complete behind MFMA 21 + 24 g: its planes, one per MFMA
+          constexpr int g = (n - 21) / 24, pl = (n - 21) % 24;
+          unsigned char* p = oth + (g >> 1) * X_OP_BYTES + ((g & 1) * XT + tid) * 16 + pl * X_PLANE_BYTES;
+#if !(X9_EXP & 2)
+          *reinterpret_cast<u32x4*>(p) = pl == 0 ? sh : pl == 1 ? sm : sl;
+#else
+          (void)p;
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (n == 111) {
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (n == 112) {
+          read_plane(I2{}, oth);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (s == 7) {                       // column sums of the staged chunk: one row per MFMA
+          cs += gc[idx]; cr += gc[idx] * rsc[idx >> 2][idx & 3];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (s == 8) {                       // chunk ch + 2 has had the whole trip to land: it becomes the staged chunk
+          if constexpr (idx == 0) {
+            read_plane(I1{}, oth);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < XRC; ++j) asm volatile("" : "+v"(gn[j]), "+v"(xn[j]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rsn[q]));
+          }
+          gc[idx] = gn[idx]; xc[idx] = xn[idx];
+          if constexpr (idx < 4) rsc[idx] = rsn[idx];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      bsum += cs * c1.fb; rsum += cr * c1.fr;
+      buf ^= 1;
+    }
+  }
+
+  // ---- partial tile store: partial[split][o][i] (zeros when the slice was empty: the reduction sums every split)
+  float* __restrict__ part = T.partial + (size_t)split * T.O * T.I;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = T.i0 + wi * 128 + b * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = T.o0 + wo * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        part[(size_t)o * T.I + i] = acc[a][b][r];
+      }
+    }
+  }
+  if (T.want_vec && T.i0 == 0) {
+    T.partial_vec[((size_t)split * 2 + 0) * T.O + T.o0 + tid] = bsum;
+    T.partial_vec[((size_t)split * 2 + 1) * T.O + T.o0 + tid] = rsum;
+  }
+}
+
+}  // namespace
+
+bool wgrad_x9_eligible(const WgradProblem& p) {
+  static const bool off = debug_knob("ARDAE_WGRAD_X9") && atoi(debug_knob("ARDAE_WGRAD_X9")) == 0;
+  if (off || p.O % XT || p.I % XT || p.M % XRC || p.M < 64 * 32) return false;
+  for (int k = 0; k < p.npairs; ++k)
+    if ((int64_t)p.ldG[k] * XRC * 4 >= (int64_t)1 << 31 || (int64_t)p.ldX[k] * XRC * 4 >= (int64_t)1 << 31) return false;
+  return true;
+}
+
+int launch_wgrad_x9(const WwBatchDev& b, hipStream_t st) {
+  static const bool attr_set = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X_BUF_BYTES) == hipSuccess;
+  }();
+  ARDAE_CHECK_ARG(attr_set, "wgrad_x9: cannot reserve %d bytes of LDS", 2 * X_BUF_BYTES);
+  hipLaunchKernelGGL(wgrad_x9_kernel, dim3(b.ntiles * b.splits), dim3(256), 2 * X_BUF_BYTES, st, b);
+  return 0;
+}
+
+}  // namespace ardae
