@@ -155,38 +155,42 @@ def test_iwae64_after_equal_steps_matches_the_oracle():
 
 
 def test_iwae64_config2_widths_on_production_kernels(golden_dir):
-    """The quality gate at BASELINE config #2's WIDTHS (784 pixels, noise 100, h 256, z 32; cDAE mlp-grad h 256 L 3) with 32 images x
-    256 Monte-Carlo rows per batch = 8192 rows, i.e. on the production N-row kernels (software-pipelined linear / layer-chain kernels,
-    256 x 256 weight gradients) - the small-problem gate above only reaches the generic ones.
+    """The north-star quality gate - IWAE-64 within 0.2 nats of the reference after equal steps - at BASELINE config #2's WIDTHS (784 pixels,
+    noise 100, h 256, z 32; cDAE mlp-grad h 256 L 3) with 32 images x 256 Monte-Carlo rows per batch = 8192 rows, i.e. on the production
+    kernels (software-pipelined N-row / layer-chain kernels, bf16x9 weight gradients, 16 x 16 per-image blocks).
 
-    Oracle side: `tests/golden/quality_cfg2.npz`, written by `oracle/gen_quality_golden.py` (the CPU oracle trained for 1000 steps at
-    lr 3e-4 on the batches this test regenerates from the same generator seeds, three noise seeds, IWAE-64 on 256 held-out images
-    every 100 steps; ~4 minutes of CPU per seed, which is why it travels as a fixture).  Engine side: trained here, three seeds with its own
-    Philox noise and three with the ORACLE's noise injected (same seeds as the fixture).
+    Oracle side: `tests/golden/quality_cfg2.npz`, written by `oracle/gen_quality_golden.py` (the CPU oracle - the pinned restatement of
+    ivae_ardae.py:707-846 - trained for 2400 steps at lr 3e-4 on the batches this test regenerates from the same generator seeds, one run
+    per noise seed, IWAE-64 on 256 held-out images every 100 steps; 30 minutes of CPU per seed, which is why it travels as a fixture).
+    Engine side: trained here, six seeds with its own Philox noise and one run on each of the first four ORACLE noise streams, injected.
 
-    What can be asserted.  Training at these widths is still in its noisy phase after 1000 steps: single IWAE-64 values jump by 10-25
-    nats between neighbouring checkpoints for EITHER trainer (oracle seed 1: -276.9 / -280.3 / -267.2 at steps 400 / 600 / 800; the
-    engine likewise), so a 0.2-nat gate on single values is a coin toss here, whoever computes the gradients - the 0.2-nat gate itself is
-    the small-problem test above, where training converges.  The statistic here is robust to those excursions: the MEDIAN of the
-    last five checkpoints' values (steps 600-1000).  Gates: both trainers have moved > 200 nats from the initial
-    model; the seed-averaged statistic of the engine (own noise) lies within 0.2 nats + two standard errors (from the two trainers'
-    seed-to-seed spread) of the oracle's; every engine run lies inside the oracle's range widened by the bound measured for chaotic
-    divergence of identical trainings, and with the oracle's noise injected every seed's statistic stays within that bound of its oracle run.
-    Measured (MI355X, round 3): initial model -2708.2; oracle -266.83 / -267.99 / -267.97 (mean -267.60); engine with its own noise
-    -268.84 / -268.23 / -270.15 (mean -269.07: 1.47 nats from the oracle's mean at a standard error of 0.68); engine with the oracle's
-    noise -270.83 / -269.38 / -268.56.  THE RESOLUTION OF THIS STATISTIC, measured directly: the same engine with its per-image layers on
-    32 x 32 instead of 16 x 16 blocks (`ARDAE_SMALL16_MAX_BLOCKS=0`: the same arithmetic to 1e-7 rms against float64 for either -
-    scratch/err_small.py - only the order of the fp32 sums over k differs) ends at -267.48 / -267.92 / -268.64 and -267.77 / -267.89 /
-    -268.49: identical seeds, batches and noise, 0.07 - 3.06 nats apart.  I.e. 2440 nats of progress and agreement at the level at which
-    two roundings of ONE trainer agree (a few nats) - which is what this training length can resolve; it cannot resolve 0.2 nats."""
+    The statistic (round 4).  Single checkpoints of the RAW weights cannot carry a 0.2-nat gate: even on the plateau (from step ~1400) they
+    jump by 1 - 10 nats between neighbouring checkpoints, for either trainer (oracle seed 2024: -263.9 / -265.6 / -263.9 / -271.8 within
+    700 steps).  Evaluated on an exponential moving average of the weights instead (decay 0.99, updated every step: Polyak averaging, the
+    evaluation mode the reference itself offers - `--weight-avg polyak`, ivae_ardae.py:560-565,646-647) the bound is smooth; the MEDIAN of
+    its last five checkpoints (steps 2000 - 2400) differs by 0.1 - 0.2 nats between noise seeds of ONE trainer (standard deviation: oracle
+    0.19, engine 0.18).  That resolves the north star's tolerance:
+      * the engine is not WORSE than the oracle by more than the north star's 0.2 nats: mean over seeds (engine, own noise) >= mean over
+        seeds (oracle) - 0.2 (the one-sided check: a systematic loss of quality cannot hide in seed noise);
+      * |difference of the two means| <= 0.2 + two standard errors of that difference (from the two trainers' seed-to-seed spreads);
+      * every engine run inside the oracle's seed range widened by 0.75 nats on both sides;
+      * with the oracle's noise injected, every seed's BEST late checkpoint within QG2_SHARED_BOUND = 2.0 nats of its oracle run's.  (Best
+        of five, not the median: identical trainings drift apart chaotically at the level of single weights, and either trainer now and
+        then runs into an excursion of the raw weights - oracle seed 2024: -271.8 at step 1700 - that drags the averaged weights down for
+        the next ~300 steps; the engine run on seed 2024's noise had one at steps 2200 - 2400: -266.8 / -268.6 / -265.9 against -263.4
+        before it.  Measured paired differences of the best checkpoints: -0.13 / -0.01 / +0.56 / +0.13 nats.)
+      * both trainers have moved > 2400 nats from the initial model (-2708).
+    Measured (MI355X, round 4; medians of the five late checkpoints, four oracle seeds): oracle -263.56 / -263.28 / -263.61 / -263.24 (mean
+    -263.42); engine with its own noise -262.97 / -263.13 / -263.07 / -263.13 / -263.25 / -263.51 (mean -263.18: 0.25 +- 0.12 nats ABOVE
+    the oracle - both trainers still improve by ~0.15 nats per 100 steps there: the engine is level with the oracle of ~150 steps later)."""
     import numpy as np
     from oracle.gen_quality_golden import MC as M2, CC as C2, B as B2, NZ as NZ2, K as K2, batches, eval_set
     fx = np.load(os.path.join(golden_dir, "quality_cfg2.npz"))
-    lr, steps, marks, seeds = float(fx["lr"]), int(fx["steps"]), [int(m) for m in fx["marks"]], [int(s) for s in fx["seeds"]]
-    assert int(fx["B"]) == B2 and int(fx["NZ"]) == NZ2 and int(fx["K"]) == K2
-    late = [i for i, m in enumerate(marks) if m >= 600]
-    stat = lambda row: float(np.median([row[i] for i in late]))
-    ref = [stat(fx["iwae"][s]) for s in range(len(seeds))]
+    lr, steps, marks, seeds, decay = float(fx["lr"]), int(fx["steps"]), [int(m) for m in fx["marks"]], [int(s) for s in fx["seeds"]], float(fx["ema"])
+    assert int(fx["B"]) == B2 and int(fx["NZ"]) == NZ2 and int(fx["K"]) == K2 and steps >= 2400 and len(seeds) >= 4
+    late = [i for i, m in enumerate(marks) if m >= steps - 400]
+    stat = lambda row: float(np.median(row))            # over the five late checkpoints
+    ref = [stat(fx["iwae_ema"][s][late]) for s in range(len(seeds))]
     ll_init = float(fx["iwae_init"])
     pm0 = O.init_params(O.model_param_spec(M2), 0, O.model_init_special(M2))
     pc0 = O.init_params(O.cdae_param_spec(C2), 1)
@@ -194,6 +198,8 @@ def test_iwae64_config2_widths_on_production_kernels(golden_dir):
     bs = batches(steps)
     tc = O.TrainCfg(nz_cdae=NZ2, m_lr=lr, d_lr=lr)
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    names = [n for n, _ in O.model_param_spec(M2)]
+    rows = []
 
     def train(seed, shared):
         model = net.MNISTIPVAE(input_dim=M2.input_dim, noise_dim=M2.noise_dim, h_dim=M2.h_dim, num_hidden_layers=M2.n_layers, nonlinearity=M2.nonlin,
@@ -205,28 +211,42 @@ def test_iwae64_config2_widths_on_production_kernels(golden_dir):
         net.manual_seed(seed)
         eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ2, m_lr=lr, d_lr=lr), batch_size=B2)
         gn = torch.Generator().manual_seed(seed)
-        row = []
+        ema = model.flat_params().clone()                  # the parameters are views of this flat buffer, in named_parameters() order
+        vals = []
         for t, (x1, x2) in enumerate(bs, 1):
             if shared:
                 noise = O.draw_step_noise(M2, tc, B2, gn)
                 eng.step(x1.cuda(), x2.cuda(), noise={k: v.cuda().contiguous() for k, v in noise.items()})
             else:
                 eng.step(x1.cuda(), x2.cuda())
-            if t in marks:
-                pm = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-                row.append(float(O.iwae_logprob(M2, pm, x_eval, K2, enc_noise, prop_noise)))
+            ema.lerp_(model.flat_params(), 1.0 - decay)
+            if t in marks and marks.index(t) in late:
+                flat, pe, off = ema.cpu(), {}, 0
+                for n, shp in O.model_param_spec(M2):
+                    k = int(np.prod(shp)); pe[n] = flat[off:off + k].view(*shp).clone(); off += k
+                assert off == flat.numel() and list(model.state_dict().keys()) == names
+                vals.append(float(O.iwae_logprob(M2, pe, x_eval, K2, enc_noise, prop_noise)))
         assert all(v == v for v in eng.stats().values())
-        return row
+        rows.append(np.round(vals, 2).tolist())
+        return stat(vals)
 
-    own = [stat(train(s, False)) for s in (31337, 11, 12)]
-    shared = [stat(train(s, True)) for s in seeds]
-    print(f"config-#2 widths, median IWAE-{K2} of steps {[marks[i] for i in late]}: init {ll_init:.2f}  oracle {ref}  engine(own noise) {own}  engine(oracle's noise) {shared}")
+    own = [train(s, False) for s in (31337, 11, 12, 13, 14, 15)]
+    shared_seeds = seeds[:4]
+    shared = [train(s, True) for s in shared_seeds]
     m_ref, m_own = float(np.mean(ref)), float(np.mean(own))
-    assert m_ref - ll_init > 200.0 and m_own - ll_init > 200.0, (ll_init, ref, own)
     se = float(np.sqrt(np.var(ref, ddof=1) / len(ref) + np.var(own, ddof=1) / len(own)))
+    print("per-checkpoint values (engine own noise x 6, engine on the oracle's noise x 4):", rows, " oracle:", np.round(fx["iwae_ema"][:, late], 2).tolist())
+    print(f"config-#2 widths, IWAE-{K2} of the averaged weights, median over steps {[marks[i] for i in late]}: init {ll_init:.2f}  oracle {np.round(ref, 3).tolist()} "
+          f"(mean {m_ref:.3f})  engine(own noise) {np.round(own, 3).tolist()} (mean {m_own:.3f}, difference {m_own - m_ref:+.3f} +- {se:.3f})  "
+          f"engine(oracle's noise) {np.round(shared, 3).tolist()}")
+    assert m_ref - ll_init > 2400.0 and m_own - ll_init > 2400.0, (ll_init, ref, own)
+    assert m_own >= m_ref - 0.2, (ref, own, se)                                             # north-star tolerance, on the side that matters
     assert abs(m_own - m_ref) <= 0.2 + 2.0 * se, (ref, own, se)
-    assert all(min(ref) - QG2_SHARED_BOUND <= v <= max(ref) + QG2_SHARED_BOUND for v in own), (ref, own)
-    assert all(abs(a - b) <= QG2_SHARED_BOUND for a, b in zip(shared, ref)), (ref, shared)
+    assert all(min(ref) - 0.75 <= v <= max(ref) + 0.75 for v in own), (ref, own)
+    best_ref = [float(np.max(fx["iwae_ema"][s][late])) for s in range(len(shared_seeds))]
+    best_shared = [float(np.max(r)) for r in rows[len(own):]]
+    print("best late checkpoints, engine on the oracle's noise vs oracle:", np.round(best_shared, 2).tolist(), np.round(best_ref, 2).tolist())
+    assert all(abs(a - b) <= QG2_SHARED_BOUND for a, b in zip(best_shared, best_ref)), (best_ref, best_shared)
 
 
-QG2_SHARED_BOUND = 5.0     # nats: identical trainings (same batches, same noise) drift apart chaotically - two roundings of the engine: up to 3.06 apart, up to 3.99 from the oracle run of the same seed
+QG2_SHARED_BOUND = 2.0     # nats (the value before round 3 widened it): identical trainings (same batches, same noise) drift apart chaotically
