@@ -47,21 +47,30 @@ constexpr int X_OP_BYTES = 3 * X_PLANE_BYTES;
 constexpr int X_BUF_BYTES = 2 * X_OP_BYTES;   // G, X: 48 KiB
 
 // s_nop 4: a scalar base the compiler restored with v_readlane needs 5 wait states before a VMEM instruction reads it (linear_wide_kernel.h)
-#ifndef X9_EXP
-#define X9_EXP 0
-#endif
+// The staged rows are loaded with inline asm (hipcc sinks ordinary prefetch loads to their first use) into the SAME registers trip after trip:
+// the operand is read-write, so every definition is tied to its predecessor's register and the loop's back edge needs no copy - a copy of
+// a register whose load is still in flight would read garbage (tools/check_kernel_registers.py looks for exactly that).
+// s_nop 4: a scalar base the compiler restored with v_readlane needs 5 wait states before a VMEM instruction reads it (linear_wide_kernel.h)
 __device__ __forceinline__ void xload1(float& dst, unsigned voff, const float* sbase) {
-#if X9_EXP & 8
-  dst = 1.f;
-#elif X9_EXP & 1
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-#else
-  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-#endif
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
-
 __device__ __forceinline__ void xload4(f32x4& dst, unsigned voff, const float* sbase) {
-  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// Loads retire in order: "at most N newer ones may still be in flight" lands everything older.  The wait names NO register: a read-write
+// operand would let the compiler give the waited-for value another register - through a copy placed BEFORE the wait, i.e. a copy of a
+// register whose load is still in flight (seen in the first version of this kernel; tools/check_kernel_registers.py).  Instead the first
+// instructions that touch a freshly landed register are asm volatile statements too (which the compiler keeps in order behind the wait)
+// and hand ordinary values on: the top half (first piece of the cut) and a copy for everything else.
+template <int N>
+__device__ __forceinline__ void xwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+__device__ __forceinline__ void take_landed(const float& loaded, unsigned& top, float& copy) {
+  asm volatile("v_and_b32 %0, 0xffff0000, %2\n\tv_mov_b32 %1, %2" : "=&v"(top), "=&v"(copy) : "v"(loaded));
+}
+__device__ __forceinline__ void take_landed(const f32x4& loaded, f32x4& copy) {
+  asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+               : "=&v"(copy[0]), "=&v"(copy[1]), "=&v"(copy[2]), "=&v"(copy[3])
+               : "v"(loaded[0]), "v"(loaded[1]), "v"(loaded[2]), "v"(loaded[3]));
 }
 
 // One value cut into its three bf16 pieces, as fp32 bit patterns whose low halves are zero: h = the top 16 bits of x (sign, exponent, 7
@@ -131,15 +140,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
     return c;
   };
   // thread t stages column t: rows 0 .. 15 of the chunk (a wave's load = 256 contiguous bytes of one row)
+  // A chunk's 36 loads in THE order every trip re-issues them in: G rows 0 .. 15 with the sigma quad q behind row 4 q + 3, then X rows
+  // 0 .. 15 (loads retire in order, so "the value I am about to use has landed" is a compile-time vmcnt count: see the trip below)
   auto issue_loads = [&](const X9Chunk& c, float (&g)[XRC], float (&x)[XRC], f32x4 (&rs)[4]) {
-    // sigma of the chunk's 16 rows (every lane reads the same 64 bytes; travels with the rows, two chunks ahead of its use: a scalar load
-    // issued in the trip that needs it would expose its latency once per chunk)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) xload4(rs[q], 0u, c.rs + 4 * q);
     const float* pg = c.g;
     const float* px = c.x;
 #pragma unroll
-    for (int j = 0; j < XRC; ++j) { xload1(g[j], (unsigned)tid * 4u, pg); pg += c.ldg; }      // (one 64-bit scalar add per row)
+    for (int j = 0; j < XRC; ++j) {
+      xload1(g[j], (unsigned)tid * 4u, pg); pg += c.ldg;       // (one 64-bit scalar add per row)
+      if ((j & 3) == 3) xload4(rs[j >> 2], 0u, c.rs + (j & ~3));
+    }
 #pragma unroll
     for (int j = 0; j < XRC; ++j) { xload1(x[j], (unsigned)tid * 4u, px); px += c.ldx; }
   };
@@ -160,15 +170,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
     }
     write_group(h, m, l, op, kg, buf);
   };
-  auto column_sums = [&](const X9Chunk& c, const float (&g)[XRC]) {      // bias / sigma gradients: this thread's column of G (branch-free)
-    float s = 0.f, r = 0.f;
-#pragma unroll
-    for (int j = 0; j < XRC; ++j) {
-      s += g[j];
-      r += g[j] * c.rs[j];
-    }
-    bsum += s * c.fb; rsum += r * c.fr;
-  };
 
   f32x16 acc[4][4];
 #pragma unroll
@@ -179,26 +180,30 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   if (c_begin < c_end) {
-    float gc[XRC], xc[XRC], gn[XRC], xn[XRC];
-    f32x4 rsc[4], rsn[4];
-    // ---- prologue: chunk c_begin -> buffer 0; chunk c_begin + 1 staged in registers; nothing else in flight
+    float gc[XRC], xc[XRC];
+    f32x4 rsc[4];
+#pragma unroll
+    for (int j = 0; j < XRC; ++j) gc[j] = xc[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rsc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- prologue: chunk c_begin -> buffer 0 (latency exposed once per launch); chunk c_begin + 1 requested into the staging registers
     {
       const X9Chunk c0 = chunk_at(c_begin);
       issue_loads(c0, gc, xc, rsc);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int j = 0; j < XRC; ++j) asm volatile("" : "+v"(gc[j]), "+v"(xc[j]));
-      column_sums(c0, gc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rsc[q]));
+      {
+        float s0 = 0.f, r0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < XRC; ++j) { s0 += gc[j]; r0 += gc[j] * rsc[j >> 2][j & 3]; }
+        bsum += s0 * c0.fb; rsum += r0 * c0.fr;
+      }
       stage_group(gc, 0, 0, lds); stage_group(gc, 0, 1, lds); stage_group(xc, 1, 0, lds); stage_group(xc, 1, 1, lds);
       issue_loads(chunk_at(c_begin + 1), gc, xc, rsc);
       __syncthreads();
-      // landed BEFORE the loop is entered: values defined by asm loads must not be in flight at a control-flow join (the compiler may
-      // reconcile the loop header's definitions with register moves it believes are safe - linear_wide_kernel.h)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < XRC; ++j) asm volatile("" : "+v"(gc[j]), "+v"(xc[j]));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rsc[q]));
     }
     int buf = 0;
     // Fragments: lane (row / column l31 of the block, k group hh), one ds_read_b128 per operand block and plane, read ONCE per chunk and
@@ -220,19 +225,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
     using I2 = std::integral_constant<int, 2>;
     read_plane(I2{}, lds);      // the first chunk's l and m planes (every later chunk's are read in the tail of the trip before it)
     read_plane(I1{}, lds);
-    // One chunk per trip: gc / xc / rsc hold chunk ch + 1 (landed), gn / xn / rsn receive chunk ch + 2.  The trip's 144 MFMAs - the nine
-    // piece products (plane of G, plane of X), smallest first: (l,l) (m,l) (l,m) (h,l) (l,h) (m,m) (h,m) (m,h) (h,h) - run as ONE stream;
-    // everything else sits BETWEEN two MFMAs in program order (sched_barrier pins it), because only there the vector ALU, the LDS and
-    // the memory pipes work beside the matrix cores (about four v_* per 32-cycle MFMA are free: scratch/mfma/bf16x6.hip):
-    //   MFMA 0           the chunk's h-plane fragments are requested (first needed by product 3; l and m planes are in registers)
-    //   MFMA 1, 3 .. 71  the 36 loads of chunk ch + 2, one at a time (issued back to back they cost ~2000 idle cycles per trip)
-    //   MFMA 0, 3 .. 93  chunk ch + 1 is cut into its bf16 planes, one element (~6 v_*) per slot; a k group's three fragment writes
-    //                    follow its eighth element one per MFMA (all four waves writing three fragments at once stalls the stream)
-    //   MFMA 111         s_barrier: chunk ch + 1 is complete in the other LDS buffer (and nobody reads this one any more)
-    //   MFMA 112 ..      its l-plane fragments replace this chunk's (dead since product 4), from MFMA 128 its m-plane (dead since
-    //                    product 7): the next trip starts on operands that are already in registers
-    //   MFMA 112 .. 127  bias / sigma column sums of the staged rows;  MFMA 128 ..: chunk ch + 2 has landed and becomes the staged one
-    // (in-kernel cycle stamps, round 4: 8200 cycles per trip with everything at the top of the trip, 4608 are MFMA issue slots).
+    // One chunk per trip.  The trip's 144 MFMAs - the nine piece products (plane of G, plane of X), smallest first: (l,l) (m,l) (l,m) (h,l)
+    // (l,h) (m,m) (h,m) (m,h) (h,h) - run as ONE stream; everything else sits in a GAP between two MFMAs (sched_barrier pins the program
+    // order), because only there the vector ALU, the LDS and the memory pipes work beside the matrix cores, and only while a gap's
+    // instructions take less than the MFMA's 32 cycles (about four v_* or one memory instruction: scratch/mfma/bf16x6.hip; in-kernel cycle
+    // stamps, round 4: 8200 cycles per trip with loads, cuts and fragment reads bunched, 4608 are MFMA issue slots).  Gap by gap:
+    //   the staged chunk (ch + 1, in gc / xc: 16 rows of G, 16 of X per thread) is cut pair by pair, seven gaps per pair of rows:
+    //     wait + cut first half of row 2 p (and its share of the bias column sum) | second half (and of the sigma column sum) | RE-LOAD
+    //     the register with row 2 p of chunk ch + 2 | the same three for row 2 p + 1 | pack the pair into the three planes' dwords;
+    //     behind every fourth pair (one k group of an operand) three gaps write its three fragments to the other LDS buffer;
+    //   a row's register is re-loaded the moment it has been cut, so a load has a whole trip to land and needs no second register set:
+    //     loads retire in order and every trip issues the same 36 in the same order, so when row e is cut exactly 35 newer loads may be in
+    //     flight (its sigma quad: 31) - a compile-time vmcnt;
+    //   gap 0 also requests the chunk's h-plane fragments (first needed by product 3; l and m planes are in registers already);
+    //   gap 124: s_barrier - chunk ch + 1 is complete in the other buffer, nobody reads this one any more;
+    //   gap 125 / 128: its l- and m-plane fragments replace this chunk's (dead since products 4 / 7): the next trip starts on registers.
 #pragma unroll 1
     for (int ch = c_begin; ch < c_end; ++ch) {
       unsigned char* cur = lds + buf * X_BUF_BYTES;
@@ -242,8 +249,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
       const float* pgn = c2.g;
       const float* pxn = c2.x;
       u32x4 sh, sm, sl;
-      Cut3 ce{0u, 0u, 0u};
-      float cs = 0.f, cr = 0.f;
+      Cut3 ce{0u, 0u, 0u}, co{0u, 0u, 0u};
+      float r1 = 0.f, vv = 0.f, cs = 0.f, cr = 0.f;
+      f32x4 rsv = {0.f, 0.f, 0.f, 0.f};
       static_for<144>([&](auto nn) {
         constexpr int n = decltype(nn)::value, s = n >> 4, idx = n & 15, a = idx >> 2, b = idx & 3;
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[X9_PA[s]][a], Bf[X9_PB[s]][b], acc[a][b], 0, 0, 0);
@@ -252,66 +260,59 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
           read_plane(I0{}, cur);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr ((n & 1) == 1 && n < 72) {           // load q of chunk ch + 2: 16 rows of G, 16 rows of X, sigma of the 16 rows
-          constexpr int q = n >> 1;
-          if constexpr (q < 16) { xload1(gn[q], (unsigned)tid * 4u, pgn); pgn += c2.ldg; }
-          else if constexpr (q < 32) { xload1(xn[q - 16], (unsigned)tid * 4u, pxn); pxn += c2.ldx; }
-          else xload4(rsn[q - 32], 0u, c2.rs + 4 * (q - 32));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (n < 96 && n % 3 == 0) {             // element e of the staged chunk is cut behind MFMA 3 e
-          constexpr int e = n / 3, op = e >> 4, j = e & 15, pos = j & 7;
-#if X9_EXP & 4
-          const Cut3 c{__float_as_uint(op ? xc[j] : gc[j]), 0u, 0u};
-#else
-          const Cut3 c = cut3(op ? xc[j] : gc[j]);
-#endif
-          if constexpr ((pos & 1) == 0) {
-            ce = c;
+        if constexpr (n < 124) {
+          constexpr int grp = n / 31, r = n % 31;            // k group grp = (operand grp / 2, rows 8 (grp % 2) ..): 4 pairs x 7 gaps + 3 writes
+          if constexpr (r < 28) {
+            constexpr int pr = r / 7, slot = r % 7, e = 8 * grp + 2 * pr + (slot >= 3 ? 1 : 0), op = e >> 4, j = e & 15;
+            float& v = op ? xc[j] : gc[j];
+            if constexpr (slot == 0 || slot == 3) {          // first half of the cut: h, and what is left
+              xwait<35>();
+              Cut3& c = slot == 0 ? ce : co;
+              take_landed(v, c.h, vv);
+              r1 = vv - __uint_as_float(c.h);
+              if constexpr (op == 0) cs += vv;
+            } else if constexpr (slot == 1 || slot == 4) {   // second half: m and l (both subtractions are exact)
+              Cut3& c = slot == 1 ? ce : co;
+              c.m = __float_as_uint(r1) & 0xffff0000u;
+              c.l = __float_as_uint(r1 - __uint_as_float(c.m));
+              if constexpr (op == 0) {
+                if constexpr ((j & 3) == 0) { xwait<31>(); take_landed(rsc[j >> 2], rsv); }
+                cr += vv * rsv[j & 3];
+              }
+            } else if constexpr (slot == 2 || slot == 5) {   // the register is free: row j of chunk ch + 2 (and the sigma quad behind row 4 q + 3)
+              if constexpr (op == 0) {
+                xload1(v, (unsigned)tid * 4u, pgn); pgn += c2.ldg;
+                if constexpr ((j & 3) == 3) xload4(rsc[j >> 2], 0u, c2.rs + (j & ~3));
+              } else {
+                xload1(v, (unsigned)tid * 4u, pxn); pxn += c2.ldx;
+              }
+            } else {                                         // the pair's dword of each plane
+              sh[pr] = pack_hi(ce.h, co.h); sm[pr] = pack_hi(ce.m, co.m); sl[pr] = pack_hi(ce.l, co.l);
+            }
           } else {
-            sh[pos >> 1] = pack_hi(ce.h, c.h); sm[pos >> 1] = pack_hi(ce.m, c.m); sl[pos >> 1] = pack_hi(ce.l, c.l);
+            constexpr int pl = r - 28;
+            unsigned char* p = oth + (grp >> 1) * X_OP_BYTES + ((grp & 1) * XT + tid) * 16 + pl * X_PLANE_BYTES;
+            *reinterpret_cast<u32x4*>(p) = pl == 0 ? sh : pl == 1 ? sm : sl;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (n < 96 && n >= 21 && (n - 21) % 24 < 3) {      // group (op, kg) is complete behind MFMA 21 + 24 g: its planes, one per MFMA
-          constexpr int g = (n - 21) / 24, pl = (n - 21) % 24;
-          unsigned char* p = oth + (g >> 1) * X_OP_BYTES + ((g & 1) * XT + tid) * 16 + pl * X_PLANE_BYTES;
-#if !(X9_EXP & 2)
-          *reinterpret_cast<u32x4*>(p) = pl == 0 ? sh : pl == 1 ? sm : sl;
-#else
-          (void)p;
-#endif
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (n == 111) {
+        if constexpr (n == 124) {
           __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (n == 112) {
+        if constexpr (n == 125) {
           read_plane(I2{}, oth);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (s == 7) {                       // column sums of the staged chunk: one row per MFMA
-          cs += gc[idx]; cr += gc[idx] * rsc[idx >> 2][idx & 3];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (s == 8) {                       // chunk ch + 2 has had the whole trip to land: it becomes the staged chunk
-          if constexpr (idx == 0) {
-            read_plane(I1{}, oth);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < XRC; ++j) asm volatile("" : "+v"(gn[j]), "+v"(xn[j]));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rsn[q]));
-          }
-          gc[idx] = gn[idx]; xc[idx] = xn[idx];
-          if constexpr (idx < 4) rsc[idx] = rsn[idx];
+        if constexpr (n == 128) {
+          read_plane(I1{}, oth);
           __builtin_amdgcn_sched_barrier(0);
         }
       });
       bsum += cs * c1.fb; rsum += cr * c1.fr;
       buf ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the re-loads of the last trip: nothing uses them)
   }
 
   // ---- partial tile store: partial[split][o][i] (zeros when the slice was empty: the reduction sums every split)

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Build-time guard for the inline-asm kernels (linear_wide_kernel.h, linear_chain_kernel.h, wgrad_wide.hip).
+"""Build-time guard for the inline-asm kernels (linear_wide_kernel.h, linear_chain_kernel.h, wgrad_wide.hip, wgrad_x9.hip).
 
 Their operand loads are issued by inline asm long before use, so the compiler does not know that those registers are "in
 flight": a register copy or spill it inserts between such a load and the s_waitcnt that lands it reads garbage (seen once:
 wrong Y2 rows in the first 8 rows of every tile when deferred stores pushed the CHAIN kernel over 256 VGPRs).  This tool
 disassembles each kernel and scans it linearly:
-  * a VGPR becomes in flight when a global_load_* / ds_read_* writes it and lands at the next s_waitcnt with vmcnt(0)
-    (global) / lgkmcnt(0) (LDS) - partial counts are ignored, which only makes the check stricter;
+  * a VGPR becomes in flight when a global_load_* / ds_read_* writes it and lands at the s_waitcnt that covers it: vector-memory
+    loads retire in order, so vmcnt(N) lands all but the N newest (wgrad_x9_kernel keeps a rolling window of loads in flight);
+    LDS reads land at lgkmcnt(0) only - partial counts are ignored there, which only makes the check stricter;
   * v_mov_b32 / v_accvgpr_write_b32 / scratch_store / v_writelane reading an in-flight VGPR is a violation;
   * any scratch usage is a violation;
   * a vector-memory instruction that reads an SGPR (descriptor, offset, base) which v_readlane / v_readfirstlane wrote fewer
@@ -26,7 +27,7 @@ import sys
 import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
-KERNELS = re.compile(r"linear_wide_kernel|linear_chain_kernel|wgrad_wide_kernel")
+KERNELS = re.compile(r"linear_wide_kernel|linear_chain_kernel|wgrad_wide_kernel|wgrad_x9_kernel")
 
 
 def regs(tok):
@@ -47,6 +48,7 @@ def sregs(tok):
 
 def scan(code, no_agpr_moves=False):
     inflight_g, inflight_l, bad = set(), set(), []
+    gqueue = []                         # destination registers of the vector-memory loads in flight, oldest first
     mfma_dst, mfma_wait = set(), 0      # result registers of the most recent MFMA and the wait states seen since it issued
     valu_sgpr = {}                      # SGPR written by the vector ALU (v_readlane / v_readfirstlane) -> wait states since
     for n, line in enumerate(code):
@@ -94,13 +96,21 @@ def scan(code, no_agpr_moves=False):
         if mfma_dst and not op.startswith("s_") and not op.startswith("ds_") and not op.startswith("buffer_") and not op.startswith("global_"):
             mfma_wait += 1
         if op == "s_waitcnt":
-            if "vmcnt(0)" in rest:
+            m = re.search(r"vmcnt\((\d+)\)", rest)
+            if m:
+                # vector-memory loads retire in order: vmcnt(N) lands all but the N newest (stores also count, which only makes this
+                # stricter: they are not in the queue here, so fewer loads are taken to have landed than really have)
+                keep = int(m.group(1))
+                gqueue[:] = gqueue[len(gqueue) - keep:] if keep else []
                 inflight_g.clear()
+                for d in gqueue:
+                    inflight_g.update(d)
             if "lgkmcnt(0)" in rest:
                 inflight_l.clear()
             continue
         if op.startswith("global_load") or op.startswith("buffer_load"):
             inflight_g |= regs(ops[0])
+            gqueue.append(regs(ops[0]))
             continue
         if op.startswith("ds_read"):
             inflight_l |= regs(ops[0])
@@ -119,6 +129,8 @@ def scan(code, no_agpr_moves=False):
             d = regs(ops[0])
             inflight_g -= d
             inflight_l -= d
+            for q in gqueue:
+                q -= d
     return bad
 
 
@@ -143,7 +155,7 @@ def check(hipcc, src, inc):
 def main():
     hipcc, csrc = sys.argv[1], sys.argv[2]
     files = sys.argv[3:] or [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))
-                             if re.match(r"(linear_wide_inst_|linear_chain_inst_|wgrad_wide).*\.hip$", f)]
+                             if re.match(r"(linear_wide_inst_|linear_chain_inst_|wgrad_wide|wgrad_x9).*\.hip$", f)]
     inc = os.path.join(csrc, "..", "..", "include")
     with ThreadPoolExecutor(max_workers=8) as ex:
         results = list(ex.map(lambda f: check(hipcc, f, inc), files))
