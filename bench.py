@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense FP32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense BF16 matrix peak (v_mfma_f32_32x32x16_bf16: 2027 sustained, scratch/mfma/bf16x6.hip)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -110,6 +111,7 @@ def roofline_of(rep, prof_steps):
     tot_ms = sum(e["total_ms"] for e in fams)
     tot_fl = sum(e["flops"] for e in fams)
     traffic, traffic_src = None, "profiles/pmc_summary.json is missing"
+    doc, meta, here = {}, {}, None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 --pmc passes (a STORED profile value, not measured in this run)
         with open(pmc) as f:
@@ -130,9 +132,27 @@ def roofline_of(rep, prof_steps):
                                "library; launch-weighted mean over the family's instantiations)")
             else:
                 traffic_src = "null: no counter rows for the dominant family in profiles/pmc_summary.json"
+    # roofline.frac: the dominant family's launch duration from the committed rocprofv3 --kernel-trace pass when it was taken from THIS build
+    # of the kernels (same source hash), the live HIP-event brackets otherwise - and the line says which
+    frac_source = "live HIP-event brackets around the launches of this run's instrumented steps"
+    ach_events = ach
+    if os.path.exists(pmc) and meta.get("kernel_source_sha256") == here:
+        per = [(doc[n]["trace_avg_us"], e["flops"] / e["calls"], e["calls"]) for e in rep for n in [e["name"].split(" x")[0]]
+               if kernel_family(n) == top["name"] and n in doc and doc[n].get("trace_avg_us")]
+        if per and sum(c for _, _, c in per) == top["calls"]:
+            ach = sum(f * c for _, f, c in per) / sum(us * 1e-6 * c for us, _, c in per) / 1e12
+            frac_source = (f"rocprofv3 --kernel-trace average launch durations of profiles/ (git {meta.get('git', '?')}, same kernel sources as the loaded "
+                           f"library) x this run's per-launch algorithmic FLOPs; live event brackets of this run give {ach_events:.1f} TFLOP/s")
     single = max((e for e in rep if e["flops"] > 0 and e["total_ms"] > 0.02 * tot_ms), key=tf, default=None)
     return {"bound": "mfma", "kernel": top["name"], "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "frac_source": frac_source, "achieved_live_events": ach_events,
+            "traffic": traffic, "traffic_source": traffic_src,
+            # two matrix paths in the step: the N-row layers run v_mfma_f32_32x32x2_f32 (the FP32-MFMA roof above); the 256 x 256 weight
+            # gradients form their fp32 products EXACTLY from three bf16 pieces per operand on the BF16 matrix cores (wgrad_x9_kernel:
+            # nine v_mfma_f32_32x32x16_bf16 piece products per fp32 product, fp32 accumulation) - its fp32-equivalent rate is bounded by
+            # BF16_MFMA_PEAK / 9 and by HBM, not by the FP32-MFMA peak
+            "matrix_paths": {"fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "bf16x9_fp32_equivalent_peak_tflops": BF16_MFMA_PEAK_TFLOPS / 9.0,
+                             "bf16x9_kernels": sorted({kernel_family(e["name"]) for e in rep if "x9" in e["name"]})},
             "share_of_step_kernel_time": top["total_ms"] / tot_ms,
             "avg_launch_us": 1e3 * top["total_ms"] / top["calls"], "launches_per_step": top["calls"] / prof_steps,
             "algorithmic_gflop_per_launch": top["flops"] / top["calls"] / 1e9,
@@ -299,6 +319,8 @@ def main():
             "executed_tflop_per_step": None if executed is None else executed / 1e12,
             "whole_step_tflops_executed": None if executed is None else executed * steps_per_s / 1e12,
             "whole_step_frac_executed": None if executed is None else executed * steps_per_s / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+            "whole_step_frac_note": "fp32-equivalent FLOPs of the whole step against the FP32-MFMA peak; since round 4 the 256 x 256 weight gradients "
+                                    "(33 % of those FLOPs) run on the BF16 matrix cores (bf16x9), which that peak does not bound",
             "algorithmic_tflop_per_step": flop / 1e12,
             "algorithmic_tflop_note": "SURVEY 8(d) formula, incl. per-image-hoisted work the reference performs on every row",
             "whole_step_tflops": flop * steps_per_s / 1e12,

@@ -255,7 +255,12 @@ enum { ARDAE_MODEL_NO_CENTER = 1,
        /* kind 6: MNISTResConvAuxIPVAEClipped (--model auxresconv-clip / auxresconvct-clip, models/ivae/auxresconv2.py:71-72,91): the two
         * log-variance heads WITHOUT the 'spm4' clip, and z0 = mu0 + (std exp(lv0 / 2) + 1) eps0 (`min_std = 1.`).  A sampler call with noise
         * takes it as the unscaled draws (std = 1); a std = 0 pass is a RANDOM draw for this class: ardae_model_encode_hidden_raw */
-       ARDAE_MODEL_CLIPPED = 16 };
+       ARDAE_MODEL_CLIPPED = 16,
+       /* kinds 3 / 7 (MNISTAuxIPVAE / ToyAuxIPVAE): NormalDistribution.clip_logvar of the two Gaussian heads (models/reparam.py:17-41;
+        * constructor arguments clip_z0_logvar / clip_z_logvar, models/ivae/auxmnist.py:56-72,144-161) - a code per head:
+        * 0 none, 1 'hard' (clamp to [-4, 2]), 2 'softplus', 3 .. 8 'spm10' / 'spm6' / 'spm5' / 'spm4' / 'spm3' / 'spm2'
+        * (softplus(x + k) - k), 9 'tanh', 10 '2tanh'.  z0 head: flags bits 8-11, z head: bits 12-15. */
+       ARDAE_MODEL_CLIP_Z0_SHIFT = 8, ARDAE_MODEL_CLIP_Z_SHIFT = 12, ARDAE_MODEL_CLIP_MASK = 0xff00 };
 size_t ardae_model_param_floats(const ardae_model_desc* d);
 size_t ardae_model_packed_floats(const ardae_model_desc* d);
 /* mode 0: encode only; mode 1: vae_forward + vae_backward; mode 2: decode only (B = rows, nz = 1); mode 3: encode_pair */

@@ -62,6 +62,8 @@ class ModelCfg:
     do_center: bool = True       # residual-conv kinds: the trunk sees 2x - 1 (--model resconvct-res / auxresconvct) or x (resconv-res / auxresconv)
     clipped: bool = False        # "auxresconv" only: MNISTResConvAuxIPVAEClipped (--model auxresconv-clip / auxresconvct-clip, ivae/auxresconv2.py):
                                  # NO 'spm4' clip of the two log-variances and z0 = mu0 + (std exp(lv0 / 2) + 1) eps0 (`min_std=1.`, :91)
+    clip_z0: str = "none"        # "auxmnist" / "auxtoy": clip_z0_logvar / clip_z_logvar (ivae/auxmnist.py:144-161), the choices of
+    clip_z: str = "none"         # NormalDistribution.clip_logvar (models/reparam.py:17-41)
     enc_type: str = "res-wn-mlp"  # "resconv" only: the sampler head (models/ivae/resconv.py:101-116): 'mlp' (--model resconv / resconvct), 'res-wn-mlp'
                                  # (-res), 'res-mlp' (-res2), 'res-wn-mlp-lin' (-res3), 'res-mlp-lin' (-res4); n_layers = --model-n-layers
 
@@ -434,6 +436,24 @@ def resconv_trunk(c, p, x):
     return F.elu(res_linear(p, f"{tp}11.", h.reshape(h.size(0), 512), True))
 
 
+def clip_logvar(name, lv):
+    """NormalDistribution.clip_logvar (models/reparam.py:17-41; MIN_LOGVAR = -4, MAX_LOGVAR = 2 :7-8)."""
+    if name in (None, "none"):
+        return lv
+    if name == "hard":
+        return torch.min(torch.max(lv, -4. * torch.ones_like(lv)), 2. * torch.ones_like(lv))
+    if name == "softplus":
+        return F.softplus(lv)
+    if name.startswith("spm"):
+        k = float(name[3:])
+        return F.softplus(lv + k) - k
+    if name == "tanh":
+        return torch.tanh(lv)
+    if name == "2tanh":
+        return 2.0 * torch.tanh(lv)
+    raise ValueError(name)
+
+
 def spm4(lv):
     """NormalDistribution.clip_logvar with nonlinearity='spm4' (models/reparam.py:30-31)."""
     return F.softplus(lv + 4.) - 4.
@@ -522,7 +542,8 @@ def aux_encode(c: ModelCfg, p, x, noise, nz):
     already scaled by std (std = 0 -> zeros: z0 = mu0(x), z = mu(x, z0)).
       h0 = MLP(2x-1);  (mu0, lv0) = heads(h0);  z0 = mu0[b] + exp(lv0[b]/2) eps0         (per image -> per sample)
       h  = MLP(cat[2x-1, z0]);  (mu, lv) = heads(h);  z = mu + exp(lv/2) eps
-    (--model-clip-z0-logvar / --model-clip-z-logvar are 'none' in the shipped recipes: the log-variances are the plain Linear outputs.)"""
+    (--model-clip-z0-logvar / --model-clip-z-logvar are 'none' in the shipped recipes - argparse offers nothing else, ivae_ardae.py:67-72 -;
+    the classes' own clip_z0_logvar / clip_z_logvar arguments take every choice of NormalDistribution.clip_logvar: c.clip_z0 / c.clip_z.)"""
     eps0, eps = noise
     B = x.size(0)
     if c.kind == "auxconv":   # models/vae/auxconv.py:60-81,115-140: conv trunks in place of the MLPs, fc width 800
@@ -551,21 +572,21 @@ def aux_encode(c: ModelCfg, p, x, noise, nz):
         xs = x.reshape(B, c.input_dim)
         h0 = mlp(p, "encode.aux_encode.main.", xs, c.n_layers - 1, c.nonlin, True)
         mu0 = F.linear(h0, p["encode.aux_encode.reparam.mean_fn.weight"], p["encode.aux_encode.reparam.mean_fn.bias"])
-        lv0 = F.linear(h0, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"])
+        lv0 = clip_logvar(c.clip_z0, F.linear(h0, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"]))
         z0 = expand_rows(mu0, q) + torch.exp(0.5 * expand_rows(lv0, q)) * eps0
         h = mlp(p, "encode.encode.fc.", torch.cat([expand_rows(xs, q), z0], 1), c.n_layers - 1, c.nonlin, True)
         mu = F.linear(h, p["encode.encode.reparam.mean_fn.weight"], p["encode.encode.reparam.mean_fn.bias"])
-        lv = F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"])
+        lv = clip_logvar(c.clip_z, F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"]))
         z = expand_rows(mu, q) + torch.exp(0.5 * expand_rows(lv, q)) * eps
         return {"z": z, "h0": h0, "h": h, "z0": z0, "mu0": mu0, "lv0": lv0, "mu": mu, "lv": lv}
     xs = 2 * x.reshape(B, c.input_dim) - 1
     h0 = mlp(p, "encode.aux_encode.main.", xs, c.n_layers - 1, c.nonlin, True)
     mu0 = F.linear(h0, p["encode.aux_encode.reparam.mean_fn.weight"], p["encode.aux_encode.reparam.mean_fn.bias"])
-    lv0 = F.linear(h0, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"])
+    lv0 = clip_logvar(c.clip_z0, F.linear(h0, p["encode.aux_encode.reparam.logvar_fn.weight"], p["encode.aux_encode.reparam.logvar_fn.bias"]))
     z0 = expand_rows(mu0, nz) + torch.exp(0.5 * expand_rows(lv0, nz)) * eps0
     h = mlp(p, "encode.encode.fc.", torch.cat([expand_rows(xs, nz), z0], 1), c.n_layers - 1, c.nonlin, True)
     mu = F.linear(h, p["encode.encode.reparam.mean_fn.weight"], p["encode.encode.reparam.mean_fn.bias"])
-    lv = F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"])
+    lv = clip_logvar(c.clip_z, F.linear(h, p["encode.encode.reparam.logvar_fn.weight"], p["encode.encode.reparam.logvar_fn.bias"]))
     z = mu + torch.exp(0.5 * lv) * eps
     return {"z": z, "h0": h0, "h": h, "z0": z0, "mu0": mu0, "lv0": lv0, "mu": mu, "lv": lv}
 

@@ -62,7 +62,7 @@ def build_reference(net, mc, cc, pm, pc, dtype):
         model = net.ConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, noise_dim=mc.noise_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "auxmnist":   # ivae_ardae.py:455-466 with --model-clip-z0-logvar / --model-clip-z-logvar none
         model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
-                                  nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
+                                  nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar=mc.clip_z0, clip_z_logvar=mc.clip_z)
     elif mc.kind == "auxconv":   # ivae_ardae.py:467-478
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "resconv":   # ivae_ardae.py:359-370 (--model resconvct-res)
@@ -73,7 +73,7 @@ def build_reference(net, mc, cc, pm, pc, dtype):
                                          nonlinearity=mc.nonlin, do_center=mc.do_center)
     elif mc.kind == "auxtoy":   # ivae_ardae.py:443-454 (--model auxmlp) with --model-clip-z0-logvar / --model-clip-z-logvar none
         model = net.ToyAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
-                                nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
+                                nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar=mc.clip_z0, clip_z_logvar=mc.clip_z)
     elif mc.kind == "mnist":
         model = net.MNISTIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim,
                                num_hidden_layers=mc.n_layers, nonlinearity=mc.nonlin, enc_type="concat", z_dim=mc.z_dim)
@@ -475,6 +475,10 @@ def main():
     run_case(net, rutils, "tiny_auxmnist_grad_f64", aux_m, aux_c, aux_t, B=4, steps=1, dtype=f64, store_full=True)
     run_case(net, rutils, "tiny_auxmnist_grad", aux_m, aux_c, aux_t, B=4, steps=2, dtype=f32, store_full=True)
     run_iwae_case(net, "iwae_tiny_auxmnist", aux_m, B=3, k=16, dtype=f64)
+    # clip_z0_logvar / clip_z_logvar of the hierarchical MLP classes (NormalDistribution.clip_logvar, models/reparam.py:17-41; argparse only
+    # offers 'none', the constructors take every choice): one soft clip and one bounded one per fixture
+    import dataclasses
+    run_case(net, rutils, "tiny_auxmnist_clip", dataclasses.replace(aux_m, clip_z0="spm4", clip_z="2tanh"), aux_c, aux_t, B=4, steps=2, dtype=f32, store_full=True)
     # hierarchical conv model (--model auxconv, run_vae_dbmnist.sh "hierarchical conv"): oracle pin (its HIP path is not built yet)
     auxc_m = O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus")
     auxc_c = O.CdaeCfg("grad", 32, 1600, 64, 2)
@@ -520,6 +524,7 @@ def main():
     run_case(net, rutils, "tiny_auxtoy_grad_f64", atoy_m, atoy_c, atoy_t, B=4, steps=1, dtype=f64, store_full=True)
     run_case(net, rutils, "tiny_auxtoy_grad", atoy_m, atoy_c, atoy_t, B=4, steps=3, dtype=f32, store_full=True)
     run_iwae_case(net, "iwae_tiny_auxtoy", atoy_m, B=3, k=8, dtype=f64)
+    run_case(net, rutils, "tiny_auxtoy_clip", dataclasses.replace(atoy_m, clip_z0="hard", clip_z="softplus"), atoy_c, atoy_t, B=4, steps=2, dtype=f32, store_full=True)
     # --model auxresconv-clip / auxresconvct-clip (ivae_ardae.py:507-534): MNISTResConvAuxIPVAEClipped - unclipped log-variances, z0 keeps an
     # unscaled eps0 (min_std = 1), so the std = 0 calls of the loop are random draws and their eps0 are part of the fixture's noise
     clip_m = O.ModelCfg("auxresconv", 784, 100, 450, 32, 1, "elu", clipped=True)

@@ -81,6 +81,9 @@ class ModelDesc(ctypes.Structure):
 MODEL_NO_CENTER = 1      # ardae_model_desc.flags (residual-conv kinds: do_center=False)
 MODEL_HEAD_SHIFT = 1     # kind 5: sampler-head type in flags bits 1-3 (layout.RESCONV_HEADS)
 MODEL_CLIPPED = 16       # kind 6: MNISTResConvAuxIPVAEClipped (no 'spm4' clip, z0 keeps an unscaled eps0)
+# kinds 3 / 7: NormalDistribution.clip_logvar of the z0 / z heads (models/reparam.py:17-41; flags bits 8-11 / 12-15)
+LOGVAR_CLIP = {None: 0, "none": 0, "hard": 1, "softplus": 2, "spm10": 3, "spm6": 4, "spm5": 5, "spm4": 6, "spm3": 7, "spm2": 8, "tanh": 9, "2tanh": 10}
+MODEL_CLIP_Z0_SHIFT, MODEL_CLIP_Z_SHIFT = 8, 12
 
 
 # utils/models.py:14-32 (get_nonlinear_func): all seven names; 'csoftplus' = log(exp(x) + 1) is softplus (evaluated in its accurate form)

@@ -35,6 +35,7 @@ struct Lin {
 
 struct AuxLayout {
   int D, nd, h, zd, nl, act;
+  int clip0, clip1;               // NormalDistribution.clip_logvar codes of the z0 / z heads (ardae_hip.h: ARDAE_MODEL_CLIP_*), 0 = none
   bool toy;                       // kind 7
   std::vector<Lin> am, ef, dec;   // aux_encode.main, encode.fc, decode.main: nl Linear each (nl - 1 hidden + fc, all followed by act)
   Lin mean0, logvar0, mean, logvar, logit, logvarx;   // logit: decode.reparam.logit_fn, or (toy) mean_fn followed by logvarx = logvar_fn
@@ -47,7 +48,8 @@ struct AuxLayout {
     return q;
   }
   explicit AuxLayout(const ardae_model_desc& d)
-      : D(d.input_dim), nd(d.noise_dim), h(d.h_dim), zd(d.z_dim), nl(d.n_layers), act(d.act), toy(d.kind == 7) {
+      : D(d.input_dim), nd(d.noise_dim), h(d.h_dim), zd(d.z_dim), nl(d.n_layers), act(d.act),
+        clip0((d.flags >> ARDAE_MODEL_CLIP_Z0_SHIFT) & 15), clip1((d.flags >> ARDAE_MODEL_CLIP_Z_SHIFT) & 15), toy(d.kind == 7) {
     size_t off = 0;
     auto one = [&](int out, int in) {
       Lin l; l.out = out; l.in = in; l.w = off; off += (size_t)out * in; l.b = off; off += out;
@@ -101,6 +103,7 @@ size_t al64(size_t n) { return (n + 63) & ~size_t(63); }
 
 struct AuxWs {
   float *xs, *mu0, *lv0, *rb, *z0, *mu, *lv, *z, *zero;
+  float *lv0r, *lvr;                    // the heads' raw outputs when a log-variance clip is on (lv0 / lv then hold the clipped values)
   std::vector<float*> e, t, dcd;        // e[l] [B,h] (l = 1..nl), t[i] [R,h], dcd[l] [R,h]
   float *o, *o2, *rec_row, *pri_row;    // decoder logits (toy: mean, o2 = logvar) and row losses
   // backward
@@ -147,6 +150,8 @@ void carve(const AuxLayout& P, Bump& ws, int B, int nz, int mode, AuxWs& W) {
   for (int l = 1; l <= P.nl; ++l) W.t[l] = ws.take(R * h);
   W.mu = ws.take(R * P.zd); W.lv = ws.take(R * P.zd); W.z = ws.take(N * P.zd);
   W.zero = ws.take(R * P.nd + N * P.zd);
+  W.lv0r = P.clip0 ? ws.take((size_t)B * P.nd) : W.lv0;
+  W.lvr = P.clip1 ? ws.take(R * P.zd) : W.lv;
   if (mode == 0) return;
   W.dcd.assign(P.nl + 1, nullptr);
   for (int l = 1; l <= P.nl; ++l) W.dcd[l] = ws.take(N * h);
@@ -200,6 +205,36 @@ int grid_of(int64_t n) {
   return (int)(g < 4096 ? g : 4096);
 }
 }  // namespace
+// NormalDistribution.clip_logvar (models/reparam.py:17-41) on a head's raw output x: y = c(x), or (dy given) the backward dx = dy c'(x).
+// codes: 1 'hard' clamp to [MIN_LOGVAR, MAX_LOGVAR] = [-4, 2] (:7-8; torch.max / torch.min pass the gradient where x is strictly inside),
+// 2 'softplus', 3 .. 8 'spmK' = softplus(x + K) - K for K = 10, 6, 5, 4, 3, 2, 9 'tanh', 10 '2tanh'
+__global__ void logvar_clip_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ y, int64_t n, int code) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float v = x[e];
+  float f, d;
+  if (code == 1) {
+    f = fminf(fmaxf(v, -4.f), 2.f);
+    d = (v > -4.f && v < 2.f) ? 1.f : ((v == -4.f || v == 2.f) ? 0.5f : 0.f);      // (ties: torch.max / min split the gradient evenly)
+  } else if (code <= 8) {
+    const float k = code == 2 ? 0.f : code == 3 ? 10.f : code == 4 ? 6.f : code == 5 ? 5.f : code == 6 ? 4.f : code == 7 ? 3.f : 2.f;
+    const float u = v + k;
+    f = (u > 20.f ? u : log1pf(expf(u))) - k;
+    d = 1.f / (1.f + expf(-u));
+  } else {
+    const float t = tanhf(v), s = code == 9 ? 1.f : 2.f;
+    f = s * t;
+    d = s * (1.f - t * t);
+  }
+  y[e] = dy ? dy[e] * d : f;
+}
+int launch_logvar_clip(const float* x, const float* dy, float* y, int64_t n, int code, hipStream_t st) {
+  if (code == 0 || n == 0) return 0;
+  hipLaunchKernelGGL(logvar_clip_kernel, dim3(grid_of(n)), dim3(256), 0, st, x, dy, y, n, code);
+  ARDAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int ld_eps, int64_t rows, int cols, int rpg, float* out, hipStream_t st,
                        float min_std, const float* raw, int ld_raw) {
   hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_of(rows * cols)), dim3(256), 0, st, mu, lv, cols, eps, ld_eps, rows, cols, rpg, out, min_std, raw, ld_raw);
@@ -238,8 +273,9 @@ int sampler_fwd(const AuxLayout& P, const AuxPacked& K, const float* params, con
   {
     LinArgs A{}; A.bias = params + P.mean0.b; A.Y = W.mu0; A.ldY = P.nd;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.nd, W.e[nl], h, h, packed + K.mean0_f, A, st));
-    LinArgs A2{}; A2.bias = params + P.logvar0.b; A2.Y = W.lv0; A2.ldY = P.nd;
+    LinArgs A2{}; A2.bias = params + P.logvar0.b; A2.Y = W.lv0r; A2.ldY = P.nd;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, P.nd, W.e[nl], h, h, packed + K.logvar0_f, A2, st));
+    ARDAE_TRY(launch_logvar_clip(W.lv0r, nullptr, W.lv0, (int64_t)B * P.nd, P.clip0, st));
     LinArgs A3{}; A3.bias = params + P.ef[0].b; A3.Y = W.rb; A3.ldY = h;   // image half of the first encoder layer (+ its bias)
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, B, h, W.xs, P.D, P.D, packed + K.efx_f, A3, st));
   }
@@ -253,8 +289,9 @@ int sampler_fwd(const AuxLayout& P, const AuxPacked& K, const float* params, con
   {
     LinArgs A{}; A.bias = params + P.mean.b; A.Y = W.mu; A.ldY = P.zd;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.t[nl], h, h, packed + K.mean_f, A, st));
-    LinArgs A2{}; A2.bias = params + P.logvar.b; A2.Y = W.lv; A2.ldY = P.zd;
+    LinArgs A2{}; A2.bias = params + P.logvar.b; A2.Y = W.lvr; A2.ldY = P.zd;
     ARDAE_TRY(lin1(EPI_ACT, ACT_NONE, R, P.zd, W.t[nl], h, h, packed + K.logvar_f, A2, st));
+    ARDAE_TRY(launch_logvar_clip(W.lvr, nullptr, W.lv, (int64_t)R * P.zd, P.clip1, st));
   }
   if (P.toy) return launch_reparam_fwd(W.mu, W.lv, eps, lde, (int64_t)R * nz, P.zd, nz, W.z, st);      // q z's per stage row
   return launch_reparam_fwd(W.mu, W.lv, eps, lde, R, P.zd, 1, W.z, st);
@@ -415,6 +452,8 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
     ARDAE_TRY(launch_segment_sum(W.dlv, P.zd, R, nzs, P.zd, 1.0f, W.dlv_s, P.zd, st));
     dmu = W.dmu_s; dlv = W.dlv_s;
   }
+  // through the z head's log-variance clip: d lv_raw = d lv c'(lv_raw) (in place; one value per stage row)
+  ARDAE_TRY(launch_logvar_clip(W.lvr, dlv, const_cast<float*>(dlv), (int64_t)R * P.zd, P.clip1, st));
   {
     LinArgs A{}; A.M = R; A.Nout = h; A.nsrc = 2; A.act = act; A.S = W.t[nl]; A.ldS = h; A.Y = W.dt[nl]; A.ldY = h;
     A.src[0].x = dmu; A.src[0].ld = P.zd; A.src[0].K = P.zd; A.src[0].wp = packed + K.mean_b;
@@ -434,6 +473,7 @@ int aux_model_vae_backward(const ardae_model_desc& d, const float* params, const
   ARDAE_TRY(launch_reparam_bwd(W.dz0, W.z0, W.mu0, R, P.nd, nzs, W.dlv0r, st));
   ARDAE_TRY(launch_segment_sum(W.dz0, P.nd, B, nzs, P.nd, 1.0f, W.dmu0, P.nd, st));
   ARDAE_TRY(launch_segment_sum(W.dlv0r, P.nd, B, nzs, P.nd, 1.0f, W.dlv0, P.nd, st));
+  ARDAE_TRY(launch_logvar_clip(W.lv0r, W.dlv0, W.dlv0, (int64_t)B * P.nd, P.clip0, st));      // ... and through the z0 head's
   {
     LinArgs A{}; A.M = B; A.Nout = h; A.nsrc = 2; A.act = act; A.S = W.e[nl]; A.ldS = h; A.Y = W.de[nl]; A.ldY = h;
     A.src[0].x = W.dmu0; A.src[0].ld = P.nd; A.src[0].K = P.nd; A.src[0].wp = packed + K.mean0_b;

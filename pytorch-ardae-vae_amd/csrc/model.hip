@@ -93,8 +93,12 @@ int desc_ok(const ardae_model_desc* d) {
   ARDAE_CHECK_ARG(d->kind >= 0 && d->kind <= 7,
                   "model: kind must be 0 (MNISTIPVAE), 1 (ToyIPVAE concat), 2 (ConvIPVAE), 3 (MNISTAuxIPVAE), 4 (MNISTConvAuxIPVAE), 5 (ResConvIPVAE) or "
                   "6 (MNISTResConvAuxIPVAE) or 7 (ToyAuxIPVAE)");
-  ARDAE_CHECK_ARG((d->flags & ~(ARDAE_MODEL_NO_CENTER | ARDAE_MODEL_HEAD_MASK | ARDAE_MODEL_CLIPPED)) == 0 && ((d->kind == 5 || d->kind == 6) || d->flags == 0),
-                  "model: unknown flags %d (ARDAE_MODEL_NO_CENTER / the sampler-head bits / ARDAE_MODEL_CLIPPED exist for the residual-conv kinds 5 / 6 only)", d->flags);
+  ARDAE_CHECK_ARG((d->flags & ~(ARDAE_MODEL_NO_CENTER | ARDAE_MODEL_HEAD_MASK | ARDAE_MODEL_CLIPPED | ARDAE_MODEL_CLIP_MASK)) == 0 &&
+                      ((d->kind == 5 || d->kind == 6) ? (d->flags & ARDAE_MODEL_CLIP_MASK) == 0
+                                                      : ((d->kind == 3 || d->kind == 7) ? (d->flags & ~ARDAE_MODEL_CLIP_MASK) == 0 : d->flags == 0)),
+                  "model: unknown flags %d (ARDAE_MODEL_NO_CENTER / the sampler-head bits / ARDAE_MODEL_CLIPPED: residual-conv kinds 5 / 6 only; "
+                  "the log-variance clip codes: kinds 3 / 7 only)", d->flags);
+  ARDAE_CHECK_ARG(((d->flags >> ARDAE_MODEL_CLIP_Z0_SHIFT) & 15) <= 10 && ((d->flags >> ARDAE_MODEL_CLIP_Z_SHIFT) & 15) <= 10, "model: unknown log-variance clip code");
   if ((d->kind == 5 || d->kind == 6)) {
     ARDAE_CHECK_ARG(d->input_dim == 784 && d->noise_dim >= 1 && d->z_dim >= 1 && d->h_dim >= 1 && d->act == ACT_ELU && (d->kind == 6 || (d->n_layers >= 1 && d->n_layers <= 4)),
                     "model: the residual-conv models are 28x28x1, ELU, and (kind 5) 1 .. 4 hidden layers in the sampler head");

@@ -360,6 +360,16 @@ class ImplicitPosteriorVAE(FlatParamModule):
         self._note_packed()
         return self._packed
 
+    def _set_logvar_clips(self, clip_z0_logvar, clip_z_logvar):
+        """clip_z0_logvar / clip_z_logvar of the hierarchical MLP models (ivae/auxmnist.py:144-161: 'none' -> None; the choices are
+        NormalDistribution.clip_logvar's, models/reparam.py:17-41; any other name leaves the log-variance as it is there, and is refused here)."""
+        for c in (clip_z0_logvar, clip_z_logvar):
+            if c not in L.LOGVAR_CLIP:
+                raise NotImplementedError(f"clip_logvar {c!r}: models/reparam.py:17-41 knows {sorted(k for k in L.LOGVAR_CLIP if k)}")
+        self.clip_z0_logvar = None if clip_z0_logvar == "none" else clip_z0_logvar
+        self.clip_z_logvar = None if clip_z_logvar == "none" else clip_z_logvar
+        self._flag_extra = (L.LOGVAR_CLIP[clip_z0_logvar] << L.MODEL_CLIP_Z0_SHIFT) | (L.LOGVAR_CLIP[clip_z_logvar] << L.MODEL_CLIP_Z_SHIFT)
+
     def _x(self, input):
         self._require_gpu(input)
         return _f32c(input).view(input.size(0), self.input_dim)
@@ -536,19 +546,18 @@ class ConvIPVAE(ImplicitPosteriorVAE):
 
 class MNISTAuxIPVAE(ImplicitPosteriorVAE):
     """models/ivae/auxmnist.py::ImplicitPosteriorVAE (`--model auxmnist`, the shipped "hierarchical mlp" recipe): AuxEncoder -> z0 ->
-    SimpleEncoder -> z, both Gaussian reparameterisations, `enc_type='simple'`, no log-variance clipping.  A sampler call takes two draws;
+    SimpleEncoder -> z, both Gaussian reparameterisations, `enc_type='simple'`; `clip_z0_logvar` / `clip_z_logvar`: the `clip_logvar` choices of
+    models/reparam.py:17-41 ('hard', 'softplus', 'spm10' .. 'spm2', 'tanh', '2tanh'; 'none' in the shipped recipe).  A sampler call takes two draws;
     `noise=` accepts the pair (eps0 [rows, noise_dim], eps [rows, z_dim]) or one [rows, noise_dim + z_dim] tensor."""
     _kind = "auxmnist"
     _enc_types = ("simple",)
 
     def __init__(self, energy_func=normal_energy_func, input_dim=784, noise_dim=100, h_dim=300, z_dim=32, nonlinearity="softplus",
                  num_hidden_layers=2, enc_type="simple", clip_z0_logvar=None, clip_z_logvar=None, do_xavier=True):
-        for c in (clip_z0_logvar, clip_z_logvar):
-            if c not in (None, "none"):
-                raise NotImplementedError("log-variance clipping (the shipped recipes pass 'none')")
         if enc_type != "simple":
             raise NotImplementedError                     # ivae/auxmnist.py:72-73
-        self.do_xavier, self.clip_z0_logvar, self.clip_z_logvar = do_xavier, None, None
+        self.do_xavier = do_xavier
+        self._set_logvar_clips(clip_z0_logvar, clip_z_logvar)
         super().__init__(energy_func, input_dim, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, "none", enc_type)
 
 
@@ -562,12 +571,9 @@ class ToyAuxIPVAE(ImplicitPosteriorVAE):
 
     def __init__(self, energy_func=normal_energy_func, input_dim=2, noise_dim=2, h_dim=64, z_dim=2, nonlinearity="tanh", num_hidden_layers=1,
                  init="gaussian", enc_type="simple", clip_z0_logvar=None, clip_z_logvar=None):
-        for c in (clip_z0_logvar, clip_z_logvar):
-            if c not in (None, "none"):
-                raise NotImplementedError("log-variance clipping (the shipped recipes pass 'none')")
         if enc_type != "simple":
             raise NotImplementedError                     # ivae/auxtoy.py:70-71
-        self.clip_z0_logvar, self.clip_z_logvar = None, None
+        self._set_logvar_clips(clip_z0_logvar, clip_z_logvar)
         super().__init__(energy_func, input_dim, noise_dim, h_dim, z_dim, nonlinearity, num_hidden_layers, init, enc_type)
 
     @staticmethod

@@ -25,6 +25,9 @@ CASES = {
     "tiny_auxmnist_grad": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, True),
     # --model auxmlp (ToyAuxIPVAE, ivae_ardae.py:443-454): q z0's x q z's per image (nz_cdae 16 = 4 x 4), Gaussian decoder, tanh
     "tiny_auxtoy_grad": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, True),
+    # clip_z0_logvar / clip_z_logvar of the two hierarchical MLP classes (NormalDistribution.clip_logvar, models/reparam.py:17-41; round 4)
+    "tiny_auxmnist_clip": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus", clip_z0="spm4", clip_z="2tanh"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, True),
+    "tiny_auxtoy_clip": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh", clip_z0="hard", clip_z="softplus"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, True),
     # the shipped "hierarchical conv" recipe's model family (run_vae_dbmnist.sh --model auxconv, hidden1a context of 1600 columns)
     "auxconv_b4_nz8": (O.ModelCfg("auxconv", 784, 100, 800, 32, 1, "softplus"), O.CdaeCfg("grad", 32, 1600, 64, 2), 8, False),
     # the shipped "implicit resconv" / "hierarchical resconv" recipes' model families (--model resconvct-res / auxresconvct, ELU,
@@ -81,10 +84,10 @@ def build(mc, cc):
         model = net.MNISTConvAuxIPVAE(input_height=28, input_channels=1, z0_dim=mc.noise_dim, z_dim=mc.z_dim, nonlinearity=mc.nonlin)
     elif mc.kind == "auxtoy":
         model = net.ToyAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
-                                nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
+                                nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar=mc.clip_z0, clip_z_logvar=mc.clip_z)
     elif mc.kind == "auxmnist":
         model = net.MNISTAuxIPVAE(input_dim=mc.input_dim, noise_dim=mc.noise_dim, h_dim=mc.h_dim, num_hidden_layers=mc.n_layers,
-                                  nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar="none", clip_z_logvar="none")
+                                  nonlinearity=mc.nonlin, enc_type="simple", z_dim=mc.z_dim, clip_z0_logvar=mc.clip_z0, clip_z_logvar=mc.clip_z)
     elif mc.kind == "conv":
         model = net.ConvIPVAE(input_height=28, input_channels=1, z_dim=mc.z_dim, noise_dim=mc.noise_dim, nonlinearity=mc.nonlin)
     else:
@@ -253,7 +256,8 @@ def test_engine_step_production_kernels_vs_oracle(kind):
     assert_update_close(model.flat_params().cpu(), before_m, ref_m, "model update")
 
 
-@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad", "tiny_auxtoy_grad", "tiny_toy_tanh", "tiny_mnist_elu",
+@pytest.mark.parametrize("name", ["tiny_mnist_grad", "tiny_toy_grad", "tiny_mnist_res", "tiny_auxmnist_grad", "tiny_auxtoy_grad", "tiny_auxmnist_clip", "tiny_auxtoy_clip",
+                                  "tiny_toy_tanh", "tiny_mnist_elu",
                                   "tiny_mnist_leaky", "tiny_toy_relu_relu", "tiny_mnist_tanh_res", "tiny_mnist_swish", "tiny_toy_swish_res"])
 def test_vae_phase_grads_golden(golden_dir, name):
     mc, cc, nz, full, fx, pm, pc = load_case(golden_dir, name)
@@ -753,8 +757,9 @@ def test_aux_model_module_surface(golden_dir):
     assert rel(loss.item(), lr_.item()) < 1e-4 and rel(rec.item(), recr.item()) < 2e-5 and rel(pri.item(), prir.item()) < 2e-5
     for n, p in model.named_parameters():
         assert rel_l2(p.grad.cpu(), preq[n].grad) < 2e-4, n
+    net.MNISTAuxIPVAE(clip_z_logvar="spm4")                     # every choice of NormalDistribution.clip_logvar constructs (round 4) ...
     with pytest.raises(NotImplementedError):
-        net.MNISTAuxIPVAE(clip_z_logvar="spm4")
+        net.MNISTAuxIPVAE(clip_z_logvar="spm7")                 # ... names it does not know are refused (the reference would silently not clip)
 
 
 def test_toy_aux_model_module_surface_and_iwae(golden_dir):

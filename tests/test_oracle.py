@@ -19,6 +19,8 @@ CASES = {
     # --model auxmlp: ToyAuxIPVAE (q z0's x q z's per image: nz_cdae 16 = 4 x 4), Gaussian decoder, tanh, hidden1a context
     "tiny_auxtoy_grad": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, torch.float32),
     "tiny_auxtoy_grad_f64": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, torch.float64),
+    "tiny_auxmnist_clip": (O.ModelCfg("auxmnist", 24, 10, 48, 8, 2, "softplus", clip_z0="spm4", clip_z="2tanh"), O.CdaeCfg("grad", 8, 96, 64, 3), 8, torch.float32),
+    "tiny_auxtoy_clip": (O.ModelCfg("auxtoy", 2, 2, 32, 2, 2, "tanh", clip_z0="hard", clip_z="softplus"), O.CdaeCfg("grad", 2, 64, 64, 3), 16, torch.float32),
     # the other activations of get_nonlinear_func (utils/models.py:14-32): tanh = the class default of the reference's models and cDAEs,
     # relu = the default of --cdae-nonlin (mlp-grad: second-order terms vanish), elu, leaky_relu
     "tiny_toy_tanh": (O.ModelCfg("toy", 2, 10, 64, 2, 2, "tanh"), O.CdaeCfg("grad", 2, 2, 64, 3, "tanh"), 8, torch.float32),

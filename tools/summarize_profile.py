@@ -60,6 +60,10 @@ def main(src, dst_prefix):
             e["hbm_bytes_per_launch"] = 1024.0 * (2.0 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0))
         out[k] = e
     # bench.py looks kernels up by the template-argument form it prints; add those aliases
+    for k, (c, t) in agg.items():
+        e = out.setdefault(k, {})
+        e["trace_calls"] = c
+        e["trace_avg_us"] = t / 1e3 / c
     for k in list(out):
         m = re.match(r"(linear_kernel)<(.*)>", k)
         if m:
@@ -70,6 +74,7 @@ def main(src, dst_prefix):
             out["linear_wide_kernel<%s, %s, %s, %s, %d, %d>" % (a[0], a[1], a[2], a[3], a[4] == "true", a[5] == "true")] = out[k]
         if k.startswith("wgrad_wide_kernel<"):
             out["wgrad_wide_kernel<256x256>" if "4, 4, 2" in k else "wgrad_wide_kernel<256x32>"] = out[k]
+    # (the kernel-trace pass's average durations - trace_avg_us - travel in the same hash-stamped file: bench.py's roofline.frac quotes them)
     # which build the counters belong to: bench.py quotes them only for a library built from the same kernel sources
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
