@@ -711,7 +711,8 @@ class ArdaeEngine:
         nparams = len(list(self.model.named_parameters()))
         return {"state_dict": {k: t.clone() for k, t in self.model.state_dict().items()},
                 "optimizer": {"state": self._opt_state(self.model, self.opt_m), "param_groups": [self.opt_m.param_group(nparams)]},
-                "engine": {"step_count": self.step_count, "cdae_steps": self.opt_c.steps, "rng_seed": rng.get_state()["seed"],
+                # state_version 2 (round 3 on): the device step block describes the COMING step (the last launch of a step advances it)
+                "engine": {"state_version": 2, "step_count": self.step_count, "cdae_steps": self.opt_c.steps, "rng_seed": rng.get_state()["seed"],
                            "rng_host_offset": rng.get_state()["offset"], "step_state": self.state.cpu().clone()}}
 
     def cdae_checkpoint(self):
@@ -763,6 +764,10 @@ class ArdaeEngine:
         if eng is not None:     # written by this engine: continue the same noise stream (the saved block already describes the coming step)
             rng.manual_seed(eng["rng_seed"], eng.get("rng_host_offset", rng.get_state()["offset"]))
             self.state.copy_(eng["step_state"].to(self.dev))
+            if int(eng.get("state_version", 1)) < 2:
+                # written before round 3: the block still described the step just DONE (t == step_count, that step's Philox offsets) -
+                # advance it once, or Adam's t would lag by one for good and the first resumed step would repeat the last step's noise
+                self.opt_m.advance(self.lib, self.RNG_STRIDE)
         else:                   # written by the reference / the module path: the optimisers' t, and Philox offsets this run has not used yet
             self.state.zero_()      # (a resumed run with an unchanged seed would otherwise replay the draws of steps 1..step_count)
             self.state[0] = self.RNG_STRIDE * self.step_count

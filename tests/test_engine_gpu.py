@@ -472,6 +472,19 @@ def test_engine_checkpoint_roundtrip_reference_format(tmp_path):
     eng_b.step(xs[4], xs[5])
     assert torch.equal(model_b.flat_params(), want_m) and torch.equal(cdae_b.flat_params(), want_c)
 
+    # a file written BEFORE the device step block described the coming step (no 'state_version': the block holds the step just done -
+    # t == step_count and that step's Philox offsets): on load the block is advanced once, and the run continues on the same bits
+    import copy
+    old_layout = copy.deepcopy(mck2)
+    del old_layout["engine"]["state_version"]
+    st = old_layout["engine"]["step_state"]                      # [rng offset, Adam t, (step size, sqrt bc2) as one packed int64, -]
+    st[0] -= net.ArdaeEngine.RNG_STRIDE; st[1] -= 1              # what the older layout stored after two steps
+    model_o, cdae_o, eng_o = fresh(False)
+    eng_o.load_checkpoints(old_layout, cck2)
+    assert eng_o.step_count == 2 and int(eng_o.state[1]) == 3 and int(eng_o.state[0]) == int(mck2["engine"]["step_state"][0])
+    eng_o.step(xs[4], xs[5])
+    assert torch.equal(model_o.flat_params(), want_m) and torch.equal(cdae_o.flat_params(), want_c)
+
     # interchangeable with the drop-in optimisers (and hence with the reference's utils.Adam / torch RMSprop layouts)
     model_c, cdae_c = build(mc, cc)
     model_c, cdae_c = model_c.to("cuda"), cdae_c.to("cuda")
