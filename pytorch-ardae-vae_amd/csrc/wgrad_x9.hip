@@ -75,7 +75,9 @@ __device__ __forceinline__ void take_landed(const f32x4& loaded, f32x4& copy) {
 
 // One value cut into its three bf16 pieces, as fp32 bit patterns whose low halves are zero: h = the top 16 bits of x (sign, exponent, 7
 // mantissa bits), m = the top 16 bits of x - h, l = x - h - m (at most 8 significant bits are left: its low half is zero by itself).
-// Both subtractions are exact, so h + m + l == x bit for bit; the pieces share x's sign.
+// Both subtractions are exact, so h + m + l == x bit for bit; the pieces share x's sign.  (Pieces that fall into the denormal range - |x| below
+// ~1e-30 - lose their low half here when l is a denormal: less than 2^-133 |other operand| per product, far below an fp32 underflow;
+// tests/test_abi.py::test_three_piece_cut_is_exact.)
 struct Cut3 { unsigned h, m, l; };
 __device__ __forceinline__ Cut3 cut3(float x) {
   Cut3 c;

@@ -216,3 +216,31 @@ def test_activation_names_follow_get_nonlinear_func():
     # the reference's class defaults (tanh) construct
     net.MLPGradCARDAE(input_dim=2, context_dim=2, h_dim=16, num_hidden_layers=1)
     net.ToyIPVAE(input_dim=2, noise_dim=2, h_dim=16, z_dim=2, enc_type="concat")
+
+
+def test_three_piece_cut_is_exact():
+    """csrc/wgrad_x9.hip::cut3, restated in numpy: h = the top 16 bits of x, m = the top 16 bits of x - h, l = x - h - m.  Both subtractions are
+    exact and h + m + l == x bit for bit for EVERY finite fp32 value (a million random bit patterns plus edge cases: all 24 significand bits
+    set, powers of two, tiny and huge magnitudes, zeros).  For |x| >= 2^-100 the remainder l has at most 8 significand bits - its low half is
+    zero by itself, i.e. it is a bf16 value as it stands and nothing is lost when the kernel keeps only its high half; below that (pieces in
+    the denormal range, |x| < ~1e-30) the kernel's l loses its low half when it is a denormal: less than 2^-133 in absolute terms, far below an
+    fp32 underflow."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 1 << 32, size=1 << 20, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 1.9999999, -1.9999999, 3.4e38, -3.4e38, 1.2e-38, 1e-30, 16777215.0, 0.1, 1.0 / 3.0], dtype=np.float32)
+    x = np.concatenate([x, edge])
+    hi = lambda v: (v.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    h = hi(x)
+    r1 = (x - h).astype(np.float32)
+    assert np.array_equal(r1.astype(np.float64), x.astype(np.float64) - h.astype(np.float64))          # exact
+    m = hi(r1)
+    l = (r1 - m).astype(np.float32)
+    assert np.array_equal(l.astype(np.float64), r1.astype(np.float64) - m.astype(np.float64))          # exact
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))
+    normal = np.abs(x) >= np.float32(2.0 ** -100)
+    assert np.all((l[normal].view(np.uint32) & np.uint32(0xffff)) == 0)                                 # l is a bf16 value as it stands
+    lost = np.abs(l.astype(np.float64) - hi(l).astype(np.float64))                                     # what keeping only l's high half drops
+    assert np.all(lost[normal] == 0) and np.all(lost < 2.0 ** -133)
