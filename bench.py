@@ -223,27 +223,59 @@ def main():
                            enc_type="concat", z_dim=32).to(dev)
     cdae = net.MLPGradCARDAE(input_dim=32, context_dim=32, std=1., h_dim=256, num_hidden_layers=3, nonlinearity="softplus",
                              noise_type="gaussian", enc_ctx=True, enc_input=True).to(dev)
-    eng = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=B, force_dp=force_dp and distributed)
-    net.manual_seed(42)                                   # one noise stream: every rank draws its rows of the global draw (engine._normal)
     g = torch.Generator(device="cpu").manual_seed(1234)
     pimg = ((torch.rand(784, generator=g) < 0.2).float() * 0.6 + 0.03).to(dev)
-    (xc,), xv = eng.input_buffers(1)                      # the binarisation kernel writes the engine's static batch buffers: step() copies nothing
     lib = L.lib()
     state = {"i": 0}
+    init_m, init_c = model.flat_params().clone(), cdae.flat_params().clone()
 
-    def one_step():
-        # dynamic binarisation on the device (datasets/mnist.py:36-40): two fresh batches per step
-        i = state["i"]; state["i"] += 1
-        L.check(lib.ardae_bernoulli(L.ptr(pimg), B, 784, L.ptr(xc), ctypes.c_uint64(1000 + rank), ctypes.c_uint64(2 * i), L.stream_ptr()))
-        L.check(lib.ardae_bernoulli(L.ptr(pimg), B, 784, L.ptr(xv), ctypes.c_uint64(1000 + rank), ctypes.c_uint64(2 * i + 1), L.stream_ptr()))
-        eng.step(xc, xv)
+    def make_engine(**kw):
+        with torch.no_grad():                             # (a second attempt starts from the same parameters)
+            model.flat_params().copy_(init_m); cdae.flat_params().copy_(init_c)
+        e = net.ArdaeEngine(model, cdae, net.TrainConfig(nz_cdae=NZ), batch_size=B, force_dp=force_dp and distributed, **kw)
+        net.manual_seed(42)                               # one noise stream: every rank draws its rows of the global draw (engine._normal)
+        state["i"] = 0
+        return e
 
     def barrier():
         if distributed:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        one_step()
+    # Several ranks: the step with its two RCCL all-reduces CAPTURED in the graphs first (`ardae_dp_allreduce_mean`; what one GPU can test
+    # of it is tested).  Should capturing a collective be refused on the machine at hand, every rank falls back - together: the outcome is
+    # agreed on with an all-reduce - to the form whose pieces all have run in the suite, graphs cut at the collectives with
+    # torch.distributed between them, and the line says so (`dp_fallback`).
+    dp_fallback = None
+    for attempt, kw in enumerate(({}, {"dp_comm": None}, {"dp_comm": None, "graph": False})):
+        eng = make_engine(**kw)
+        (xc,), xv = eng.input_buffers(1)                  # the binarisation kernel writes the engine's static batch buffers: step() copies nothing
+
+        def one_step():
+            # dynamic binarisation on the device (datasets/mnist.py:36-40): two fresh batches per step
+            i = state["i"]; state["i"] += 1
+            L.check(lib.ardae_bernoulli(L.ptr(pimg), B, 784, L.ptr(xc), ctypes.c_uint64(1000 + rank), ctypes.c_uint64(2 * i), L.stream_ptr()))
+            L.check(lib.ardae_bernoulli(L.ptr(pimg), B, 784, L.ptr(xv), ctypes.c_uint64(1000 + rank), ctypes.c_uint64(2 * i + 1), L.stream_ptr()))
+            eng.step(xc, xv)
+
+        err = None
+        try:
+            if knob("BENCH_INJECT_FAILURE", "") == str(attempt):      # rehearsal of the fallback (tests/test_dp_gpu.py)
+                raise RuntimeError("injected failure of attempt %d" % attempt)
+            for _ in range(args.warmup):                  # (the capture happens at the engine's third step)
+                one_step()
+            torch.cuda.synchronize()
+        except Exception as exc:                          # noqa: BLE001 - anything a refused capture can raise
+            if not distributed or attempt == 2:
+                raise
+            err = f"{type(exc).__name__}: {exc}"
+        if not distributed:
+            break
+        flag = torch.tensor([0.0 if err is None else 1.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if float(flag) == 0.0:
+            break
+        dp_fallback = f"attempt {attempt} ({kw or 'captured RCCL all-reduces'}) failed on some rank" + (f": {err}" if err else "")
+        sys.stderr.write(f"[bench.py rank {rank}] {dp_fallback}; falling back\n")
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -281,7 +313,7 @@ def main():
                        "torch_distributed": {"backend": str(torch.distributed.get_backend()), "world_size": torch.distributed.get_world_size()},
                        "rccl": None if seen is None else {"library": eng.comm.backend, "ranks": seen[0], "rank": seen[1], "device": seen[2],
                                                           "allreduce": "ardae_dp_allreduce_mean, captured in the step graphs"},
-                       "env": env_report}
+                       "dp_fallback": dp_fallback, "env": env_report}
     stats = eng.stats()
 
     # ---- live per-kernel timing (HIP events on the launch stream), separate from the throughput region

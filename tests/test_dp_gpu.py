@@ -241,6 +241,13 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["ranks"]["env"]["set_before_device_init"] is True and d["ranks"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert d["ranks"]["torch_distributed"] == {"backend": "gloo", "world_size": 2} and d["ranks"]["rccl"] is None
     assert d["config"]["workload"].startswith("EXPERIMENT (BENCH_GLOBAL_B=32)") and "batch 32," in d["metric"]
+    # the multi-rank fallback (a refused capture of the collectives): every rank fails attempt 0, all agree, attempt 1 runs and the line says so
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "3",
+                        "--no-cpu-baseline", "--prof-steps", "0"], env=dict(env, BENCH_INJECT_FAILURE="0"), capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d2 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "attempt 0" in d2["ranks"]["dp_fallback"] and d2["value"] > 0 and d["ranks"]["dp_fallback"] is None
     # a rank that fails must end the job with a non-zero status (here: a global batch that does not divide over the ranks)
     env_bad = dict(env, BENCH_GLOBAL_B="33")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
