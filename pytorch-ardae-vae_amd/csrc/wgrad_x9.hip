@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
     //   gap 0 also requests the chunk's h-plane fragments (first needed by product 3; l and m planes are in registers already);
     //   gap 124: s_barrier - chunk ch + 1 is complete in the other buffer, nobody reads this one any more;
     //   gap 125 / 128: its l- and m-plane fragments replace this chunk's (dead since products 4 / 7): the next trip starts on registers.
+    X9Chunk c1 = chunk_at(c_begin + 1);
 #pragma unroll 1
     for (int ch = c_begin; ch < c_end; ++ch) {
       unsigned char* cur = lds + buf * X_BUF_BYTES;
       unsigned char* oth = lds + (buf ^ 1) * X_BUF_BYTES;
-      const X9Chunk c1 = chunk_at(ch + 1);
       const X9Chunk c2 = chunk_at(ch + 2);
       const float* pgn = c2.g;
       const float* pxn = c2.x;
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x9_kernel(const WwBatchDev batch
       });
       bsum += cs * c1.fb; rsum += cr * c1.fr;
       buf ^= 1;
+      c1 = c2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the re-loads of the last trip: nothing uses them)
   }
