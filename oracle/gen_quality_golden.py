@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Oracle side of the IWAE-64 quality gate at BASELINE config #2 widths (test infrastructure).
 
-    python oracle/gen_quality_golden.py [--lr 3e-4] [--steps 2400] [--every 100] [--ema 0.99] [--seeds 2024 1 2 3] [--out tests/golden/quality_cfg2.npz]
+    python oracle/gen_quality_golden.py [--lr 3e-4] [--steps 2400] [--every 100] [--ema 0.99] [--seeds 2024 1 2 3 4 5 6 7] [--out tests/golden/quality_cfg2.npz]
 
 Trains the CPU oracle (the pinned restatement of ivae_ardae.py:707-846) on the synthetic four-prototype problem of
 tests/test_training_quality_gpu.py at config #2's widths (784 pixels, noise 100, h 256, z 32; cDAE mlp-grad h 256 L 3) with 32 images x 256
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2400)
     ap.add_argument("--every", type=int, default=100)
     ap.add_argument("--ema", type=float, default=0.99)
-    ap.add_argument("--seeds", type=int, nargs="+", default=[2024, 1, 2, 3])
+    ap.add_argument("--seeds", type=int, nargs="+", default=[2024, 1, 2, 3, 4, 5, 6, 7])
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "quality_cfg2.npz"))
     a = ap.parse_args()

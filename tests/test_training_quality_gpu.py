@@ -161,7 +161,8 @@ def test_iwae64_config2_widths_on_production_kernels(golden_dir):
 
     Oracle side: `tests/golden/quality_cfg2.npz`, written by `oracle/gen_quality_golden.py` (the CPU oracle - the pinned restatement of
     ivae_ardae.py:707-846 - trained for 2400 steps at lr 3e-4 on the batches this test regenerates from the same generator seeds, one run
-    per noise seed, IWAE-64 on 256 held-out images every 100 steps; 30 minutes of CPU per seed, which is why it travels as a fixture).
+    per noise seed, eight seeds, IWAE-64 on 256 held-out images every 100 steps; 30 minutes of CPU per seed, which is why it travels as a
+    fixture).
     Engine side: trained here, six seeds with its own Philox noise and one run on each of the first four ORACLE noise streams, injected.
 
     The statistic (round 4).  Single checkpoints of the RAW weights cannot carry a 0.2-nat gate: even on the plateau (from step ~1400) they
