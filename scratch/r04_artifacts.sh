@@ -11,7 +11,7 @@ for gb in 256 128 64; do
   BENCH_GLOBAL_B=$gb python bench.py --steps 200 --warmup 20 --no-cpu-baseline > "$O/bench_b$gb.json" 2> "$O/bench_b$gb.err"
 done
 echo "shards done"
-python scratch/bench_configs.py > "$R/gpurun_out/r04_configs.txt" 2> "$O/configs.err"
+python scratch/bench_configs.py 1 2 4 5 6 7 8 9 10 > "$R/gpurun_out/r04_configs.txt" 2> "$O/configs.err"
 echo "configs done"
 unset ARDAE_DEBUG_KNOBS
 bash scripts_profile.sh r04 > "$O/profile.log" 2>&1
