@@ -170,7 +170,7 @@ def test_iwae64_config2_widths_on_production_kernels(golden_dir):
     700 steps).  Evaluated on an exponential moving average of the weights instead (decay 0.99, updated every step: Polyak averaging, the
     evaluation mode the reference itself offers - `--weight-avg polyak`, ivae_ardae.py:560-565,646-647) the bound is smooth; the MEDIAN of
     its last five checkpoints (steps 2000 - 2400) differs by 0.1 - 0.2 nats between noise seeds of ONE trainer (standard deviation: oracle
-    0.19, engine 0.18).  That resolves the north star's tolerance:
+    0.22, engine 0.18).  That resolves the north star's tolerance:
       * the engine is not WORSE than the oracle by more than the north star's 0.2 nats: mean over seeds (engine, own noise) >= mean over
         seeds (oracle) - 0.2 (the one-sided check: a systematic loss of quality cannot hide in seed noise);
       * |difference of the two means| <= 0.2 + two standard errors of that difference (from the two trainers' seed-to-seed spreads);
@@ -181,9 +181,9 @@ def test_iwae64_config2_widths_on_production_kernels(golden_dir):
         the next ~300 steps; the engine run on seed 2024's noise had one at steps 2200 - 2400: -266.8 / -268.6 / -265.9 against -263.4
         before it.  Measured paired differences of the best checkpoints: -0.13 / -0.01 / +0.56 / +0.13 nats.)
       * both trainers have moved > 2400 nats from the initial model (-2708).
-    Measured (MI355X, round 4; medians of the five late checkpoints, four oracle seeds): oracle -263.56 / -263.28 / -263.61 / -263.24 (mean
-    -263.42); engine with its own noise -262.97 / -263.13 / -263.07 / -263.13 / -263.25 / -263.51 (mean -263.18: 0.25 +- 0.12 nats ABOVE
-    the oracle - both trainers still improve by ~0.15 nats per 100 steps there: the engine is level with the oracle of ~150 steps later)."""
+    Measured (MI355X, round 4; medians of the five late checkpoints, eight oracle seeds): oracle -263.56 / -263.28 / -263.61 / -263.24 / -263.07 /
+    -263.41 / -263.25 / -263.69 (mean -263.39, sd 0.22); engine with its own noise -262.97 / -263.13 / -263.07 / -263.13 / -263.25 / -263.51 (mean
+    -263.18: 0.21 +- 0.11 nats ABOVE the oracle - both trainers still improve by ~0.15 nats per 100 steps there: the engine is level with the oracle of ~150 steps later)."""
     import numpy as np
     from oracle.gen_quality_golden import MC as M2, CC as C2, B as B2, NZ as NZ2, K as K2, batches, eval_set
     fx = np.load(os.path.join(golden_dir, "quality_cfg2.npz"))
